@@ -1,0 +1,160 @@
+"""ctypes binding of the CPU oracle (oracle/libsd_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libsd_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("sd_oracle.cpp", "cv_leaves.h", "orb_pattern.inc", "frame_oracle.inc")]
+    srcs = [s for s in srcs if os.path.exists(s)]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libsd_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.orc_extractor_create.restype = C.c_void_p
+        _LIB.orc_extractor_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        _LIB.orc_extractor_destroy.argtypes = [C.c_void_p]
+        _LIB.orc_fast_atan2.restype = C.c_float
+        _LIB.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Extractor:
+    """Mirror of ORB_SLAM2::ORBextractor (include/ORBextractor.h:45-114) on numpy buffers."""
+
+    def __init__(self, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.L = lib()
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+        self.h = C.c_void_p(self.L.orc_extractor_create(nfeatures, scale_factor, nlevels, ini_th, min_th))
+        self.scale = np.zeros(nlevels, np.float32); self.inv_scale = np.zeros(nlevels, np.float32)
+        self.sigma2 = np.zeros(nlevels, np.float32); self.inv_sigma2 = np.zeros(nlevels, np.float32)
+        self.quota = np.zeros(nlevels, np.int32); self.umax = np.zeros(16, np.int32)
+        self.L.orc_extractor_tables(self.h, _p(self.scale), _p(self.inv_scale), _p(self.sigma2), _p(self.inv_sigma2),
+                                    _p(self.quota), _p(self.umax))
+
+    def __del__(self):
+        try:
+            self.L.orc_extractor_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_blur_taps(self, taps):
+        t = np.asarray(taps, np.uint16)
+        assert t.shape == (7,)
+        self.L.orc_extractor_set_blur_taps(self.h, _p(t))
+
+    def __call__(self, gray):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        cap = self.nfeatures + 64 * self.nlevels + 64
+        kp = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+        self.per_level = np.zeros(self.nlevels, np.int32); self.cand_per_level = np.zeros(self.nlevels, np.int32)
+        n = self.L.orc_extract(self.h, _p(gray), w, h, gray.strides[0], _p(kp), _p(desc), cap, _p(self.per_level),
+                               _p(self.cand_per_level))
+        assert n >= 0, "oracle capacity too small"
+        return kp[:n].copy(), desc[:n].copy()
+
+    def pyramid(self, level):
+        """Padded plane of mvImagePyramid[level] (19-px REFLECT_101 border) and its interior view."""
+        W, H = C.c_int(), C.c_int()
+        self.L.orc_pyramid_dims(self.h, level, C.byref(W), C.byref(H))
+        buf = np.zeros((H.value + 38, W.value + 38), np.uint8)
+        self.L.orc_pyramid_copy(self.h, level, _p(buf))
+        return buf
+
+    def blurred(self, level):
+        W, H = C.c_int(), C.c_int()
+        self.L.orc_pyramid_dims(self.h, level, C.byref(W), C.byref(H))
+        buf = np.zeros((H.value, W.value), np.uint8)
+        self.L.orc_blurred_copy(self.h, level, _p(buf))
+        return buf
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return lib().orc_descriptor_distance(_p(a), _p(b))
+
+
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw)
+    return dst
+
+
+def fast(img, threshold):
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = img.size // 4 + 16
+    out = np.zeros((cap, 3), np.int32)
+    n = lib().orc_fast(_p(img), img.shape[1], img.shape[0], img.strides[0], threshold, _p(out), cap)
+    return out[:n].copy()
+
+
+def fast_atan2(y, x):
+    return float(lib().orc_fast_atan2(float(y), float(x)))
+
+
+def gaussian7(img, taps=(18, 34, 48, 56, 48, 34, 18)):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros_like(img)
+    t = np.asarray(taps, np.uint16)
+    lib().orc_gaussian7(_p(img), img.shape[1], img.shape[0], img.strides[0], _p(out), out.strides[0], _p(t))
+    return out
+
+
+def cvt_gray(img, rgb_order):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w, c = img.shape
+    out = np.zeros((h, w), np.uint8)
+    lib().orc_cvt_gray(_p(img), w, h, img.strides[0], c, int(rgb_order), _p(out), w)
+    return out
+
+
+def depth_to_f32(depth_u16, factor):
+    d = np.ascontiguousarray(depth_u16, np.uint16)
+    out = np.zeros(d.shape, np.float32)
+    lib().orc_depth_to_f32(_p(d), d.shape[1], d.shape[0], d.shape[1], C.c_float(factor), _p(out))
+    return out
+
+
+def stereo_from_rgbd(kp, depth_f32, mbf):
+    kp = np.ascontiguousarray(kp); d = np.ascontiguousarray(depth_f32, np.float32)
+    n = len(kp)
+    ur = np.zeros(n, np.float32); dep = np.zeros(n, np.float32)
+    lib().orc_stereo_from_rgbd(_p(kp), n, _p(d), d.shape[1], d.shape[0], C.c_float(mbf), _p(ur), _p(dep))
+    return ur, dep
+
+
+def stereo_matches(exL, exR, kpL, descL, kpR, descR, mbf, fx):
+    kpL = np.ascontiguousarray(kpL); kpR = np.ascontiguousarray(kpR)
+    descL = np.ascontiguousarray(descL, np.uint8); descR = np.ascontiguousarray(descR, np.uint8)
+    n = len(kpL)
+    ur = np.zeros(n, np.float32); dep = np.zeros(n, np.float32); bd = np.zeros(n, np.int32)
+    nm = lib().orc_stereo_matches(exL.h, exR.h, _p(kpL), _p(descL), n, _p(kpR), _p(descR), len(kpR), C.c_float(mbf),
+                                  C.c_float(fx), _p(ur), _p(dep), _p(bd))
+    return ur, dep, bd, nm
