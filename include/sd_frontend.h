@@ -1,0 +1,142 @@
+/* sd_frontend.h — C ABI of the MI355X-native per-frame front end (libsd_frontend.so).
+ *
+ * Drop-in boundary for the hot path of li-guihai/slam-dynamic (an ORB-SLAM2 fork):
+ * ORBextractor, the Frame-side stereo/RGB-D association, the 256-bit Hamming matchers
+ * and the dynamic-point cull.  The reference has no FFI layer — its boundary is the C++
+ * class API in namespace ORB_SLAM2 — so every entry point below names the reference
+ * interface it replaces (file:line relative to the reference tree).  Plain pointers and
+ * sizes only; no OpenCV, torch or STL types.  All functions return an int status
+ * (SD_OK == 0, < 0 on error) and never throw or abort.  The reference-side bindings a
+ * maintainer would add are shown in INTEGRATION.md and in
+ * slam-dynamic_amd/host/ORBextractor.h (a header-only mirror of the class API).
+ *
+ * Device model: one process per GPU.  Pointers named d_* are device (HBM) pointers;
+ * `stream` is a hipStream_t passed as void* (NULL = the library's own stream).
+ */
+#ifndef SD_FRONTEND_H
+#define SD_FRONTEND_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SD_OK 0
+#define SD_ERR_INVALID (-1)     /* bad argument                                             */
+#define SD_ERR_NO_DEVICE (-2)   /* no HIP device / HIP runtime unusable (never a CPU fallback) */
+#define SD_ERR_HIP (-3)         /* a HIP call failed; see sd_last_error()                   */
+#define SD_ERR_CAPACITY (-4)    /* caller buffer too small                                  */
+#define SD_ERR_UNSUPPORTED (-5) /* geometry outside what the kernels were sized for         */
+#define SD_ERR_STATE (-6)       /* call sequence error (e.g. stereo before extract)         */
+
+/* Same 28-byte layout as cv::KeyPoint {Point2f pt; float size, angle, response; int octave, class_id;}
+ * so an adapter can memcpy into std::vector<cv::KeyPoint> (ORBextractor.h:59-61). */
+typedef struct sd_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} sd_keypoint;
+
+typedef struct sd_extractor sd_extractor; /* ORB_SLAM2::ORBextractor state (parameters, tables)      */
+typedef struct sd_batch sd_batch;         /* device workspace for up to max_images images of one size */
+
+int sd_version(void);
+const char* sd_status_string(int status);
+const char* sd_last_error(void); /* thread-local text of the last SD_ERR_HIP / SD_ERR_UNSUPPORTED */
+int sd_device_count(int* n);     /* hipGetDeviceCount; SD_ERR_NO_DEVICE when none */
+
+/* ---- ORBextractor (include/ORBextractor.h:45-114, src/ORBextractor.cc:410-470) ---- */
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)  ORBextractor.h:51 */
+int sd_extractor_create(sd_extractor** out, int nfeatures, float scaleFactor, int nlevels, int iniThFAST,
+                        int minThFAST);
+int sd_extractor_destroy(sd_extractor* ex);
+/* The 7 fixed-point (8.8) taps of GaussianBlur(7x7, sigma 2) (ORBextractor.cc:1086) are a spec
+ * parameter (OpenCV-version dependent); default {18,34,48,56,48,34,18}. */
+int sd_extractor_set_blur_taps(sd_extractor* ex, const uint16_t taps[7]);
+/* GetLevels / GetScaleFactor / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares  (ORBextractor.h:63-83) + mnFeaturesPerLevel, umax (ORBextractor.h:102-104).
+ * Any pointer may be NULL.  scale..inv_sigma2, quota: nlevels entries; umax: 16 entries. */
+int sd_extractor_levels(const sd_extractor* ex, int* nlevels, float* scale_factor);
+int sd_extractor_tables(const sd_extractor* ex, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                        int32_t* quota, int32_t* umax);
+/* Size of mvImagePyramid[level] for a WxH input (ORBextractor.cc:1111-1112). */
+int sd_extractor_level_size(const sd_extractor* ex, int width, int height, int level, int* lw, int* lh);
+
+/* ---- batched ORBextractor::operator() (src/ORBextractor.cc:1043-1105) ----
+ * One sd_batch owns, in HBM, the 8-level padded pyramid (the public member mvImagePyramid,
+ * ORBextractor.h:85), the blurred planes, FAST candidates and the results of up to max_images
+ * images of width x height.  Like the reference object it is not re-entrant: one batch per
+ * concurrent caller (the reference uses one extractor per eye, Frame.cc:87-90). */
+int sd_batch_create(sd_batch** out, sd_extractor* ex, int width, int height, int max_images);
+int sd_batch_destroy(sd_batch* b);
+int sd_batch_kp_capacity(const sd_batch* b, int* cap); /* max keypoints one image can return */
+
+/* operator()(image, mask [ignored], keypoints, descriptors) for n_images gray images already in
+ * HBM: image i starts at d_gray + i*image_pitch, rows `stride` bytes apart.  Asynchronous on
+ * `stream`; results stay on the device. */
+int sd_batch_extract_device(sd_batch* b, const uint8_t* d_gray, size_t stride, size_t image_pitch, int n_images,
+                            void* stream);
+/* Same, from host memory (upload + extract + stream sync).  Empty image (NULL / 0 size) => 0 keypoints,
+ * as ORBextractor.cc:1046-1047. */
+int sd_batch_extract_host(sd_batch* b, const uint8_t* gray, size_t stride, size_t image_pitch, int n_images);
+
+/* Results.  Device views: kp [max_images][cap], desc [max_images][cap][32], count [max_images]. */
+int sd_batch_results_device(sd_batch* b, sd_keypoint** d_kp, uint8_t** d_desc, int32_t** d_count, int* cap);
+int sd_batch_counts(sd_batch* b, int32_t* counts, int n_images);           /* syncs the stream */
+int sd_batch_download(sd_batch* b, int image, sd_keypoint* kp, uint8_t* desc, int cap, int* n,
+                      int32_t* per_level /* nlevels or NULL */);
+/* mvImagePyramid[level] of image `image`: device pointer to the interior (x=0,y=0) pixel; the 19-px
+ * BORDER_REFLECT_101 frame lies at negative offsets (ORBextractor.cc:1107-1130). */
+int sd_batch_pyramid_level(sd_batch* b, int image, int level, const uint8_t** d_interior, int* w, int* h,
+                           size_t* stride);
+/* Copy the padded plane ((h+38) x (w+38), tightly packed) / the blurred interior plane (h x w) to host. */
+int sd_batch_download_pyramid(sd_batch* b, int image, int level, uint8_t* padded_out);
+int sd_batch_download_blurred(sd_batch* b, int image, int level, uint8_t* out);
+/* Number of FAST candidates per level before the quadtree (vToDistributeKeys.size(), ORBextractor.cc:829) */
+int sd_batch_candidate_counts(sd_batch* b, int image, int32_t* per_level);
+
+/* ---- Frame::ComputeStereoMatches (src/Frame.cc:874-1048) ----
+ * The batch must hold n_frames stereo pairs extracted as images 2f (left) and 2f+1 (right).
+ * mbf = Camera.bf, fx = Camera.fx (mb = mbf/fx, Frame.cc:228).  Outputs per left keypoint. */
+int sd_batch_stereo_match(sd_batch* b, int n_frames, float mbf, float fx, void* stream);
+int sd_batch_stereo_device(sd_batch* b, float** d_uright, float** d_depth, int* cap); /* [n_frames][cap] */
+int sd_batch_download_stereo(sd_batch* b, int frame, float* uright, float* depth, int32_t* sad_dist, int cap);
+
+/* ---- Frame::ComputeStereoFromRGBD (src/Frame.cc:1051-1072) + depth scaling (Tracking.cc:271-272) ----
+ * d_depth: 16-bit depth images (rows `stride_elems` elements apart); depth_factor = 1/DepthMapFactor.
+ * Fuses imDepth.convertTo(CV_32F, factor) with the per-keypoint lookup (undistortion is the identity
+ * when k1 == 0, Frame.cc:814-818).  One image per frame. */
+int sd_batch_rgbd_from_u16(sd_batch* b, const uint16_t* d_depth, size_t stride_elems, size_t image_pitch_elems,
+                           int n_images, float depth_factor, float mbf, void* stream);
+int sd_batch_rgbd_from_f32(sd_batch* b, const float* d_depth, size_t stride_elems, size_t image_pitch_elems,
+                           int n_images, float mbf, void* stream);
+int sd_batch_download_rgbd(sd_batch* b, int image, float* uright, float* depth, int cap);
+
+/* ---- Tracking::GrabImage* preprocessing (src/Tracking.cc:170-343) ---- */
+/* cvtColor(RGB|BGR|RGBA|BGRA -> GRAY); rgb_order = Camera.RGB.  channels 3 or 4. */
+int sd_cvt_gray_device(const uint8_t* d_src, int width, int height, size_t src_stride, size_t src_pitch, int channels,
+                       int rgb_order, uint8_t* d_dst, size_t dst_stride, size_t dst_pitch, int n_images, void* stream);
+/* imDepth.convertTo(CV_32F, factor) for CV_16U input. */
+int sd_depth_to_f32_device(const uint16_t* d_src, int width, int height, size_t src_stride_elems, float factor,
+                           float* d_dst, int n_images, size_t src_pitch_elems, void* stream);
+
+/* ---- ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1804-1820) ---- */
+int sd_descriptor_distance(const uint8_t a[32], const uint8_t b[32]); /* host, returns 0..256 */
+/* All-pairs Hamming distances of two descriptor sets in HBM: out[i*nb + j] (u16). */
+int sd_hamming_matrix_device(const uint8_t* d_a, int na, const uint8_t* d_b, int nb, uint16_t* d_out, void* stream);
+
+/* ---- profiling support for bench.py ----
+ * When enabled, every kernel of the batch pipeline is bracketed by hipEvents on the stream it is
+ * launched on; sd_batch_kernel_times returns the accumulated milliseconds and launch counts. */
+int sd_batch_set_profiling(sd_batch* b, int enabled);
+int sd_batch_kernel_count(const sd_batch* b, int* n);
+int sd_batch_kernel_times(sd_batch* b, int index, const char** name, double* total_ms, int64_t* launches);
+int sd_batch_reset_kernel_times(sd_batch* b);
+int sd_batch_sync(sd_batch* b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SD_FRONTEND_H */

@@ -1,0 +1,705 @@
+// HIP kernels of the ORB extractor for gfx950 (CDNA4, wave64).
+//
+// Each kernel covers the whole batch (all images, all pyramid levels) in one launch so
+// that a batch of stereo frames fills the 256 CUs; per-image work is far too small to do
+// so on its own.  Reference loops they replace:
+//   k_pyr_level0 / k_pyr_level  ComputePyramid            src/ORBextractor.cc:1107-1132
+//   k_fast_cells                cv::FAST per 30-px cell    src/ORBextractor.cc:789-829
+//   k_quadtree                  DistributeOctTree          src/ORBextractor.cc:539-763
+//   k_orient                    IC_Angle + kp finalise     src/ORBextractor.cc:77-104,837-852,1095-1101
+//   k_blur                      GaussianBlur 7x7 sigma 2   src/ORBextractor.cc:1085-1086
+//   k_describe                  computeOrbDescriptor       src/ORBextractor.cc:107-147
+// Compiled with -ffp-contract=off: the f32 expressions must round exactly like the
+// reference's un-fused SSE2 code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sd_plan.h"
+#include "../../include/sd_frontend.h"
+
+#define SD_WAVE 64
+
+struct SdDevPlan {               // lives in HBM; every kernel gets a pointer to it
+    SdLevel lv[SD_MAX_LEVELS];
+    int nlevels;
+    int iniTh, minTh;
+    int cellTotal;
+    int cellListCap;
+    int kpCapLevels, kpCap;
+    unsigned long long pyrImageBytes, blurImageBytes;
+    int umax[16];
+    int taps[7];
+};
+
+__constant__ signed char c_pattern[1024] = {
+#include "orb_pattern.inc"
+};
+
+__device__ __forceinline__ int sd_reflect101(int p, int len)
+{
+    // |p| excursions are at most 19+3 px and len >= 40, so one fold suffices
+    if (p < 0) p = -p;
+    if (p >= len) p = 2 * (len - 1) - p;
+    return p;
+}
+
+// ------------------------------------------------------------------ pyramid, level 0
+// Padded copy of the gray input with BORDER_REFLECT_101 (ORBextractor.cc:1127-1128).
+// Thread = 4 consecutive padded pixels (one aligned u32 store); block 64x4.
+__global__ void __launch_bounds__(256) k_pyr_level0(const uint8_t* __restrict__ gray, size_t gstride, size_t gpitch,
+                                                    uint8_t* __restrict__ pyr, const SdDevPlan* __restrict__ PP)
+{
+    const SdDevPlan& P = *PP;
+    const SdLevel& g = P.lv[0];
+    const int img = blockIdx.z;
+    const int gx = blockIdx.x * 64 + threadIdx.x;
+    const int Yp = blockIdx.y * 4 + threadIdx.y;          // padded row 0 .. H+37
+    if (Yp >= g.H + 2 * SD_EDGE) return;
+    const int X0 = -20 + 4 * gx;                           // first interior-relative column of this u32
+    if (X0 > g.W + SD_EDGE - 1) return;
+    const int sy = sd_reflect101(Yp - SD_EDGE, g.H);
+    const uint8_t* srow = gray + (size_t)img * gpitch + (size_t)sy * gstride;
+    uint32_t pack = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int X = X0 + k;
+        X = X < -SD_EDGE ? -SD_EDGE : (X > g.W + SD_EDGE - 1 ? g.W + SD_EDGE - 1 : X);
+        pack |= (uint32_t)srow[sd_reflect101(X, g.W)] << (8 * k);
+    }
+    uint8_t* drow = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)Yp * g.stride;
+    *(uint32_t*)(drow + SD_XOFF + X0) = pack;
+}
+
+// ------------------------------------------------------------------ pyramid, level >= 1
+// cv::resize(INTER_LINEAR) of level-1's interior + REFLECT_101 border in one pass: every padded
+// pixel is the resized value at its reflected interior position (no second pass, no dependency
+// between threads).  Coefficient tables come from the host plan (sd_plan.h).
+__global__ void __launch_bounds__(256) k_pyr_level(uint8_t* __restrict__ pyr, const int16_t* __restrict__ tabs,
+                                                   const SdDevPlan* __restrict__ PP, int level)
+{
+    const SdDevPlan& P = *PP;
+    const SdLevel& g = P.lv[level];
+    const SdLevel& s = P.lv[level - 1];
+    const int img = blockIdx.z;
+    const int gx = blockIdx.x * 64 + threadIdx.x;
+    const int Yp = blockIdx.y * 4 + threadIdx.y;
+    if (Yp >= g.H + 2 * SD_EDGE) return;
+    const int X0 = -20 + 4 * gx;
+    if (X0 > g.W + SD_EDGE - 1) return;
+    const int16_t* xo = tabs + g.tabOffset; const int16_t* a0t = xo + g.W; const int16_t* a1t = a0t + g.W;
+    const int16_t* yo = a1t + g.W; const int16_t* b0t = yo + g.H; const int16_t* b1t = b0t + g.H;
+    const int y = sd_reflect101(Yp - SD_EDGE, g.H);
+    const int sy0 = yo[y];
+    const int r0 = min(max(sy0, 0), s.H - 1), r1 = min(max(sy0 + 1, 0), s.H - 1);
+    const int b0 = b0t[y], b1 = b1t[y];
+    const uint8_t* sbase = pyr + (size_t)img * P.pyrImageBytes + s.pyrOffset + (size_t)SD_EDGE * s.stride + SD_XOFF;
+    const uint8_t* S0 = sbase + (size_t)r0 * s.stride;
+    const uint8_t* S1 = sbase + (size_t)r1 * s.stride;
+    uint32_t pack = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int X = X0 + k;
+        X = X < -SD_EDGE ? -SD_EDGE : (X > g.W + SD_EDGE - 1 ? g.W + SD_EDGE - 1 : X);
+        const int x = sd_reflect101(X, g.W);
+        const int sx = xo[x];
+        const int sx1 = min(sx + 1, s.W - 1);
+        const int a0 = a0t[x], a1 = a1t[x];
+        const int h0 = S0[sx] * a0 + S0[sx1] * a1;
+        const int h1 = S1[sx] * a0 + S1[sx1] * a1;
+        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        pack |= (uint32_t)(v & 255) << (8 * k);
+    }
+    uint8_t* drow = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)Yp * g.stride;
+    *(uint32_t*)(drow + SD_XOFF + X0) = pack;
+}
+
+// ------------------------------------------------------------------ FAST-9/16 per cell
+// One workgroup per cell window (<= 64x64 px, staged in LDS).  Instead of OpenCV's
+// threshold-dependent row buffers we use the threshold-free form of the same result:
+//   s(p)   = max over the 16 contiguous 9-arcs of min |v - ring| on the darker/brighter side, -1
+//            (== cornerScore<16>; p is a corner at threshold T  <=>  s(p) >= T)
+//   keep_T = s(p) >= T  and  s(p) > s(q) for the 8 neighbours q inside the scanned window
+// and the cell uses T = iniTh if keep_iniTh is non-empty, else minTh (ORBextractor.cc:807-816).
+#define SD_TILE_S 72   // LDS row stride of the window tile
+
+__device__ __forceinline__ bool sd_has9(unsigned m)
+{
+    unsigned x = m | (m << 16);
+    unsigned y = x & (x >> 1);
+    y &= y >> 2;
+    y &= y >> 4;          // bit i: ring bits i..i+7 set
+    y &= x >> 8;          // bit i: ring bits i..i+8 set
+    return (y & 0xFFFFu) != 0;
+}
+
+__device__ __forceinline__ int sd_fast_score(const uint8_t* c, int minTh)
+{
+    const int S = SD_TILE_S;
+    const int v = c[0];
+    int d[16];
+    d[0] = v - c[3 * S];       d[1] = v - c[3 * S + 1];   d[2] = v - c[2 * S + 2];   d[3] = v - c[S + 3];
+    d[4] = v - c[3];           d[5] = v - c[-S + 3];      d[6] = v - c[-2 * S + 2];  d[7] = v - c[-3 * S + 1];
+    d[8] = v - c[-3 * S];      d[9] = v - c[-3 * S - 1];  d[10] = v - c[-2 * S - 2]; d[11] = v - c[-S - 3];
+    d[12] = v - c[-3];         d[13] = v - c[S - 3];      d[14] = v - c[2 * S - 2];  d[15] = v - c[3 * S - 1];
+    unsigned dark = 0, bright = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        dark |= (unsigned)(d[k] > minTh) << k;      // ring pixel darker than v - T
+        bright |= (unsigned)(d[k] < -minTh) << k;   // ring pixel brighter than v + T
+    }
+    if (!sd_has9(dark) && !sd_has9(bright)) return 0;
+    // sliding 9-window min / max over the cyclic ring by doubling
+    int mn2[16], mx2[16], mn4[16], mx4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+    int A = -1000, B = 1000;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+        int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+        A = max(A, mn9);
+        B = min(B, mx9);
+    }
+    return max(A, -B) - 1;
+}
+
+__global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ pyr, const SdCell* __restrict__ cells,
+                                                    uint32_t* __restrict__ cellList, int* __restrict__ cellCount,
+                                                    const SdDevPlan* __restrict__ PP)
+{
+    const SdDevPlan& P = *PP;
+    __shared__ uint8_t tile[70 * SD_TILE_S];
+    __shared__ uint8_t keep[64 * 64];       // NMS-surviving score per scanned pixel (0 = none)
+    __shared__ int s_any, s_wsum[4];
+    const int img = blockIdx.y;
+    const SdCell c = cells[blockIdx.x];
+    const SdLevel& g = P.lv[c.level];
+    const int ww = c.x1 - c.x0, wh = c.y1 - c.y0;
+    const int sw = ww - 6, sh = wh - 6;                    // scanned area
+    const int tid = threadIdx.x;
+    if (tid == 0) s_any = 0;
+    if (sw <= 0 || sh <= 0) { if (tid == 0) cellCount[(size_t)img * P.cellTotal + blockIdx.x] = 0; return; }
+    const uint8_t* src = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)(SD_EDGE + c.y0) * g.stride +
+                         SD_XOFF + c.x0;
+    for (int i = tid; i < ww * wh; i += 256) {
+        int y = i / ww, x = i - y * ww;
+        tile[y * SD_TILE_S + x] = src[(size_t)y * g.stride + x];
+    }
+    __syncthreads();
+    const int npix = sw * sh;
+    // scores (0 unless corner at minTh) into keep[] first
+    for (int i = tid; i < npix; i += 256) {
+        int y = i / sw, x = i - y * sw;
+        int s = sd_fast_score(&tile[(y + 3) * SD_TILE_S + x + 3], P.minTh);
+        keep[i] = (uint8_t)(s >= P.minTh ? s : 0);
+    }
+    __syncthreads();
+    // 3x3 NMS (strictly greater than all 8 neighbours; outside the scanned area counts as 0)
+    uint8_t mine[16];
+    int any = 0;
+    {
+        int k = 0;
+        for (int i = tid; i < npix; i += 256, k++) {
+            int y = i / sw, x = i - y * sw;
+            int s = keep[i];
+            int ok = s > 0;
+            if (ok) {
+#pragma unroll
+                for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; dx++) {
+                        if (dx == 0 && dy == 0) continue;
+                        int xx = x + dx, yy = y + dy;
+                        int q = (xx >= 0 && xx < sw && yy >= 0 && yy < sh) ? keep[yy * sw + xx] : 0;
+                        ok &= (s > q);
+                    }
+            }
+            mine[k] = (uint8_t)(ok ? s : 0);
+            any |= (ok && s >= P.iniTh);
+        }
+    }
+    if (any) s_any = 1;
+    __syncthreads();
+    {
+        int k = 0;
+        for (int i = tid; i < npix; i += 256, k++) keep[i] = mine[k];
+    }
+    __syncthreads();
+    const int T = s_any ? P.iniTh : P.minTh;
+    // ordered (row-major) compaction: thread t owns the contiguous chunk [t*chunk, (t+1)*chunk)
+    const int chunk = (npix + 255) / 256;
+    const int beg = tid * chunk, end = min(beg + chunk, npix);
+    int cnt = 0;
+    for (int i = beg; i < end; i++) cnt += (keep[i] >= T);
+    // block exclusive scan of cnt
+    const int lane = tid & 63, wv = tid >> 6;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; w++) base += s_wsum[w];
+    const int total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    int pos = base + incl - cnt;
+    uint32_t* out = cellList + (size_t)img * P.cellListCap + c.listOffset;
+    for (int i = beg; i < end; i++) {
+        int s = keep[i];
+        if (s >= T) {
+            int y = i / sw, x = i - y * sw;
+            // coordinates relative to (minBorderX, minBorderY): FAST-local + j*wCell (ORBextractor.cc:822-823)
+            uint32_t px = (uint32_t)(x + 3 + c.jw), py = (uint32_t)(y + 3 + c.ih);
+            if (pos < c.cap) out[pos] = px | (py << 12) | ((uint32_t)s << 24);
+            pos++;
+        }
+    }
+    if (tid == 0) cellCount[(size_t)img * P.cellTotal + blockIdx.x] = min(total, c.cap);
+}
+
+// ------------------------------------------------------------------ quadtree distribution
+// One workgroup per (image, level).  The std::list of the reference is an array in list order;
+// a pass divides a set of nodes "in processing order" (list order for the plain passes, descending
+// (size, creation) for the sorted passes of ORBextractor.cc:673-738), children are created in that
+// order and end up reversed at the head of the list, exactly like repeated push_front.  The early
+// `break` of the sorted pass is a prefix-sum cut.  Per-candidate state (node id) lives in HBM/L2,
+// node arrays in LDS.
+struct SdQtShared {
+    // carved from dynamic LDS; all arrays have maxNodes (MN) entries unless noted
+    short4* rectA; short4* rectB;      // x = x0, y = x1, z = y0, w = y1
+    int* cntA; int* cntB;
+    int* child;                        // 4*MN? no: MN entries (child slots of one pass <= MN)
+    int* gidx;                         // MN
+    short* order;                      // MN: list positions in processing order
+    short* procRank;                   // MN: rank in processing order or -1
+    short* keptRank;                   // MN
+    unsigned long long* keys;          // sortP entries
+    unsigned* best;                    // MN
+};
+
+__device__ __forceinline__ int sd_block_excl_scan(int* a, int n, int* wsum /*[>=5]*/)
+{
+    // in-place exclusive scan of a[0..n) by 256 threads; returns the total
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int chunk = (n + 255) / 256;
+    const int beg = min(tid * chunk, n), end = min(beg + chunk, n);
+    int sum = 0;
+    for (int i = beg; i < end; i++) sum += a[i];
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; w++) base += wsum[w];
+    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    int run = base + incl - sum;
+    for (int i = beg; i < end; i++) { int v = a[i]; a[i] = run; run += v; }
+    __syncthreads();
+    return total;
+}
+
+__device__ __forceinline__ int sd_quadrant(short4 r, int x, int y)
+{
+    const int midx = r.x + ((r.y - r.x + 1) >> 1);     // UL.x + ceil((UR.x-UL.x)/2)
+    const int midy = r.z + ((r.w - r.z + 1) >> 1);
+    return (x < midx ? 0 : 1) + (y < midy ? 0 : 2);   // n1,n2,n3,n4 -> 0,1,2,3
+}
+
+__global__ void __launch_bounds__(256) k_quadtree(const uint32_t* __restrict__ cellList,
+                                                  const int* __restrict__ cellCount, const SdCell* __restrict__ cells,
+                                                  uint32_t* __restrict__ cand, uint16_t* __restrict__ nodeOf,
+                                                  int* __restrict__ lvlCount, int* __restrict__ candCount,
+                                                  uint32_t* __restrict__ lvlKp, int* __restrict__ errFlag,
+                                                  const SdDevPlan* __restrict__ PP, int MN, int sortP)
+{
+    const SdDevPlan& P = *PP;
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int s_wsum[8];
+    __shared__ int s_scal[8];
+    const int level = blockIdx.x, img = blockIdx.y;
+    const SdLevel& g = P.lv[level];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // carve
+    unsigned char* p = smem;
+    unsigned long long* keys = (unsigned long long*)p; p += (size_t)sortP * 8;
+    short4* rectA = (short4*)p; p += (size_t)MN * 8;
+    short4* rectB = (short4*)p; p += (size_t)MN * 8;
+    int* cntA = (int*)p; p += (size_t)MN * 4;
+    int* cntB = (int*)p; p += (size_t)MN * 4;
+    int* child = (int*)p; p += (size_t)MN * 4;
+    int* gidx = (int*)p; p += (size_t)MN * 4;
+    int* tmp = (int*)p; p += (size_t)MN * 4;
+    unsigned* best = (unsigned*)p; p += (size_t)MN * 4;
+    short* order = (short*)p; p += (size_t)MN * 2;
+    short* procRank = (short*)p; p += (size_t)MN * 2;
+    short* keptRank = (short*)p; p += (size_t)MN * 2;
+
+    uint32_t* myCand = cand + (size_t)img * P.cellListCap + g.candOffset;
+    uint16_t* myNode = nodeOf + (size_t)img * P.cellListCap + g.candOffset;
+    const int* myCellCount = cellCount + (size_t)img * P.cellTotal + g.cell0;
+    const uint32_t* myList = cellList + (size_t)img * P.cellListCap;
+
+    // ---- 1. compact the per-cell candidate lists in cell order (row-major cells, row-major pixels)
+    for (int i = tid; i < g.nCells; i += 256) tmp[i] = myCellCount[i];
+    __syncthreads();
+    int M;
+    {
+        // nCells may exceed MN only for tiny quotas; scan in tmp needs nCells <= MN (checked on host)
+        M = sd_block_excl_scan(tmp, g.nCells, s_wsum);
+    }
+    for (int ci = wv; ci < g.nCells; ci += 4) {
+        const SdCell c = cells[g.cell0 + ci];
+        const int n = myCellCount[ci], off = tmp[ci];
+        for (int r = lane; r < n; r += 64) myCand[off + r] = myList[c.listOffset + r];
+    }
+    __syncthreads();
+    if (tid == 0) candCount[(size_t)img * P.nlevels + level] = M;
+
+    // ---- 2. initial nodes (ORBextractor.cc:543-588)
+    const int N = g.quota;
+    const int nIni = g.nIni;
+    const float hX = g.hX;
+    for (int i = tid; i < nIni; i += 256) child[i] = 0;
+    __syncthreads();
+    for (int c = tid; c < M; c += 256) {
+        const uint32_t v = myCand[c];
+        const int x = v & 0xFFF;
+        int idx = (int)((float)x / hX);
+        idx = min(idx, nIni - 1);
+        myNode[c] = (uint16_t)idx;
+        atomicAdd(&child[idx], 1);
+    }
+    __syncthreads();
+    for (int i = tid; i < nIni; i += 256) tmp[i] = child[i] > 0;
+    __syncthreads();
+    int n = sd_block_excl_scan(tmp, nIni, s_wsum);
+    for (int i = tid; i < nIni; i += 256) {
+        if (child[i] > 0) {
+            short4 r;
+            r.x = (short)(int)(hX * (float)i); r.y = (short)(int)(hX * (float)(i + 1));
+            r.z = 0; r.w = (short)(g.maxBY - g.minBY);
+            rectA[tmp[i]] = r; cntA[tmp[i]] = child[i];
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < M; c += 256) myNode[c] = (uint16_t)tmp[myNode[c]];
+    __syncthreads();
+
+    short4* rc = rectA; short4* rn = rectB; int* cc = cntA; int* cn = cntB;
+    bool sortedPhase = false;
+    for (int iter = 0; iter < 96; iter++) {
+        const int prev = n;
+        // ---- processing order
+        int m;
+        if (!sortedPhase) {
+            for (int i = tid; i < n; i += 256) tmp[i] = cc[i] > 1;
+            __syncthreads();
+            m = sd_block_excl_scan(tmp, n, s_wsum);
+            for (int i = tid; i < n; i += 256) if (cc[i] > 1) order[tmp[i]] = (short)i;
+        } else {
+            for (int i = tid; i < sortP; i += 256)
+                keys[i] = (i < n && cc[i] > 1) ? (((unsigned long long)(unsigned)cc[i] << 32) | (unsigned)(0xFFFF - i)) : 0ull;
+            __syncthreads();
+            // bitonic sort, descending
+            for (int k = 2; k <= sortP; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = tid; i < sortP; i += 256) {
+                        int ixj = i ^ j;
+                        if (ixj > i) {
+                            unsigned long long a = keys[i], b = keys[ixj];
+                            bool desc = ((i & k) == 0);
+                            if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[ixj] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (int i = tid; i < n; i += 256) tmp[i] = cc[i] > 1;
+            __syncthreads();
+            m = sd_block_excl_scan(tmp, n, s_wsum);
+            for (int i = tid; i < m; i += 256) order[i] = (short)(0xFFFF - (unsigned)(keys[i] & 0xFFFFu));
+        }
+        __syncthreads();
+        // ---- child counts for every node in `order`
+        for (int i = tid; i < n; i += 256) procRank[i] = -1;
+        for (int i = tid; i < 4 * m; i += 256) child[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < m; i += 256) procRank[order[i]] = (short)i;
+        __syncthreads();
+        for (int c = tid; c < M; c += 256) {
+            const int pos = myNode[c];
+            const int t = procRank[pos];
+            if (t >= 0) {
+                const uint32_t v = myCand[c];
+                const int q = sd_quadrant(rc[pos], v & 0xFFF, (v >> 12) & 0xFFF);
+                atomicAdd(&child[4 * t + q], 1);
+            }
+        }
+        __syncthreads();
+        // ---- sorted pass: cut at the first division that reaches N nodes (break at :731-732)
+        int mEff = m;
+        if (sortedPhase) {
+            if (tid == 0) s_scal[0] = m;
+            for (int i = tid; i < m; i += 256)
+                gidx[i] = (child[4 * i] > 0) + (child[4 * i + 1] > 0) + (child[4 * i + 2] > 0) + (child[4 * i + 3] > 0) - 1;
+            __syncthreads();
+            for (int i = tid; i < m; i += 256) tmp[i] = gidx[i];
+            __syncthreads();
+            sd_block_excl_scan(tmp, m, s_wsum);
+            for (int i = tid; i < m; i += 256)
+                if (n + tmp[i] + gidx[i] >= N) atomicMin(&s_scal[0], i);
+            __syncthreads();
+            mEff = min(m, s_scal[0] + 1);
+            __syncthreads();
+            for (int i = tid + mEff; i < m; i += 256) procRank[order[i]] = -1;
+            __syncthreads();
+        }
+        // ---- creation index of the non-empty children, in creation order
+        for (int i = tid; i < 4 * mEff; i += 256) gidx[i] = child[i] > 0;
+        __syncthreads();
+        const int E = sd_block_excl_scan(gidx, 4 * mEff, s_wsum);
+        for (int i = tid; i < n; i += 256) tmp[i] = procRank[i] < 0;
+        __syncthreads();
+        const int K = sd_block_excl_scan(tmp, n, s_wsum);
+        for (int i = tid; i < n; i += 256) keptRank[i] = (short)tmp[i];
+        __syncthreads();
+        // ---- new list: children reversed at the head, untouched nodes behind in their old order
+        int nExp = 0;
+        for (int j = tid; j < 4 * mEff; j += 256) {
+            const int cj = child[j];
+            if (cj > 0) {
+                const short4 r = rc[order[j >> 2]];
+                const int q = j & 3;
+                const int midx = r.x + ((r.y - r.x + 1) >> 1), midy = r.z + ((r.w - r.z + 1) >> 1);
+                short4 o;
+                o.x = (q & 1) ? (short)midx : r.x; o.y = (q & 1) ? r.y : (short)midx;
+                o.z = (q & 2) ? (short)midy : r.z; o.w = (q & 2) ? r.w : (short)midy;
+                const int np = E - 1 - gidx[j];
+                rn[np] = o; cn[np] = cj;
+                nExp += (cj > 1);
+            }
+        }
+        for (int i = tid; i < n; i += 256)
+            if (procRank[i] < 0) { const int np = E + keptRank[i]; rn[np] = rc[i]; cn[np] = cc[i]; }
+        for (int c = tid; c < M; c += 256) {
+            const int pos = myNode[c];
+            const int t = procRank[pos];
+            int np;
+            if (t >= 0) {
+                const uint32_t v = myCand[c];
+                const int q = sd_quadrant(rc[pos], v & 0xFFF, (v >> 12) & 0xFFF);
+                np = E - 1 - gidx[4 * t + q];
+            } else np = E + keptRank[pos];
+            myNode[c] = (uint16_t)np;
+        }
+        // nToExpand (block sum)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nExp += __shfl_xor(nExp, o, 64);
+        __syncthreads();
+        if (lane == 0) s_wsum[4 + wv] = nExp;
+        __syncthreads();
+        const int nToExpand = s_wsum[4] + s_wsum[5] + s_wsum[6] + s_wsum[7];
+        n = E + K;
+        { short4* t1 = rc; rc = rn; rn = t1; int* t2 = cc; cc = cn; cn = t2; }
+        __syncthreads();
+        if (n >= N || n == prev) break;                       // ORBextractor.cc:666-669, 735-736
+        if (!sortedPhase && (n + nToExpand * 3) > N) sortedPhase = true;   // :670
+        if (n + 4 > MN) { if (tid == 0) atomicOr(errFlag, 1); break; }
+    }
+
+    // ---- 3. best response per node, first in candidate order on ties (ORBextractor.cc:741-760)
+    for (int i = tid; i < n; i += 256) best[i] = 0;
+    __syncthreads();
+    for (int c = tid; c < M; c += 256) {
+        const uint32_t v = myCand[c];
+        atomicMax(&best[myNode[c]], ((v >> 24) << 24) | (0xFFFFFFu - (unsigned)c));
+    }
+    __syncthreads();
+    const int nOut = min(n, g.kpCap);
+    if (n > g.kpCap && tid == 0) atomicOr(errFlag, 2);
+    uint32_t* out = lvlKp + (size_t)img * P.kpCapLevels + g.kpOffset;
+    for (int i = tid; i < nOut; i += 256) {
+        const unsigned c = 0xFFFFFFu - (best[i] & 0xFFFFFFu);
+        out[i] = myCand[c];
+    }
+    if (tid == 0) lvlCount[(size_t)img * P.nlevels + level] = nOut;
+}
+
+// ------------------------------------------------------------------ orientation + final keypoint record
+// Half a wave (32 lanes = the 31 columns of the patch) per keypoint.
+__device__ __forceinline__ float sd_fast_atan2(float y, float x)
+{
+    const float p1 = 0.9997878412794807f * (float)(180 / M_PI);
+    const float p3 = -0.3258083974640975f * (float)(180 / M_PI);
+    const float p5 = 0.1555786518463281f * (float)(180 / M_PI);
+    const float p7 = -0.04432655554792128f * (float)(180 / M_PI);
+    float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)2.2204460492503131e-16);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)2.2204460492503131e-16);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__global__ void __launch_bounds__(256) k_orient(const uint8_t* __restrict__ pyr, const uint32_t* __restrict__ lvlKp,
+                                                const int* __restrict__ lvlCount, sd_keypoint* __restrict__ kpOut,
+                                                float2* __restrict__ rot, int* __restrict__ count, const SdDevPlan* __restrict__ PP)
+{
+    const SdDevPlan& P = *PP;
+    const int img = blockIdx.y;
+    const int slot = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int l32 = threadIdx.x & 31;
+    if (slot >= P.kpCapLevels) return;
+    int level = 0;
+#pragma unroll
+    for (int l = 1; l < SD_MAX_LEVELS; l++)
+        if (l < P.nlevels && slot >= P.lv[l].kpOffset) level = l;
+    const SdLevel& g = P.lv[level];
+    const int* lc = lvlCount + (size_t)img * P.nlevels;
+    const int idx = slot - g.kpOffset;
+    int before = 0;
+    for (int l = 0; l < level; l++) before += lc[l];
+    if (slot == 0 && l32 == 0) {
+        int tot = 0;
+        for (int l = 0; l < P.nlevels; l++) tot += lc[l];
+        count[img] = tot;
+    }
+    if (idx >= lc[level]) return;
+    const uint32_t v = lvlKp[(size_t)img * P.kpCapLevels + slot];
+    const int px = (int)(v & 0xFFF) + g.minBX, py = (int)((v >> 12) & 0xFFF) + g.minBY;
+    const uint8_t* center = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)(SD_EDGE + py) * g.stride +
+                            SD_XOFF + px;
+    const int u = l32 - SD_HALF_PATCH;
+    int m10 = 0, m01 = 0;
+    if (l32 < 31) {
+        const int au = u < 0 ? -u : u;
+        for (int vv = -SD_HALF_PATCH; vv <= SD_HALF_PATCH; vv++) {
+            const int d = P.umax[vv < 0 ? -vv : vv];
+            if (au <= d) {
+                const int val = center[(ptrdiff_t)vv * g.stride + u];
+                m10 += u * val;
+                m01 += vv * val;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }
+    if (l32 == 0) {
+        const float angle = sd_fast_atan2((float)m01, (float)m10);
+        sd_keypoint k;
+        k.x = (float)px * g.scale;      // level 0: scale == 1.0f exactly (ORBextractor.cc:1095-1101)
+        k.y = (float)py * g.scale;
+        k.size = g.sizeF; k.angle = angle; k.response = (float)(v >> 24);
+        k.octave = level; k.class_id = -1;
+        kpOut[(size_t)img * P.kpCap + before + idx] = k;
+        const float factorPI = (float)(M_PI / 180.f);
+        const float ang = angle * factorPI;
+        // a,b := correctly rounded f32 of cos/sin of the f32 angle (oracle spec Q3)
+        rot[(size_t)img * P.kpCapLevels + slot] = make_float2((float)cos((double)ang), (float)sin((double)ang));
+    }
+}
+
+// ------------------------------------------------------------------ Gaussian blur 7x7 (fixed point 8.8 taps)
+// result = (sum_ij k_i k_j p_ij + 0x8000) >> 16; both passes exact, REFLECT_101 comes for free from the
+// pyramid's own 19-px border.  Tile 64x16 per 256-thread block, staged through LDS.
+__global__ void __launch_bounds__(256) k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, const SdDevPlan* __restrict__ PP)
+{
+    const SdDevPlan& P = *PP;
+    __shared__ uint8_t t_in[22][72];
+    __shared__ uint16_t t_h[22][64];
+    const int zi = blockIdx.z;
+    const int img = zi / P.nlevels, level = zi - img * P.nlevels;
+    const SdLevel& g = P.lv[level];
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
+    if (x0 >= g.W || y0 >= g.H) return;
+    const int tid = threadIdx.x;
+    const uint8_t* src = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)SD_EDGE * g.stride + SD_XOFF;
+    for (int i = tid; i < 22 * 70; i += 256) {
+        int r = i / 70, c = i - r * 70;
+        int y = min(y0 + r - 3, g.H + 2), x = min(x0 + c - 3, g.W + 2);
+        t_in[r][c] = src[(ptrdiff_t)y * g.stride + x];
+    }
+    __syncthreads();
+    for (int i = tid; i < 22 * 64; i += 256) {
+        int r = i >> 6, c = i & 63;
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) s += P.taps[k] * t_in[r][c + k];
+        t_h[r][c] = (uint16_t)s;
+    }
+    __syncthreads();
+    uint8_t* dst = blur + (size_t)img * P.blurImageBytes + g.blurOffset;
+    for (int i = tid; i < 16 * 64; i += 256) {
+        int r = i >> 6, c = i & 63;
+        int x = x0 + c, y = y0 + r;
+        if (x < g.W && y < g.H) {
+            unsigned s = 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) s += (unsigned)P.taps[k] * t_h[r + k][c];
+            unsigned v = (s + 0x8000u) >> 16;
+            dst[(size_t)y * g.blurStride + x] = (uint8_t)(v > 255 ? 255 : v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ steered rBRIEF
+// One wave per keypoint: lane i evaluates pairs i, i+64, i+128, i+192; the four 64-bit wave
+// ballots ARE the descriptor (bit k of the descriptor = pair k, LSB first within each byte).
+__global__ void __launch_bounds__(256) k_describe(const uint8_t* __restrict__ blur, const uint32_t* __restrict__ lvlKp,
+                                                  const int* __restrict__ lvlCount, const float2* __restrict__ rot,
+                                                  uint8_t* __restrict__ descOut, const SdDevPlan* __restrict__ PP)
+{
+    const SdDevPlan& P = *PP;
+    const int img = blockIdx.y;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (slot >= P.kpCapLevels) return;
+    int level = 0;
+#pragma unroll
+    for (int l = 1; l < SD_MAX_LEVELS; l++)
+        if (l < P.nlevels && slot >= P.lv[l].kpOffset) level = l;
+    const SdLevel& g = P.lv[level];
+    const int* lc = lvlCount + (size_t)img * P.nlevels;
+    const int idx = slot - g.kpOffset;
+    if (idx >= lc[level]) return;
+    int before = 0;
+    for (int l = 0; l < level; l++) before += lc[l];
+    const uint32_t v = lvlKp[(size_t)img * P.kpCapLevels + slot];
+    const int px = (int)(v & 0xFFF) + g.minBX, py = (int)((v >> 12) & 0xFFF) + g.minBY;
+    const float2 ab = rot[(size_t)img * P.kpCapLevels + slot];
+    const float a = ab.x, b = ab.y;
+    const int step = g.blurStride;
+    const uint8_t* center = blur + (size_t)img * P.blurImageBytes + g.blurOffset + (size_t)py * step + px;
+    unsigned long long words[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int pi = 4 * (lane + 64 * r);
+        const float x0 = (float)c_pattern[pi], y0 = (float)c_pattern[pi + 1];
+        const float x1 = (float)c_pattern[pi + 2], y1 = (float)c_pattern[pi + 3];
+        const int iy0 = __float2int_rn(x0 * b + y0 * a), ix0 = __float2int_rn(x0 * a - y0 * b);
+        const int iy1 = __float2int_rn(x1 * b + y1 * a), ix1 = __float2int_rn(x1 * a - y1 * b);
+        const int t0 = center[iy0 * step + ix0];
+        const int t1 = center[iy1 * step + ix1];
+        words[r] = __ballot(t0 < t1);
+    }
+    if (lane < 4) {
+        unsigned long long w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
+        *(unsigned long long*)(descOut + ((size_t)img * P.kpCap + before + idx) * 32 + 8 * lane) = w;
+    }
+}

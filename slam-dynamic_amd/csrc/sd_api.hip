@@ -1,0 +1,680 @@
+// C-ABI implementation of include/sd_frontend.h: host orchestration of the HIP kernels.
+// There is no CPU fallback anywhere in this file: without a usable HIP device every compute
+// entry point returns SD_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "k_extract.h"
+#include "k_frame.h"
+
+static thread_local std::string g_err;
+static int set_err(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHK(call)                                                                                      \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return set_err(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? SD_ERR_NO_DEVICE : SD_ERR_HIP, \
+                           std::string(#call) + ": " + hipGetErrorString(e_));                            \
+    } while (0)
+
+struct sd_extractor {
+    SdParams prm;
+};
+
+enum KernelId { K_PYR0, K_PYR, K_FAST, K_QTREE, K_ORIENT, K_BLUR, K_DESC, K_STEREO, K_STEREO_F, K_RGBD, K_COUNT };
+static const char* kKernelNames[K_COUNT] = {"k_pyr_level0", "k_pyr_level", "k_fast_cells", "k_quadtree", "k_orient",
+                                            "k_blur", "k_describe", "k_stereo_match", "k_stereo_filter", "k_rgbd"};
+
+struct sd_batch {
+    sd_extractor* ex = nullptr;
+    SdPlan plan;
+    SdDevPlan hplan;
+    int maxImages = 0;
+    int nExtracted = 0;       // images valid from the last extract
+    int nStereo = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t lastStream = nullptr;
+    // device buffers
+    SdDevPlan* d_plan = nullptr;
+    SdCell* d_cells = nullptr;
+    int16_t* d_tabs = nullptr;
+    uint8_t* d_pyr = nullptr;
+    uint8_t* d_blur = nullptr;
+    uint32_t* d_cellList = nullptr;
+    int* d_cellCount = nullptr;
+    uint32_t* d_cand = nullptr;
+    uint16_t* d_nodeOf = nullptr;
+    int* d_lvlCount = nullptr;
+    int* d_candCount = nullptr;
+    uint32_t* d_lvlKp = nullptr;
+    float2* d_rot = nullptr;
+    sd_keypoint* d_kp = nullptr;
+    uint8_t* d_desc = nullptr;
+    int* d_count = nullptr;
+    int* d_err = nullptr;
+    float* d_uright = nullptr;
+    float* d_depth = nullptr;
+    int* d_sad = nullptr;
+    uint8_t* d_stage = nullptr;    // staging for host-image uploads
+    size_t stageBytes = 0;
+    int qtMN = 0, qtSortP = 0;
+    size_t qtLds = 0;
+    // profiling
+    bool profiling = false;
+    struct Rec { hipEvent_t a, b; int kid; };
+    std::vector<Rec> pending;
+    std::vector<hipEvent_t> pool;
+    double totalMs[K_COUNT] = {0};
+    int64_t launches[K_COUNT] = {0};
+};
+
+extern "C" {
+
+int sd_version(void) { return 100; }
+
+const char* sd_status_string(int s)
+{
+    switch (s) {
+    case SD_OK: return "ok";
+    case SD_ERR_INVALID: return "invalid argument";
+    case SD_ERR_NO_DEVICE: return "no HIP device";
+    case SD_ERR_HIP: return "HIP error";
+    case SD_ERR_CAPACITY: return "buffer too small";
+    case SD_ERR_UNSUPPORTED: return "unsupported geometry";
+    case SD_ERR_STATE: return "call sequence error";
+    default: return "unknown";
+    }
+}
+
+const char* sd_last_error(void) { return g_err.c_str(); }
+
+int sd_device_count(int* n)
+{
+    if (!n) return SD_ERR_INVALID;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess || c <= 0) { *n = 0; return set_err(SD_ERR_NO_DEVICE, "hipGetDeviceCount: no device"); }
+    *n = c;
+    return SD_OK;
+}
+
+int sd_extractor_create(sd_extractor** out, int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
+{
+    if (!out) return SD_ERR_INVALID;
+    *out = nullptr;
+    if (nfeatures < 1 || nlevels < 1 || nlevels > SD_MAX_LEVELS || !(scaleFactor > 1.0f) || iniThFAST < 1 ||
+        iniThFAST > 255 || minThFAST < 1 || minThFAST > 255)
+        return set_err(SD_ERR_INVALID, "extractor parameters out of range");
+    sd_extractor* ex = new sd_extractor();
+    sd_params_init(ex->prm, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST);
+    *out = ex;
+    return SD_OK;
+}
+
+int sd_extractor_destroy(sd_extractor* ex) { delete ex; return SD_OK; }
+
+int sd_extractor_set_blur_taps(sd_extractor* ex, const uint16_t taps[7])
+{
+    if (!ex || !taps) return SD_ERR_INVALID;
+    unsigned sum = 0;
+    for (int i = 0; i < 7; i++) sum += taps[i];
+    if (sum > 257) return set_err(SD_ERR_INVALID, "blur taps must sum to <= 257 (8.8 fixed point)");
+    memcpy(ex->prm.blurTaps, taps, 14);
+    return SD_OK;
+}
+
+int sd_extractor_levels(const sd_extractor* ex, int* nlevels, float* scale_factor)
+{
+    if (!ex) return SD_ERR_INVALID;
+    if (nlevels) *nlevels = ex->prm.nlevels;
+    if (scale_factor) *scale_factor = (float)ex->prm.scaleFactor;
+    return SD_OK;
+}
+
+int sd_extractor_tables(const sd_extractor* ex, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                        int32_t* quota, int32_t* umax)
+{
+    if (!ex) return SD_ERR_INVALID;
+    const SdParams& p = ex->prm;
+    for (int i = 0; i < p.nlevels; i++) {
+        if (scale) scale[i] = p.scale[i];
+        if (inv_scale) inv_scale[i] = p.inv[i];
+        if (sigma2) sigma2[i] = p.sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = p.invSigma2[i];
+        if (quota) quota[i] = p.quota[i];
+    }
+    if (umax) for (int i = 0; i < 16; i++) umax[i] = p.umax[i];
+    return SD_OK;
+}
+
+int sd_extractor_level_size(const sd_extractor* ex, int width, int height, int level, int* lw, int* lh)
+{
+    if (!ex || level < 0 || level >= ex->prm.nlevels || width < 1 || height < 1) return SD_ERR_INVALID;
+    if (lw) *lw = sd_cvRoundf((float)width * ex->prm.inv[level]);
+    if (lh) *lh = sd_cvRoundf((float)height * ex->prm.inv[level]);
+    return SD_OK;
+}
+
+static void batch_free(sd_batch* b)
+{
+    if (!b) return;
+    void* ptrs[] = {b->d_plan, b->d_cells, b->d_tabs, b->d_pyr, b->d_blur, b->d_cellList, b->d_cellCount, b->d_cand,
+                    b->d_nodeOf, b->d_lvlCount, b->d_candCount, b->d_lvlKp, b->d_rot, b->d_kp, b->d_desc, b->d_count,
+                    b->d_err, b->d_uright, b->d_depth, b->d_sad, b->d_stage};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& r : b->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : b->pool) (void)hipEventDestroy(e);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+int sd_batch_create(sd_batch** out, sd_extractor* ex, int width, int height, int max_images)
+{
+    if (!out) return SD_ERR_INVALID;
+    *out = nullptr;
+    if (!ex || width < 1 || height < 1 || max_images < 1) return set_err(SD_ERR_INVALID, "bad batch arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return set_err(SD_ERR_NO_DEVICE, "no HIP device: the front end has no CPU fallback");
+    sd_batch* b = new sd_batch();
+    b->ex = ex;
+    b->maxImages = max_images;
+    if (!sd_plan_build(b->plan, ex->prm, width, height)) {
+        std::string e = b->plan.error;
+        delete b;
+        return set_err(SD_ERR_UNSUPPORTED, e);
+    }
+    const SdPlan& P = b->plan;
+    SdDevPlan& D = b->hplan;
+    memset(&D, 0, sizeof(D));
+    for (int l = 0; l < P.nlevels; l++) D.lv[l] = P.lv[l];
+    D.nlevels = P.nlevels; D.iniTh = ex->prm.iniTh; D.minTh = ex->prm.minTh;
+    D.cellTotal = (int)P.cells.size(); D.cellListCap = P.cellListCap;
+    D.kpCapLevels = P.kpCapLevels; D.kpCap = P.kpCap;
+    D.pyrImageBytes = P.pyrImageBytes; D.blurImageBytes = P.blurImageBytes;
+    for (int i = 0; i < 16; i++) D.umax[i] = ex->prm.umax[i];
+    for (int i = 0; i < 7; i++) D.taps[i] = ex->prm.blurTaps[i];
+    // quadtree LDS sizing
+    int MN = 0;
+    for (int l = 0; l < P.nlevels; l++) {
+        MN = std::max(MN, P.lv[l].maxNodes);
+        MN = std::max(MN, P.lv[l].nCells + 16);
+    }
+    MN = (MN + 7) & ~7;
+    int sortP = 1;
+    while (sortP < MN) sortP <<= 1;
+    size_t lds = (size_t)sortP * 8 + (size_t)MN * (8 + 8 + 4 * 6 + 2 * 3) + 64;
+    if (lds > 160 * 1024 - 256 || MN > 30000)
+        { delete b; return set_err(SD_ERR_UNSUPPORTED, "per-level feature quota too large for the LDS quadtree (nfeatures too high)"); }
+    b->qtMN = MN; b->qtSortP = sortP; b->qtLds = lds;
+
+#define ALLOC(ptr, bytes)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                                   \
+        if (e_ != hipSuccess) {                                                               \
+            std::string m = std::string("hipMalloc(" #ptr "): ") + hipGetErrorString(e_);     \
+            batch_free(b);                                                                    \
+            return set_err(SD_ERR_HIP, m);                                                    \
+        }                                                                                     \
+    } while (0)
+    const size_t nI = (size_t)max_images;
+    ALLOC(b->d_plan, sizeof(SdDevPlan));
+    ALLOC(b->d_cells, sizeof(SdCell) * P.cells.size());
+    ALLOC(b->d_tabs, sizeof(int16_t) * P.tabs.size());
+    ALLOC(b->d_pyr, nI * P.pyrImageBytes + 4096);
+    ALLOC(b->d_blur, nI * P.blurImageBytes + 4096);
+    ALLOC(b->d_cellList, nI * P.cellListCap * 4 + 64);
+    ALLOC(b->d_cellCount, nI * P.cells.size() * 4);
+    ALLOC(b->d_cand, nI * P.cellListCap * 4 + 64);
+    ALLOC(b->d_nodeOf, nI * P.cellListCap * 2 + 64);
+    ALLOC(b->d_lvlCount, nI * P.nlevels * 4);
+    ALLOC(b->d_candCount, nI * P.nlevels * 4);
+    ALLOC(b->d_lvlKp, nI * P.kpCapLevels * 4);
+    ALLOC(b->d_rot, nI * P.kpCapLevels * sizeof(float2));
+    ALLOC(b->d_kp, nI * P.kpCap * sizeof(sd_keypoint));
+    ALLOC(b->d_desc, nI * P.kpCap * 32);
+    ALLOC(b->d_count, nI * 4);
+    ALLOC(b->d_err, 4);
+    ALLOC(b->d_uright, nI * P.kpCap * 4);
+    ALLOC(b->d_depth, nI * P.kpCap * 4);
+    ALLOC(b->d_sad, nI * P.kpCap * 4);
+#undef ALLOC
+    hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemcpy(b->d_plan, &D, sizeof(D), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(b->d_cells, P.cells.data(), sizeof(SdCell) * P.cells.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(b->d_tabs, P.tabs.data(), sizeof(int16_t) * P.tabs.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(b->d_err, 0, 4);
+    if (e == hipSuccess) e = hipMemset(b->d_count, 0, nI * 4);
+    if (e == hipSuccess) e = hipMemset(b->d_lvlCount, 0, nI * P.nlevels * 4);
+    if (e == hipSuccess && lds > 64 * 1024)
+        e = hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        std::string m = std::string("batch setup: ") + hipGetErrorString(e);
+        batch_free(b);
+        return set_err(SD_ERR_HIP, m);
+    }
+    b->lastStream = b->stream;
+    *out = b;
+    return SD_OK;
+}
+
+int sd_batch_destroy(sd_batch* b)
+{
+    if (b) { (void)hipDeviceSynchronize(); batch_free(b); }
+    return SD_OK;
+}
+
+int sd_batch_kp_capacity(const sd_batch* b, int* cap)
+{
+    if (!b || !cap) return SD_ERR_INVALID;
+    *cap = b->plan.kpCap;
+    return SD_OK;
+}
+
+// ---- profiling helpers: hipEvents on the stream the kernel is launched on
+static hipEvent_t get_event(sd_batch* b)
+{
+    if (!b->pool.empty()) { hipEvent_t e = b->pool.back(); b->pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    sd_batch* b; hipStream_t s; int kid; hipEvent_t a, e;
+    ProfScope(sd_batch* b_, hipStream_t s_, int kid_) : b(b_), s(s_), kid(kid_)
+    {
+        if (b->profiling) { a = get_event(b); e = get_event(b); (void)hipEventRecord(a, s); }
+    }
+    ~ProfScope()
+    {
+        if (b->profiling) { (void)hipEventRecord(e, s); b->pending.push_back({a, e, kid}); }
+    }
+};
+static void drain_profile(sd_batch* b)
+{
+    for (auto& r : b->pending) {
+        float ms = 0;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            b->totalMs[r.kid] += ms;
+            b->launches[r.kid]++;
+        }
+        b->pool.push_back(r.a); b->pool.push_back(r.b);
+    }
+    b->pending.clear();
+}
+
+static int check_launch(const char* name)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err(SD_ERR_HIP, std::string(name) + " launch: " + hipGetErrorString(e));
+    return SD_OK;
+}
+#define LAUNCH_CHECK(name) do { int rc_ = check_launch(name); if (rc_ != SD_OK) return rc_; } while (0)
+
+int sd_batch_extract_device(sd_batch* b, const uint8_t* d_gray, size_t stride, size_t image_pitch, int n_images,
+                            void* stream_)
+{
+    if (!b || n_images < 0 || n_images > b->maxImages) return set_err(SD_ERR_INVALID, "bad extract arguments");
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : b->stream;
+    b->lastStream = s;
+    b->nExtracted = 0;
+    b->nStereo = 0;
+    if (n_images == 0) return SD_OK;
+    if (!d_gray) return set_err(SD_ERR_INVALID, "null image pointer");
+    const SdPlan& P = b->plan;
+    if (stride < (size_t)P.W) return set_err(SD_ERR_INVALID, "stride smaller than width");
+    const int nl = P.nlevels;
+    {
+        ProfScope ps(b, s, K_PYR0);
+        const SdLevel& g = P.lv[0];
+        dim3 blk(64, 4), grd(((g.W + 39 + 3) / 4 + 63) / 64, (g.H + 2 * SD_EDGE + 3) / 4, n_images);
+        hipLaunchKernelGGL(k_pyr_level0, grd, blk, 0, s, d_gray, stride, image_pitch, b->d_pyr, b->d_plan);
+    }
+    LAUNCH_CHECK("k_pyr_level0");
+    for (int l = 1; l < nl; l++) {
+        ProfScope ps(b, s, K_PYR);
+        const SdLevel& g = P.lv[l];
+        dim3 blk(64, 4), grd(((g.W + 39 + 3) / 4 + 63) / 64, (g.H + 2 * SD_EDGE + 3) / 4, n_images);
+        hipLaunchKernelGGL(k_pyr_level, grd, blk, 0, s, b->d_pyr, b->d_tabs, b->d_plan, l);
+    }
+    LAUNCH_CHECK("k_pyr_level");
+    {
+        ProfScope ps(b, s, K_FAST);
+        dim3 grd((unsigned)P.cells.size(), n_images);
+        hipLaunchKernelGGL(k_fast_cells, grd, dim3(256), 0, s, b->d_pyr, b->d_cells, b->d_cellList, b->d_cellCount, b->d_plan);
+    }
+    LAUNCH_CHECK("k_fast_cells");
+    {
+        ProfScope ps(b, s, K_QTREE);
+        dim3 grd(nl, n_images);
+        hipLaunchKernelGGL(k_quadtree, grd, dim3(256), b->qtLds, s, b->d_cellList, b->d_cellCount, b->d_cells, b->d_cand,
+                           b->d_nodeOf, b->d_lvlCount, b->d_candCount, b->d_lvlKp, b->d_err, b->d_plan, b->qtMN, b->qtSortP);
+    }
+    LAUNCH_CHECK("k_quadtree");
+    {
+        ProfScope ps(b, s, K_BLUR);
+        dim3 grd((P.lv[0].W + 63) / 64, (P.lv[0].H + 15) / 16, n_images * nl);
+        hipLaunchKernelGGL(k_blur, grd, dim3(256), 0, s, b->d_pyr, b->d_blur, b->d_plan);
+    }
+    LAUNCH_CHECK("k_blur");
+    {
+        ProfScope ps(b, s, K_ORIENT);
+        dim3 grd((P.kpCapLevels + 7) / 8, n_images);
+        hipLaunchKernelGGL(k_orient, grd, dim3(256), 0, s, b->d_pyr, b->d_lvlKp, b->d_lvlCount, b->d_kp, b->d_rot, b->d_count,
+                           b->d_plan);
+    }
+    LAUNCH_CHECK("k_orient");
+    {
+        ProfScope ps(b, s, K_DESC);
+        dim3 grd((P.kpCapLevels + 3) / 4, n_images);
+        hipLaunchKernelGGL(k_describe, grd, dim3(256), 0, s, b->d_blur, b->d_lvlKp, b->d_lvlCount, b->d_rot, b->d_desc, b->d_plan);
+    }
+    LAUNCH_CHECK("k_describe");
+    b->nExtracted = n_images;
+    return SD_OK;
+}
+
+int sd_batch_sync(sd_batch* b)
+{
+    if (!b) return SD_ERR_INVALID;
+    HIPCHK(hipStreamSynchronize(b->lastStream));
+    drain_profile(b);
+    int err = 0;
+    HIPCHK(hipMemcpy(&err, b->d_err, 4, hipMemcpyDeviceToHost));
+    if (err) {
+        (void)hipMemset(b->d_err, 0, 4);
+        return set_err(SD_ERR_UNSUPPORTED, "quadtree node capacity exceeded (flag " + std::to_string(err) + ")");
+    }
+    return SD_OK;
+}
+
+int sd_batch_extract_host(sd_batch* b, const uint8_t* gray, size_t stride, size_t image_pitch, int n_images)
+{
+    if (!b || n_images < 0 || n_images > b->maxImages) return set_err(SD_ERR_INVALID, "bad extract arguments");
+    if (!gray || n_images == 0) { b->nExtracted = 0; return SD_OK; }   // empty image: silent return
+    const SdPlan& P = b->plan;
+    const size_t tight = (size_t)P.W * P.H;
+    const size_t need = tight * n_images;
+    if (b->stageBytes < need) {
+        if (b->d_stage) (void)hipFree(b->d_stage);
+        b->d_stage = nullptr; b->stageBytes = 0;
+        HIPCHK(hipMalloc((void**)&b->d_stage, need));
+        b->stageBytes = need;
+    }
+    for (int i = 0; i < n_images; i++)
+        HIPCHK(hipMemcpy2DAsync(b->d_stage + tight * i, P.W, gray + image_pitch * i, stride, P.W, P.H,
+                                hipMemcpyHostToDevice, b->stream));
+    int rc = sd_batch_extract_device(b, b->d_stage, P.W, tight, n_images, b->stream);
+    if (rc != SD_OK) return rc;
+    return sd_batch_sync(b);
+}
+
+int sd_batch_results_device(sd_batch* b, sd_keypoint** d_kp, uint8_t** d_desc, int32_t** d_count, int* cap)
+{
+    if (!b) return SD_ERR_INVALID;
+    if (d_kp) *d_kp = b->d_kp;
+    if (d_desc) *d_desc = b->d_desc;
+    if (d_count) *d_count = b->d_count;
+    if (cap) *cap = b->plan.kpCap;
+    return SD_OK;
+}
+
+int sd_batch_counts(sd_batch* b, int32_t* counts, int n_images)
+{
+    if (!b || !counts || n_images < 0 || n_images > b->maxImages) return SD_ERR_INVALID;
+    int rc = sd_batch_sync(b);
+    if (rc != SD_OK) return rc;
+    for (int i = 0; i < n_images; i++) counts[i] = 0;
+    int n = std::min(n_images, b->nExtracted);
+    if (n > 0) HIPCHK(hipMemcpy(counts, b->d_count, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return SD_OK;
+}
+
+int sd_batch_download(sd_batch* b, int image, sd_keypoint* kp, uint8_t* desc, int cap, int* n, int32_t* per_level)
+{
+    if (!b || !n || image < 0 || image >= b->maxImages) return SD_ERR_INVALID;
+    int rc = sd_batch_sync(b);
+    if (rc != SD_OK) return rc;
+    *n = 0;
+    if (per_level) for (int l = 0; l < b->plan.nlevels; l++) per_level[l] = 0;
+    if (image >= b->nExtracted) return SD_OK;
+    int cnt = 0;
+    HIPCHK(hipMemcpy(&cnt, b->d_count + image, 4, hipMemcpyDeviceToHost));
+    if (cnt > cap) { *n = cnt; return set_err(SD_ERR_CAPACITY, "keypoint buffer too small"); }
+    if (cnt > 0) {
+        if (kp) HIPCHK(hipMemcpy(kp, b->d_kp + (size_t)image * b->plan.kpCap, (size_t)cnt * sizeof(sd_keypoint), hipMemcpyDeviceToHost));
+        if (desc) HIPCHK(hipMemcpy(desc, b->d_desc + (size_t)image * b->plan.kpCap * 32, (size_t)cnt * 32, hipMemcpyDeviceToHost));
+    }
+    if (per_level)
+        HIPCHK(hipMemcpy(per_level, b->d_lvlCount + (size_t)image * b->plan.nlevels, (size_t)b->plan.nlevels * 4, hipMemcpyDeviceToHost));
+    *n = cnt;
+    return SD_OK;
+}
+
+int sd_batch_pyramid_level(sd_batch* b, int image, int level, const uint8_t** d_interior, int* w, int* h, size_t* stride)
+{
+    if (!b || image < 0 || image >= b->maxImages || level < 0 || level >= b->plan.nlevels) return SD_ERR_INVALID;
+    const SdLevel& g = b->plan.lv[level];
+    if (d_interior) *d_interior = b->d_pyr + (size_t)image * b->plan.pyrImageBytes + g.pyrOffset + (size_t)SD_EDGE * g.stride + SD_XOFF;
+    if (w) *w = g.W;
+    if (h) *h = g.H;
+    if (stride) *stride = (size_t)g.stride;
+    return SD_OK;
+}
+
+int sd_batch_download_pyramid(sd_batch* b, int image, int level, uint8_t* padded_out)
+{
+    if (!b || !padded_out || image < 0 || image >= b->maxImages || level < 0 || level >= b->plan.nlevels) return SD_ERR_INVALID;
+    int rc = sd_batch_sync(b);
+    if (rc != SD_OK) return rc;
+    const SdLevel& g = b->plan.lv[level];
+    const uint8_t* src = b->d_pyr + (size_t)image * b->plan.pyrImageBytes + g.pyrOffset + (SD_XOFF - SD_EDGE);
+    HIPCHK(hipMemcpy2D(padded_out, g.W + 2 * SD_EDGE, src, g.stride, g.W + 2 * SD_EDGE, g.H + 2 * SD_EDGE, hipMemcpyDeviceToHost));
+    return SD_OK;
+}
+
+int sd_batch_download_blurred(sd_batch* b, int image, int level, uint8_t* out)
+{
+    if (!b || !out || image < 0 || image >= b->maxImages || level < 0 || level >= b->plan.nlevels) return SD_ERR_INVALID;
+    int rc = sd_batch_sync(b);
+    if (rc != SD_OK) return rc;
+    const SdLevel& g = b->plan.lv[level];
+    const uint8_t* src = b->d_blur + (size_t)image * b->plan.blurImageBytes + g.blurOffset;
+    HIPCHK(hipMemcpy2D(out, g.W, src, g.blurStride, g.W, g.H, hipMemcpyDeviceToHost));
+    return SD_OK;
+}
+
+int sd_batch_candidate_counts(sd_batch* b, int image, int32_t* per_level)
+{
+    if (!b || !per_level || image < 0 || image >= b->maxImages) return SD_ERR_INVALID;
+    int rc = sd_batch_sync(b);
+    if (rc != SD_OK) return rc;
+    HIPCHK(hipMemcpy(per_level, b->d_candCount + (size_t)image * b->plan.nlevels, (size_t)b->plan.nlevels * 4, hipMemcpyDeviceToHost));
+    return SD_OK;
+}
+
+// ---------------------------------------------------------------- stereo / RGB-D
+int sd_batch_stereo_match(sd_batch* b, int n_frames, float mbf, float fx, void* stream_)
+{
+    if (!b || n_frames < 0) return SD_ERR_INVALID;
+    if (2 * n_frames > b->nExtracted) return set_err(SD_ERR_STATE, "stereo_match needs 2*n_frames extracted images (L,R interleaved)");
+    if (!(fx > 0) || !(mbf > 0)) return set_err(SD_ERR_INVALID, "mbf and fx must be positive");
+    if (b->plan.kpCap > 65535) return set_err(SD_ERR_UNSUPPORTED, "more than 65535 keypoints per image");
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
+    b->lastStream = s;
+    if (n_frames == 0) return SD_OK;
+    {
+        ProfScope ps(b, s, K_STEREO);
+        dim3 grd((b->plan.kpCap + 3) / 4, n_frames);
+        hipLaunchKernelGGL(k_stereo_match, grd, dim3(256), 0, s, b->d_kp, b->d_desc, b->d_count, b->d_pyr, b->d_uright,
+                           b->d_depth, b->d_sad, b->d_plan, mbf, fx);
+    }
+    LAUNCH_CHECK("k_stereo_match");
+    {
+        ProfScope ps(b, s, K_STEREO_F);
+        hipLaunchKernelGGL(k_stereo_filter, dim3(n_frames), dim3(256), 0, s, b->d_count, b->d_uright, b->d_depth, b->d_sad, b->d_plan);
+    }
+    LAUNCH_CHECK("k_stereo_filter");
+    b->nStereo = n_frames;
+    return SD_OK;
+}
+
+int sd_batch_stereo_device(sd_batch* b, float** d_uright, float** d_depth, int* cap)
+{
+    if (!b) return SD_ERR_INVALID;
+    if (d_uright) *d_uright = b->d_uright;
+    if (d_depth) *d_depth = b->d_depth;
+    if (cap) *cap = b->plan.kpCap;
+    return SD_OK;
+}
+
+int sd_batch_download_stereo(sd_batch* b, int frame, float* uright, float* depth, int32_t* sad_dist, int cap)
+{
+    if (!b || frame < 0 || frame >= b->nStereo) return SD_ERR_INVALID;
+    int rc = sd_batch_sync(b);
+    if (rc != SD_OK) return rc;
+    int cnt = 0;
+    HIPCHK(hipMemcpy(&cnt, b->d_count + 2 * frame, 4, hipMemcpyDeviceToHost));
+    if (cnt > cap) return set_err(SD_ERR_CAPACITY, "stereo buffer too small");
+    const size_t off = (size_t)frame * b->plan.kpCap;
+    if (cnt > 0) {
+        if (uright) HIPCHK(hipMemcpy(uright, b->d_uright + off, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+        if (depth) HIPCHK(hipMemcpy(depth, b->d_depth + off, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+        if (sad_dist) HIPCHK(hipMemcpy(sad_dist, b->d_sad + off, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    }
+    return SD_OK;
+}
+
+int sd_batch_rgbd_from_u16(sd_batch* b, const uint16_t* d_depth, size_t stride_elems, size_t image_pitch_elems,
+                           int n_images, float depth_factor, float mbf, void* stream_)
+{
+    if (!b || !d_depth || n_images < 0) return SD_ERR_INVALID;
+    if (n_images > b->nExtracted) return set_err(SD_ERR_STATE, "rgbd lookup needs extracted images");
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
+    b->lastStream = s;
+    if (n_images == 0) return SD_OK;
+    {
+        ProfScope ps(b, s, K_RGBD);
+        dim3 grd((b->plan.kpCap + 255) / 256, n_images);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rgbd<uint16_t>), grd, dim3(256), 0, s, b->d_kp, b->d_count, d_depth, stride_elems,
+                           image_pitch_elems, depth_factor, mbf, b->d_uright, b->d_depth, b->d_plan);
+    }
+    LAUNCH_CHECK("k_rgbd");
+    return SD_OK;
+}
+
+int sd_batch_rgbd_from_f32(sd_batch* b, const float* d_depth, size_t stride_elems, size_t image_pitch_elems, int n_images,
+                           float mbf, void* stream_)
+{
+    if (!b || !d_depth || n_images < 0) return SD_ERR_INVALID;
+    if (n_images > b->nExtracted) return set_err(SD_ERR_STATE, "rgbd lookup needs extracted images");
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
+    b->lastStream = s;
+    if (n_images == 0) return SD_OK;
+    {
+        ProfScope ps(b, s, K_RGBD);
+        dim3 grd((b->plan.kpCap + 255) / 256, n_images);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rgbd<float>), grd, dim3(256), 0, s, b->d_kp, b->d_count, d_depth, stride_elems,
+                           image_pitch_elems, 1.0f, mbf, b->d_uright, b->d_depth, b->d_plan);
+    }
+    LAUNCH_CHECK("k_rgbd");
+    return SD_OK;
+}
+
+int sd_batch_download_rgbd(sd_batch* b, int image, float* uright, float* depth, int cap)
+{
+    if (!b || image < 0 || image >= b->nExtracted) return SD_ERR_INVALID;
+    int rc = sd_batch_sync(b);
+    if (rc != SD_OK) return rc;
+    int cnt = 0;
+    HIPCHK(hipMemcpy(&cnt, b->d_count + image, 4, hipMemcpyDeviceToHost));
+    if (cnt > cap) return set_err(SD_ERR_CAPACITY, "rgbd buffer too small");
+    const size_t off = (size_t)image * b->plan.kpCap;
+    if (cnt > 0) {
+        if (uright) HIPCHK(hipMemcpy(uright, b->d_uright + off, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+        if (depth) HIPCHK(hipMemcpy(depth, b->d_depth + off, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    }
+    return SD_OK;
+}
+
+// ---------------------------------------------------------------- preprocessing / Hamming
+int sd_cvt_gray_device(const uint8_t* d_src, int width, int height, size_t src_stride, size_t src_pitch, int channels,
+                       int rgb_order, uint8_t* d_dst, size_t dst_stride, size_t dst_pitch, int n_images, void* stream)
+{
+    if (!d_src || !d_dst || width < 1 || height < 1 || n_images < 0 || (channels != 3 && channels != 4)) return SD_ERR_INVALID;
+    if (n_images == 0) return SD_OK;
+    dim3 blk(64, 4), grd(((width + 3) / 4 + 63) / 64, (height + 3) / 4, n_images);
+    hipLaunchKernelGGL(k_cvt_gray, grd, blk, 0, (hipStream_t)stream, d_src, width, height, src_stride, src_pitch, channels,
+                       rgb_order, d_dst, dst_stride, dst_pitch);
+    LAUNCH_CHECK("k_cvt_gray");
+    return SD_OK;
+}
+
+int sd_depth_to_f32_device(const uint16_t* d_src, int width, int height, size_t src_stride_elems, float factor, float* d_dst,
+                           int n_images, size_t src_pitch_elems, void* stream)
+{
+    if (!d_src || !d_dst || width < 1 || height < 1 || n_images < 0) return SD_ERR_INVALID;
+    if (n_images == 0) return SD_OK;
+    dim3 blk(64, 4), grd((width + 63) / 64, (height + 3) / 4, n_images);
+    hipLaunchKernelGGL(k_depth_to_f32, grd, blk, 0, (hipStream_t)stream, d_src, width, height, src_stride_elems, src_pitch_elems,
+                       factor, d_dst);
+    LAUNCH_CHECK("k_depth_to_f32");
+    return SD_OK;
+}
+
+int sd_descriptor_distance(const uint8_t a[32], const uint8_t b[32])
+{
+    int d = 0;
+    for (int i = 0; i < 4; i++) {
+        uint64_t x, y;
+        memcpy(&x, a + 8 * i, 8); memcpy(&y, b + 8 * i, 8);
+        d += __builtin_popcountll(x ^ y);
+    }
+    return d;
+}
+
+int sd_hamming_matrix_device(const uint8_t* d_a, int na, const uint8_t* d_b, int nb, uint16_t* d_out, void* stream)
+{
+    if (!d_a || !d_b || !d_out || na < 0 || nb < 0) return SD_ERR_INVALID;
+    if (na == 0 || nb == 0) return SD_OK;
+    dim3 blk(64, 4), grd((nb + 63) / 64, (na + 3) / 4);
+    hipLaunchKernelGGL(k_hamming_matrix, grd, blk, 0, (hipStream_t)stream, d_a, na, d_b, nb, d_out);
+    LAUNCH_CHECK("k_hamming_matrix");
+    return SD_OK;
+}
+
+// ---------------------------------------------------------------- profiling
+int sd_batch_set_profiling(sd_batch* b, int enabled)
+{
+    if (!b) return SD_ERR_INVALID;
+    b->profiling = enabled != 0;
+    return SD_OK;
+}
+int sd_batch_kernel_count(const sd_batch* b, int* n)
+{
+    if (!b || !n) return SD_ERR_INVALID;
+    *n = K_COUNT;
+    return SD_OK;
+}
+int sd_batch_kernel_times(sd_batch* b, int index, const char** name, double* total_ms, int64_t* launches)
+{
+    if (!b || index < 0 || index >= K_COUNT) return SD_ERR_INVALID;
+    drain_profile(b);
+    if (name) *name = kKernelNames[index];
+    if (total_ms) *total_ms = b->totalMs[index];
+    if (launches) *launches = b->launches[index];
+    return SD_OK;
+}
+int sd_batch_reset_kernel_times(sd_batch* b)
+{
+    if (!b) return SD_ERR_INVALID;
+    drain_profile(b);
+    for (int i = 0; i < K_COUNT; i++) { b->totalMs[i] = 0; b->launches[i] = 0; }
+    return SD_OK;
+}
+
+} // extern "C"

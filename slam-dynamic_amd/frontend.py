@@ -1,0 +1,261 @@
+"""ctypes binding of libsd_frontend.so (the C ABI in include/sd_frontend.h).
+
+This is plumbing for tests and bench.py: the product is the shared library.  Class and
+method names follow the reference's C++ API (ORB_SLAM2::ORBextractor, Frame, ORBmatcher) so
+that the parity tests read like calls into the reference.  There is NO CPU fallback: if the
+library is missing, or no HIP device is present, calls raise.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsd_frontend.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+
+SD_OK = 0
+SD_ERR_INVALID, SD_ERR_NO_DEVICE, SD_ERR_HIP, SD_ERR_CAPACITY, SD_ERR_UNSUPPORTED, SD_ERR_STATE = -1, -2, -3, -4, -5, -6
+
+
+class SdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("sd_frontend error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP extension; raise loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
+                              % LIB_PATH)
+        try:
+            # torch bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's): import it first so the
+            # process holds ONE HIP runtime shared by torch (device memory, RCCL) and this library.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = C.CDLL(LIB_PATH)
+        L.sd_status_string.restype = C.c_char_p
+        L.sd_last_error.restype = C.c_char_p
+        vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+        L.sd_extractor_create.argtypes = [C.POINTER(vp), i, f, i, i, i]
+        L.sd_extractor_destroy.argtypes = [vp]
+        L.sd_extractor_set_blur_taps.argtypes = [vp, vp]
+        L.sd_extractor_levels.argtypes = [vp, C.POINTER(i), C.POINTER(f)]
+        L.sd_extractor_tables.argtypes = [vp] * 7
+        L.sd_extractor_level_size.argtypes = [vp, i, i, i, C.POINTER(i), C.POINTER(i)]
+        L.sd_batch_create.argtypes = [C.POINTER(vp), vp, i, i, i]
+        L.sd_batch_destroy.argtypes = [vp]
+        L.sd_batch_kp_capacity.argtypes = [vp, C.POINTER(i)]
+        L.sd_batch_extract_device.argtypes = [vp, vp, sz, sz, i, vp]
+        L.sd_batch_extract_host.argtypes = [vp, vp, sz, sz, i]
+        L.sd_batch_results_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i)]
+        L.sd_batch_counts.argtypes = [vp, vp, i]
+        L.sd_batch_download.argtypes = [vp, i, vp, vp, i, C.POINTER(i), vp]
+        L.sd_batch_pyramid_level.argtypes = [vp, i, i, C.POINTER(vp), C.POINTER(i), C.POINTER(i), C.POINTER(sz)]
+        L.sd_batch_download_pyramid.argtypes = [vp, i, i, vp]
+        L.sd_batch_download_blurred.argtypes = [vp, i, i, vp]
+        L.sd_batch_candidate_counts.argtypes = [vp, i, vp]
+        L.sd_batch_stereo_match.argtypes = [vp, i, f, f, vp]
+        L.sd_batch_stereo_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i)]
+        L.sd_batch_download_stereo.argtypes = [vp, i, vp, vp, vp, i]
+        L.sd_batch_rgbd_from_u16.argtypes = [vp, vp, sz, sz, i, f, f, vp]
+        L.sd_batch_rgbd_from_f32.argtypes = [vp, vp, sz, sz, i, f, vp]
+        L.sd_batch_download_rgbd.argtypes = [vp, i, vp, vp, i]
+        L.sd_cvt_gray_device.argtypes = [vp, i, i, sz, sz, i, i, vp, sz, sz, i, vp]
+        L.sd_depth_to_f32_device.argtypes = [vp, i, i, sz, f, vp, i, sz, vp]
+        L.sd_descriptor_distance.argtypes = [vp, vp]
+        L.sd_hamming_matrix_device.argtypes = [vp, i, vp, i, vp, vp]
+        L.sd_batch_set_profiling.argtypes = [vp, i]
+        L.sd_batch_kernel_count.argtypes = [vp, C.POINTER(i)]
+        L.sd_batch_kernel_times.argtypes = [vp, i, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.sd_batch_reset_kernel_times.argtypes = [vp]
+        L.sd_batch_sync.argtypes = [vp]
+        L.sd_device_count.argtypes = [C.POINTER(i)]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != SD_OK:
+        L = lib()
+        raise SdError(rc, (L.sd_status_string(rc) or b"").decode() + ": " + (L.sd_last_error() or b"").decode())
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class ORBextractor:
+    """ORB_SLAM2::ORBextractor (include/ORBextractor.h:45-114): parameters and derived tables."""
+
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST):
+        L = lib()
+        self.h = C.c_void_p()
+        check(L.sd_extractor_create(C.byref(self.h), nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST))
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+        self.mvScaleFactor = np.zeros(nlevels, np.float32); self.mvInvScaleFactor = np.zeros(nlevels, np.float32)
+        self.mvLevelSigma2 = np.zeros(nlevels, np.float32); self.mvInvLevelSigma2 = np.zeros(nlevels, np.float32)
+        self.mnFeaturesPerLevel = np.zeros(nlevels, np.int32); self.umax = np.zeros(16, np.int32)
+        check(L.sd_extractor_tables(self.h, _p(self.mvScaleFactor), _p(self.mvInvScaleFactor), _p(self.mvLevelSigma2),
+                                    _p(self.mvInvLevelSigma2), _p(self.mnFeaturesPerLevel), _p(self.umax)))
+
+    def __del__(self):
+        try:
+            lib().sd_extractor_destroy(self.h)
+        except Exception:
+            pass
+
+    def GetLevels(self):
+        n = C.c_int(); s = C.c_float()
+        check(lib().sd_extractor_levels(self.h, C.byref(n), C.byref(s)))
+        return n.value
+
+    def GetScaleFactor(self):
+        n = C.c_int(); s = C.c_float()
+        check(lib().sd_extractor_levels(self.h, C.byref(n), C.byref(s)))
+        return s.value
+
+    def set_blur_taps(self, taps):
+        t = np.asarray(taps, np.uint16)
+        check(lib().sd_extractor_set_blur_taps(self.h, _p(t)))
+
+    def level_size(self, width, height, level):
+        w = C.c_int(); h = C.c_int()
+        check(lib().sd_extractor_level_size(self.h, width, height, level, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+
+class Batch:
+    """Device workspace: batched ORBextractor::operator() + the Frame-side association steps."""
+
+    def __init__(self, extractor, width, height, max_images):
+        self.ex = extractor
+        self.W, self.H, self.max_images = width, height, max_images
+        self.h = C.c_void_p()
+        check(lib().sd_batch_create(C.byref(self.h), extractor.h, width, height, max_images))
+        c = C.c_int()
+        check(lib().sd_batch_kp_capacity(self.h, C.byref(c)))
+        self.cap = c.value
+
+    def close(self):
+        if self.h:
+            lib().sd_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- extraction
+    def extract_host(self, images):
+        """images: (n, H, W) u8 array (or list of (H, W) arrays)."""
+        arr = np.ascontiguousarray(np.stack(images) if isinstance(images, (list, tuple)) else images, np.uint8)
+        if arr.ndim == 2:
+            arr = arr[None]
+        n, h, w = arr.shape
+        assert (h, w) == (self.H, self.W)
+        check(lib().sd_batch_extract_host(self.h, _p(arr), w, w * h, n))
+        return n
+
+    def extract_device(self, d_ptr, stride, pitch, n, stream=None):
+        check(lib().sd_batch_extract_device(self.h, C.c_void_p(d_ptr), stride, pitch, n, C.c_void_p(stream or 0)))
+
+    def sync(self):
+        check(lib().sd_batch_sync(self.h))
+
+    def counts(self, n):
+        out = np.zeros(n, np.int32)
+        check(lib().sd_batch_counts(self.h, _p(out), n))
+        return out
+
+    def download(self, image):
+        kp = np.zeros(self.cap, KP_DTYPE); desc = np.zeros((self.cap, 32), np.uint8)
+        per_level = np.zeros(self.ex.nlevels, np.int32)
+        n = C.c_int()
+        check(lib().sd_batch_download(self.h, image, _p(kp), _p(desc), self.cap, C.byref(n), _p(per_level)))
+        return kp[:n.value].copy(), desc[:n.value].copy(), per_level
+
+    def pyramid(self, image, level):
+        w, h = self.ex.level_size(self.W, self.H, level)
+        out = np.zeros((h + 38, w + 38), np.uint8)
+        check(lib().sd_batch_download_pyramid(self.h, image, level, _p(out)))
+        return out
+
+    def blurred(self, image, level):
+        w, h = self.ex.level_size(self.W, self.H, level)
+        out = np.zeros((h, w), np.uint8)
+        check(lib().sd_batch_download_blurred(self.h, image, level, _p(out)))
+        return out
+
+    def candidate_counts(self, image):
+        out = np.zeros(self.ex.nlevels, np.int32)
+        check(lib().sd_batch_candidate_counts(self.h, image, _p(out)))
+        return out
+
+    def results_device(self):
+        kp, desc, cnt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        cap = C.c_int()
+        check(lib().sd_batch_results_device(self.h, C.byref(kp), C.byref(desc), C.byref(cnt), C.byref(cap)))
+        return kp.value, desc.value, cnt.value, cap.value
+
+    # -- Frame::ComputeStereoMatches
+    def stereo_match(self, n_frames, mbf, fx, stream=None):
+        check(lib().sd_batch_stereo_match(self.h, n_frames, mbf, fx, C.c_void_p(stream or 0)))
+
+    def download_stereo(self, frame):
+        ur = np.zeros(self.cap, np.float32); dep = np.zeros(self.cap, np.float32); sad = np.zeros(self.cap, np.int32)
+        check(lib().sd_batch_download_stereo(self.h, frame, _p(ur), _p(dep), _p(sad), self.cap))
+        return ur, dep, sad
+
+    # -- Frame::ComputeStereoFromRGBD
+    def rgbd_from_u16(self, d_depth_ptr, stride_elems, pitch_elems, n, depth_factor, mbf, stream=None):
+        check(lib().sd_batch_rgbd_from_u16(self.h, C.c_void_p(d_depth_ptr), stride_elems, pitch_elems, n, depth_factor,
+                                           mbf, C.c_void_p(stream or 0)))
+
+    def rgbd_from_f32(self, d_depth_ptr, stride_elems, pitch_elems, n, mbf, stream=None):
+        check(lib().sd_batch_rgbd_from_f32(self.h, C.c_void_p(d_depth_ptr), stride_elems, pitch_elems, n, mbf,
+                                           C.c_void_p(stream or 0)))
+
+    def download_rgbd(self, image):
+        ur = np.zeros(self.cap, np.float32); dep = np.zeros(self.cap, np.float32)
+        check(lib().sd_batch_download_rgbd(self.h, image, _p(ur), _p(dep), self.cap))
+        return ur, dep
+
+    # -- profiling
+    def set_profiling(self, on):
+        check(lib().sd_batch_set_profiling(self.h, int(bool(on))))
+
+    def reset_kernel_times(self):
+        check(lib().sd_batch_reset_kernel_times(self.h))
+
+    def kernel_times(self):
+        n = C.c_int()
+        check(lib().sd_batch_kernel_count(self.h, C.byref(n)))
+        out = {}
+        for i in range(n.value):
+            name = C.c_char_p(); ms = C.c_double(); cnt = C.c_int64()
+            check(lib().sd_batch_kernel_times(self.h, i, C.byref(name), C.byref(ms), C.byref(cnt)))
+            out[name.value.decode()] = (ms.value, cnt.value)
+        return out
+
+
+def DescriptorDistance(a, b):
+    """ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1804-1820), host popcount."""
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return lib().sd_descriptor_distance(_p(a), _p(b))
+
+
+def device_count():
+    n = C.c_int()
+    rc = lib().sd_device_count(C.byref(n))
+    return n.value if rc == SD_OK else 0

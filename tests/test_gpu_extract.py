@@ -1,0 +1,78 @@
+"""GPU parity of the ORB extractor against the CPU oracle, through the C ABI (bit-exact)."""
+import numpy as np
+import pytest
+
+from conftest import assert_kp_equal
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (width, height, nfeatures, iniTh, minTh, kind, seed)
+    (1241, 376, 2000, 12, 7, "texture", 3),      # KITTI04-12 stereo settings
+    (1241, 376, 2000, 20, 7, "texture", 4),      # KITTI03 settings
+    (640, 480, 1000, 20, 7, "texture", 5),       # TUM (BASELINE config 1 feature count)
+    (640, 480, 1500, 20, 7, "noise", 6),         # uniform noise: every cell saturated with corners
+    (752, 480, 1200, 20, 7, "texture", 7),       # EuRoC-like size: different cell grid / nIni
+    (331, 257, 500, 20, 7, "texture", 8),        # small, odd sizes
+]
+
+
+def _run_case(fe, orc, synth, w, h, nf, ini, mn, kind, seed, n_img=2):
+    imgs = [synth.random_image(w, h, seed + 17 * i, kind) for i in range(n_img)]
+    ex = fe.ORBextractor(nf, 1.2, 8, ini, mn)
+    b = fe.Batch(ex, w, h, n_img)
+    b.extract_host(np.stack(imgs))
+    for i, im in enumerate(imgs):
+        o = orc.Extractor(nf, 1.2, 8, ini, mn)
+        rk, rd = o(im)
+        for l in range(8):
+            assert np.array_equal(b.pyramid(i, l), o.pyramid(l)), "pyramid level %d of image %d" % (l, i)
+            assert np.array_equal(b.blurred(i, l), o.blurred(l)), "blurred level %d of image %d" % (l, i)
+        assert np.array_equal(b.candidate_counts(i), o.cand_per_level), "FAST candidate counts, image %d" % i
+        kp, desc, per_level = b.download(i)
+        assert np.array_equal(per_level, o.per_level), "per-level keypoint counts, image %d: %r vs %r" % (i, per_level, o.per_level)
+        assert_kp_equal(kp, rk, "image %d" % i)
+        assert np.array_equal(desc, rd), "descriptors of image %d" % i
+    b.close()
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d_%d_%s" % (c[0], c[1], c[2], c[5]))
+def test_extract_matches_oracle(gpu, fe, orc, synth, case):
+    _run_case(fe, orc, synth, *case)
+
+
+def test_tables_match_oracle(gpu, fe, orc):
+    ex = fe.ORBextractor(2000, 1.2, 8, 20, 7)
+    o = orc.Extractor(2000, 1.2, 8, 20, 7)
+    assert np.array_equal(ex.mvScaleFactor.view(np.uint32), o.scale.view(np.uint32))
+    assert np.array_equal(ex.mnFeaturesPerLevel, o.quota)
+    assert np.array_equal(ex.umax, o.umax)
+
+
+def test_flat_image_gives_no_keypoints(gpu, fe):
+    """No corners anywhere -> 0 keypoints and an empty descriptor matrix (ORBextractor.cc:1064-1065)."""
+    ex = fe.ORBextractor(1000, 1.2, 8, 20, 7)
+    b = fe.Batch(ex, 640, 480, 1)
+    b.extract_host(np.full((1, 480, 640), 77, np.uint8))
+    kp, desc, per_level = b.download(0)
+    assert len(kp) == 0 and desc.shape == (0, 32) and per_level.sum() == 0
+    b.close()
+
+
+def test_batch_slots_are_independent(gpu, fe, synth):
+    """The same image in different batch slots gives identical results (no cross-image state)."""
+    im0 = synth.random_image(640, 480, 21)
+    im1 = synth.random_image(640, 480, 22)
+    ex = fe.ORBextractor(1000, 1.2, 8, 20, 7)
+    b = fe.Batch(ex, 640, 480, 4)
+    b.extract_host(np.stack([im0, im1, im0, im1]))
+    k0, d0, _ = b.download(0); k2, d2, _ = b.download(2)
+    k1, d1, _ = b.download(1); k3, d3, _ = b.download(3)
+    assert k0.tobytes() == k2.tobytes() and d0.tobytes() == d2.tobytes()
+    assert k1.tobytes() == k3.tobytes() and d1.tobytes() == d3.tobytes()
+    assert k0.tobytes() != k1.tobytes()
+    # re-running the batch is idempotent
+    b.extract_host(np.stack([im0, im1, im0, im1]))
+    k0b, d0b, _ = b.download(0)
+    assert k0.tobytes() == k0b.tobytes() and d0.tobytes() == d0b.tobytes()
+    b.close()
