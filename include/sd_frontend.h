@@ -99,9 +99,10 @@ int sd_batch_candidate_counts(sd_batch* b, int image, int32_t* per_level);
 
 /* ---- Frame::ComputeStereoMatches (src/Frame.cc:874-1048) ----
  * The batch must hold n_frames stereo pairs extracted as images 2f (left) and 2f+1 (right).
- * mbf = Camera.bf, fx = Camera.fx (mb = mbf/fx, Frame.cc:228).  Outputs per left keypoint. */
+ * mbf = Camera.bf, fx = Camera.fx (mb = mbf/fx, Frame.cc:228).  Outputs per left keypoint, stored at the
+ * LEFT image's slot (image index 2f) of the [max_images][cap] arrays. */
 int sd_batch_stereo_match(sd_batch* b, int n_frames, float mbf, float fx, void* stream);
-int sd_batch_stereo_device(sd_batch* b, float** d_uright, float** d_depth, int* cap); /* [n_frames][cap] */
+int sd_batch_stereo_device(sd_batch* b, float** d_uright, float** d_depth, int* cap); /* [max_images][cap] */
 int sd_batch_download_stereo(sd_batch* b, int frame, float* uright, float* depth, int32_t* sad_dist, int cap);
 
 /* ---- Frame::ComputeStereoFromRGBD (src/Frame.cc:1051-1072) + depth scaling (Tracking.cc:271-272) ----
@@ -113,6 +114,49 @@ int sd_batch_rgbd_from_u16(sd_batch* b, const uint16_t* d_depth, size_t stride_e
 int sd_batch_rgbd_from_f32(sd_batch* b, const float* d_depth, size_t stride_elems, size_t image_pitch_elems,
                            int n_images, float mbf, void* stream);
 int sd_batch_download_rgbd(sd_batch* b, int image, float* uright, float* depth, int cap);
+
+
+/* ---- Frame statics (include/Frame.h:160-210): intrinsics, stereo baseline, undistorted image bounds ---- */
+typedef struct sd_camera {
+    float fx, fy, cx, cy, mbf, mb;               /* mb = mbf/fx (Frame.cc:228) */
+    float mnMinX, mnMaxX, mnMinY, mnMaxY;        /* Frame::ComputeImageBounds (Frame.cc:844-872) */
+} sd_camera;
+
+/* Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:463-478,790-800): the 64x48 grid cell of every
+ * keypoint (posX*48 + posY, or -1 outside).  The device form of mGrid: per-cell lists are implied by
+ * (cell, keypoint index) order, which is the visiting order of GetFeaturesInArea (Frame.cc:735-788). */
+int sd_batch_assign_grid(sd_batch* b, int n_images, const sd_camera* cam, void* stream);
+int sd_batch_download_grid(sd_batch* b, int image, int16_t* cell, int cap);
+
+/* Frame::UnprojectStereo (src/Frame.cc:1074-1088) for every keypoint of frames first_image + k*image_step,
+ * k < n_frames, using the depth of the preceding stereo / RGB-D step.  Twc_host: n_frames row-major 4x4
+ * [mRwc | mOw].  Fills the batch's map-point table: world position + flags (bit0 valid, bit1 = the map
+ * point has Observations() > 0, never set here).  first_image must be 0. */
+int sd_batch_unproject(sd_batch* b, int first_image, int image_step, int n_frames, const sd_camera* cam,
+                       const float* Twc_host, void* stream);
+/* The map-point table ([max_images][cap][3] f32, [max_images][cap] u8): a caller that owns real MapPoints
+ * (Tracking) writes LastFrame.mvpMapPoints[i]->GetWorldPos() / flags here instead of calling unproject. */
+int sd_batch_mappoints_device(sd_batch* b, float** d_xw, uint8_t** d_flags, int* cap);
+int sd_batch_set_mappoints(sd_batch* b, int image, const float* xw, const uint8_t* flags, int n);
+int sd_batch_download_mappoints(sd_batch* b, int image, float* xw, uint8_t* flags, int cap);
+
+/* ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, th, bMono[, points_last, points_current])
+ * (src/ORBmatcher.cc:1485-1627 and the pair-emitting overload :407-559, called from Tracking::TrackHomo,
+ * Tracking.cc:998-1010, and TrackWithMotionModel).  Pair p matches Current = image cur_first + p*image_step
+ * against Last = image last_first + p*image_step of the same batch (sd_batch_assign_grid must have run on
+ * the Current images).  Tcw_host / Tlw_host: n_pairs row-major 4x4 poses (CurrentFrame.mTcw, LastFrame.mTcw).
+ * d_occupied (nullable, [n_pairs][cap] u8): CurrentFrame.mvpMapPoints[i2] already holds a point with
+ * Observations() > 0.  d_mp_desc (nullable, [max_images][cap][32]): pMP->GetDescriptor() of the Last frame's
+ * points; NULL = the Last frame's own descriptors.
+ * Results: match[i2] = index of the Last-frame point assigned to Current keypoint i2 or -1 (the new
+ * CurrentFrame.mvpMapPoints); pairs = (i, i2) in order of i == points_last / points_current BEFORE the
+ * rotation-histogram cull (ORBmatcher.cc:505-506); nmatches = the function's return value. */
+int sd_batch_search_by_projection(sd_batch* b, int cur_first, int last_first, int image_step, int n_pairs,
+                                  const float* Tcw_host, const float* Tlw_host, const sd_camera* cam, float th, int bMono,
+                                  int checkOrientation, const uint8_t* d_occupied, const uint8_t* d_mp_desc, void* stream);
+int sd_batch_matches_device(sd_batch* b, int32_t** d_match, int32_t** d_pairs, int32_t** d_npairs, int32_t** d_nmatches,
+                            int* cap);
+int sd_batch_download_matches(sd_batch* b, int pair, int32_t* match, int32_t* pairs, int cap, int* npairs, int* nmatches);
 
 /* ---- Tracking::GrabImage* preprocessing (src/Tracking.cc:170-343) ---- */
 /* cvtColor(RGB|BGR|RGBA|BGRA -> GRAY); rgb_order = Camera.RGB.  channels 3 or 4. */

@@ -158,3 +158,37 @@ def stereo_matches(exL, exR, kpL, descL, kpR, descR, mbf, fx):
     nm = lib().orc_stereo_matches(exL.h, exR.h, _p(kpL), _p(descL), n, _p(kpR), _p(descR), len(kpR), C.c_float(mbf),
                                   C.c_float(fx), _p(ur), _p(dep), _p(bd))
     return ur, dep, bd, nm
+
+
+def grid_cells(kp, cam10):
+    kp = np.ascontiguousarray(kp); c = np.ascontiguousarray(cam10, np.float32)
+    out = np.zeros(len(kp), np.int32)
+    lib().orc_grid_cells(_p(kp), len(kp), _p(c), _p(out))
+    return out
+
+
+def unproject(kp, depth, cam10, Twc):
+    kp = np.ascontiguousarray(kp); d = np.ascontiguousarray(depth, np.float32)
+    c = np.ascontiguousarray(cam10, np.float32); T = np.ascontiguousarray(Twc, np.float32).reshape(16)
+    xw = np.zeros((len(kp), 3), np.float32); valid = np.zeros(len(kp), np.uint8)
+    lib().orc_unproject(_p(kp), _p(d), len(kp), _p(c), _p(T), _p(xw), _p(valid))
+    return xw, valid
+
+
+def search_by_projection(kpC, descC, uRightC, kpL, dMP, xw, flags, Tcw, Tlw, cam10, scale_factors, th, bMono=False,
+                         checkOrientation=True, occupied=None):
+    kpC = np.ascontiguousarray(kpC); kpL = np.ascontiguousarray(kpL)
+    descC = np.ascontiguousarray(descC, np.uint8); dMP = np.ascontiguousarray(dMP, np.uint8)
+    uR = np.ascontiguousarray(uRightC, np.float32); xw = np.ascontiguousarray(xw, np.float32)
+    flags = np.ascontiguousarray(flags, np.uint8)
+    Tc = np.ascontiguousarray(Tcw, np.float32).reshape(16); Tl = np.ascontiguousarray(Tlw, np.float32).reshape(16)
+    c = np.ascontiguousarray(cam10, np.float32); sf = np.ascontiguousarray(scale_factors, np.float32)
+    Nc, Nl = len(kpC), len(kpL)
+    match = np.zeros(Nc, np.int32); pairs = np.zeros((Nl, 2), np.int32); npairs = C.c_int()
+    occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+    f = lib().orc_search_by_projection
+    f.restype = C.c_int
+    nm = f(_p(kpC), _p(descC), _p(uR), Nc, _p(kpL), _p(dMP), Nl, _p(xw), _p(flags), _p(Tc), _p(Tl), _p(c), _p(sf),
+           C.c_float(th), int(bMono), int(checkOrientation), _p(occ) if occ is not None else None, _p(match), _p(pairs),
+           C.byref(npairs))
+    return match, pairs[:npairs.value].copy(), nm

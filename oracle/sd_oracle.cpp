@@ -632,4 +632,6 @@ int orc_stereo_matches(void* hL, void* hR, const void* kL_, const uint8_t* dL, i
     return nm;
 }
 
+#include "frame_oracle.inc"
+
 } // extern "C"

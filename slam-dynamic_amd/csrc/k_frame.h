@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(256) k_stereo_match(const sd_keypoint* __restr
     const int imgL = 2 * f, imgR = 2 * f + 1;
     const int N = count[imgL], Nr = count[imgR];
     if (iL >= N) return;
-    const size_t o = (size_t)f * P.kpCap + iL;
+    const size_t o = (size_t)imgL * P.kpCap + iL;   // outputs are indexed by the LEFT image
     const sd_keypoint kL = kp[(size_t)imgL * P.kpCap + iL];
     const uint4* dl = (const uint4*)(desc + ((size_t)imgL * P.kpCap + iL) * 32);
     const uint4 l0 = dl[0], l1 = dl[1];
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) k_stereo_filter(const int* __restrict__ c
     __shared__ int s_red[4];
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int N = count[2 * f];
-    const size_t base = (size_t)f * P.kpCap;
+    const size_t base = (size_t)(2 * f) * P.kpCap;
     // number of matches
     int c = 0;
     for (int i = tid; i < N; i += 256) c += sad[base + i] >= 0;
@@ -232,4 +232,312 @@ __global__ void __launch_bounds__(256) k_hamming_matrix(const uint8_t* __restric
     const uint4* pa = (const uint4*)(a + (size_t)i * 32);
     const uint4* pb = (const uint4*)(b + (size_t)j * 32);
     out[(size_t)i * nb + j] = (uint16_t)sd_hamming256(pa[0], pa[1], pb[0], pb[1]);
+}
+
+// =====================================================================================
+// Frame grid, UnprojectStereo, and the Frame<->Frame projection matcher
+//   k_grid_cells        Frame::PosInGrid / AssignFeaturesToGrid       src/Frame.cc:463-478,790-800
+//   k_unproject         Frame::UnprojectStereo                        src/Frame.cc:1074-1088
+//   k_proj_candidates   ORBmatcher::SearchByProjection, search part   src/ORBmatcher.cc:407-485,1485-1570
+//   k_proj_resolve      ... assignment order, rotation histogram      src/ORBmatcher.cc:487-559,1572-1627
+// =====================================================================================
+#define SD_GRID_COLS 64   // FRAME_GRID_COLS, Frame.h:40
+#define SD_GRID_ROWS 48   // FRAME_GRID_ROWS, Frame.h:39
+#define SD_HISTO 30       // HISTO_LENGTH, ORBmatcher.cc:39
+#define SD_PROJ_K 64      // candidates kept per projected point (one per lane)
+
+struct SdCamera { float fx, fy, cx, cy, mbf, mb, mnMinX, mnMaxX, mnMinY, mnMaxY; };
+
+// cell id = posX*48 + posY, or -1 when the keypoint falls outside the 64x48 grid.  The reference's
+// per-cell index lists are ordered by keypoint index, so (cell id, index) is the visiting order of
+// GetFeaturesInArea (cells ix-major, iy-minor; insertion order inside a cell).
+__global__ void __launch_bounds__(256) k_grid_cells(const sd_keypoint* __restrict__ kp, const int* __restrict__ count,
+                                                    short* __restrict__ cellOf, SdCamera cam, int cap)
+{
+    const int img = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count[img]) return;
+    const sd_keypoint k = kp[(size_t)img * cap + i];
+    const float wInv = (float)SD_GRID_COLS / (cam.mnMaxX - cam.mnMinX);
+    const float hInv = (float)SD_GRID_ROWS / (cam.mnMaxY - cam.mnMinY);
+    const int px = (int)roundf((k.x - cam.mnMinX) * wInv), py = (int)roundf((k.y - cam.mnMinY) * hInv);
+    const bool in = !(px < 0 || px >= SD_GRID_COLS || py < 0 || py >= SD_GRID_ROWS);
+    cellOf[(size_t)img * cap + i] = (short)(in ? px * SD_GRID_ROWS + py : -1);
+}
+
+__device__ __forceinline__ void sd_mat3_mul_add(const float* __restrict__ T /*row-major 4x4*/, float x, float y, float z,
+                                                float& ox, float& oy, float& oz)
+{
+    // t = (a0*b0 + a1*b1) + a2*b2 ; d = t + c   (f32, left to right, no contraction)
+    float s;
+    s = T[0] * x + T[1] * y; s = s + T[2] * z; ox = s + T[3];
+    s = T[4] * x + T[5] * y; s = s + T[6] * z; oy = s + T[7];
+    s = T[8] * x + T[9] * y; s = s + T[10] * z; oz = s + T[11];
+}
+
+__global__ void __launch_bounds__(256) k_unproject(const sd_keypoint* __restrict__ kp, const int* __restrict__ count,
+                                                   const float* __restrict__ depth, const float* __restrict__ Twc,
+                                                   float* __restrict__ xw, uint8_t* __restrict__ flags, SdCamera cam,
+                                                   int cap, int imgStep)
+{
+    const int img = blockIdx.y * imgStep, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count[img]) return;
+    const size_t o = (size_t)img * cap + i;
+    const float z = depth[o];
+    float X = 0.f, Y = 0.f, Z = 0.f;
+    uint8_t f = 0;
+    if (z > 0) {
+        const sd_keypoint k = kp[o];
+        const float invfx = 1.0f / cam.fx, invfy = 1.0f / cam.fy;
+        const float x = (k.x - cam.cx) * z * invfx;
+        const float y = (k.y - cam.cy) * z * invfy;
+        sd_mat3_mul_add(Twc + (size_t)blockIdx.y * 16, x, y, z, X, Y, Z);
+        f = 1;
+    }
+    xw[3 * o] = X; xw[3 * o + 1] = Y; xw[3 * o + 2] = Z;
+    flags[o] = f;
+}
+
+// Phase A: one wave per Last-frame map point.  Projects it, scans the Current frame's keypoints for the
+// members of GetFeaturesInArea(u, v, radius, level range) and keeps the (<= 64) candidates with Hamming
+// distance <= TH_HIGH sorted by (distance, visiting order).  No assignment state is touched here.
+__global__ void __launch_bounds__(256) k_proj_candidates(
+    const sd_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc, const float* __restrict__ uRight,
+    const int* __restrict__ count, const short* __restrict__ cellOf, const float* __restrict__ xw,
+    const uint8_t* __restrict__ flags, const uint8_t* __restrict__ dmp, const float* __restrict__ Tcw,
+    const float* __restrict__ Tlw, unsigned short* __restrict__ cand, uint8_t* __restrict__ ncand,
+    int* __restrict__ errFlag, const SdDevPlan* __restrict__ PP, SdCamera cam, float th, int bMono, int curFirst,
+    int lastFirst, int step)
+{
+    const SdDevPlan& P = *PP;
+    __shared__ unsigned long long s_keys[4][SD_PROJ_K];
+    const int pair = blockIdx.y;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wv;
+    const int imgC = curFirst + pair * step, imgL = lastFirst + pair * step;
+    const int cap = P.kpCap;
+    const int Nl = count[imgL], Nc = count[imgC];
+    if (i >= Nl) return;
+    const size_t oL = (size_t)imgL * cap + i;
+    const size_t oOut = (size_t)pair * cap + i;
+    int n = 0;
+    bool ok = (flags[oL] & 1) != 0;
+    float u = 0.f, v = 0.f, invzc = 0.f, radius = 0.f;
+    int minLevel = -1, maxLevel = -1;
+    if (ok) {
+        const float* T = Tcw + (size_t)pair * 16;
+        float xc, yc, zc;
+        sd_mat3_mul_add(T, xw[3 * oL], xw[3 * oL + 1], xw[3 * oL + 2], xc, yc, zc);
+        invzc = 1.0f / zc;
+        if (invzc < 0) ok = false;
+        u = cam.fx * xc * invzc + cam.cx;
+        v = cam.fy * yc * invzc + cam.cy;
+        if (u < cam.mnMinX || u > cam.mnMaxX) ok = false;
+        if (v < cam.mnMinY || v > cam.mnMaxY) ok = false;
+        // bForward / bBackward (ORBmatcher.cc:1497-1510): tlc = Rlw*twc + tlw, twc = -Rcw^T * tcw
+        const float* Tl = Tlw + (size_t)pair * 16;
+        float twx, twy, twz, s;
+        s = (-T[0]) * T[3] + (-T[4]) * T[7]; twx = s + (-T[8]) * T[11];
+        s = (-T[1]) * T[3] + (-T[5]) * T[7]; twy = s + (-T[9]) * T[11];
+        s = (-T[2]) * T[3] + (-T[6]) * T[7]; twz = s + (-T[10]) * T[11];
+        float lx, ly, lz;
+        sd_mat3_mul_add(Tl, twx, twy, twz, lx, ly, lz);
+        const bool bForward = lz > cam.mb && !bMono, bBackward = -lz > cam.mb && !bMono;
+        const int nLastOctave = kp[oL].octave;
+        radius = th * P.lv[nLastOctave].scale;
+        if (bForward) { minLevel = nLastOctave; maxLevel = -1; }
+        else if (bBackward) { minLevel = 0; maxLevel = nLastOctave; }
+        else { minLevel = nLastOctave - 1; maxLevel = nLastOctave + 1; }
+    }
+    if (ok) {
+        const float wInv = (float)SD_GRID_COLS / (cam.mnMaxX - cam.mnMinX);
+        const float hInv = (float)SD_GRID_ROWS / (cam.mnMaxY - cam.mnMinY);
+        const int nMinCellX = max(0, (int)floorf((u - cam.mnMinX - radius) * wInv));
+        const int nMaxCellX = min(SD_GRID_COLS - 1, (int)ceilf((u - cam.mnMinX + radius) * wInv));
+        const int nMinCellY = max(0, (int)floorf((v - cam.mnMinY - radius) * hInv));
+        const int nMaxCellY = min(SD_GRID_ROWS - 1, (int)ceilf((v - cam.mnMinY + radius) * hInv));
+        if (nMinCellX >= SD_GRID_COLS || nMaxCellX < 0 || nMinCellY >= SD_GRID_ROWS || nMaxCellY < 0) ok = false;
+        if (ok) {
+            const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+            const uint4* dl = (const uint4*)(dmp + oL * 32);
+            const uint4 l0 = dl[0], l1 = dl[1];
+            const sd_keypoint* kC = kp + (size_t)imgC * cap;
+            const short* cellC = cellOf + (size_t)imgC * cap;
+            const float* urC = uRight + (size_t)imgC * cap;
+            const uint8_t* dC = desc + (size_t)imgC * cap * 32;
+            const float ur = u - cam.mbf * invzc;
+            for (int base = 0; base < Nc; base += 64) {
+                const int i2 = base + lane;
+                bool hit = false;
+                unsigned long long key = 0;
+                if (i2 < Nc) {
+                    const int cell = cellC[i2];
+                    const int cx = cell / SD_GRID_ROWS, cy = cell - cx * SD_GRID_ROWS;
+                    if (cell >= 0 && cx >= nMinCellX && cx <= nMaxCellX && cy >= nMinCellY && cy <= nMaxCellY) {
+                        const sd_keypoint k = kC[i2];
+                        bool lv = true;
+                        if (bCheckLevels) {
+                            if (k.octave < minLevel) lv = false;
+                            if (maxLevel >= 0 && k.octave > maxLevel) lv = false;
+                        }
+                        const float distx = k.x - u, disty = k.y - v;
+                        if (lv && fabsf(distx) < radius && fabsf(disty) < radius) {
+                            bool rOk = true;
+                            const float r2 = urC[i2];
+                            if (r2 > 0) { const float er = fabsf(ur - r2); if (er > radius) rOk = false; }
+                            if (rOk) {
+                                const uint4* dr = (const uint4*)(dC + (size_t)i2 * 32);
+                                const int dist = sd_hamming256(l0, l1, dr[0], dr[1]);
+                                if (dist <= SD_TH_HIGH) {
+                                    hit = true;
+                                    key = ((unsigned long long)dist << 32) | ((unsigned long long)cell << 16) | (unsigned)i2;
+                                }
+                            }
+                        }
+                    }
+                }
+                const unsigned long long m = __ballot(hit);
+                if (hit) {
+                    const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < SD_PROJ_K) s_keys[wv][pos] = key;
+                }
+                n += __popcll(m);
+            }
+        }
+    }
+    if (n > SD_PROJ_K) { if (lane == 0) atomicOr(errFlag, 4); n = SD_PROJ_K; }
+    // wave-wide bitonic sort of <= 64 keys (one per lane), ascending
+    unsigned long long key = lane < n ? s_keys[wv][lane] : ~0ull;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)key, j, 64);
+            const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(key >> 32), j, 64);
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            const bool up = ((lane & k) == 0);
+            const bool lower = ((lane & j) == 0);
+            const bool takeMin = (up == lower);
+            key = takeMin ? (key < other ? key : other) : (key > other ? key : other);
+        }
+    if (lane < n) cand[oOut * SD_PROJ_K + lane] = (unsigned short)(key & 0xFFFFu);
+    if (lane == 0) ncand[oOut] = (uint8_t)n;
+}
+
+// Phase B: one wave per frame pair walks the Last-frame points in index order (the order that decides
+// which Current keypoints are already taken, ORBmatcher.cc:462-465) in chunks of 64.  A chunk is
+// committed in parallel unless two of its points want the same keypoint and the earlier one carries a
+// map point with observations; only then the chunk is replayed serially.
+__global__ void __launch_bounds__(64) k_proj_resolve(
+    const sd_keypoint* __restrict__ kp, const int* __restrict__ count, const uint8_t* __restrict__ flags,
+    const unsigned short* __restrict__ cand, const uint8_t* __restrict__ ncand, const uint8_t* __restrict__ occupied,
+    int* __restrict__ matchOut, int* __restrict__ pairsOut, int* __restrict__ npairsOut, int* __restrict__ nmatchOut,
+    const SdDevPlan* __restrict__ PP, int checkOrientation, int curFirst, int lastFirst, int step)
+{
+    const SdDevPlan& P = *PP;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int cap = P.kpCap;
+    int* s_match = (int*)smem;                              // [cap]
+    uint8_t* s_taken = (uint8_t*)(s_match + cap);           // [cap]
+    uint8_t* s_bin = s_taken + ((cap + 15) & ~15);          // [cap]  rotation bin of pair p
+    __shared__ int s_hist[SD_HISTO];
+    __shared__ int s_ind[3];
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    const int imgC = curFirst + pair * step, imgL = lastFirst + pair * step;
+    const int Nl = count[imgL], Nc = count[imgC];
+    const sd_keypoint* kC = kp + (size_t)imgC * cap;
+    const sd_keypoint* kL = kp + (size_t)imgL * cap;
+    const uint8_t* fl = flags + (size_t)imgL * cap;
+    const unsigned short* cd = cand + (size_t)pair * cap * SD_PROJ_K;
+    const uint8_t* nc = ncand + (size_t)pair * cap;
+    int* pairs = pairsOut + (size_t)pair * cap * 2;
+    for (int i = lane; i < Nc; i += 64) { s_match[i] = -1; s_taken[i] = occupied ? occupied[(size_t)pair * cap + i] : 0; }
+    if (lane < SD_HISTO) s_hist[lane] = 0;
+    __syncthreads();
+    const float factor = 1.0f / SD_HISTO;
+    int np = 0;
+    for (int base = 0; base < Nl; base += 64) {
+        const int i = base + lane;
+        const int n = i < Nl ? nc[i] : 0;
+        const bool obs = i < Nl && (fl[i] & 2) != 0;
+        // speculative pick against the state at chunk start
+        int pick = -1;
+        for (int j = 0; j < n; j++) {
+            const int c = cd[(size_t)i * SD_PROJ_K + j];
+            if (!s_taken[c]) { pick = c; break; }
+        }
+        // conflict: an earlier lane with observations wants the same keypoint
+        bool conflict = false;
+        const unsigned long long obsMask = __ballot(obs && pick >= 0);
+        if (obsMask) {
+            for (int s = 1; s < 64; s++) {
+                const int src = lane - s;
+                const int op = __shfl(pick, src & 63, 64);
+                const int oo = __shfl((int)obs, src & 63, 64);
+                if (src >= 0 && oo && op >= 0 && op == pick) conflict = true;
+            }
+        }
+        if (__ballot(conflict)) {
+            // serial replay of this chunk in index order
+            for (int l = 0; l < 64; l++) {
+                const int il = base + l;
+                if (il >= Nl) break;
+                const int nl = nc[il];
+                int p = -1;
+                for (int j = 0; j < nl; j++) {
+                    const int c = cd[(size_t)il * SD_PROJ_K + j];
+                    if (!s_taken[c]) { p = c; break; }
+                }
+                if (lane == l) pick = p;
+                if (p >= 0 && (fl[il] & 2) && lane == 0) s_taken[p] = 1;
+                __syncthreads();
+            }
+        } else {
+            if (pick >= 0 && obs) s_taken[pick] = 1;
+        }
+        // commit in index order: mvpMapPoints[bestIdx2] = pMP (later points overwrite)
+        if (pick >= 0) atomicMax(&s_match[pick], i);
+        const unsigned long long pm = __ballot(pick >= 0);
+        if (pick >= 0) {
+            const int p = np + __popcll(pm & ((1ull << lane) - 1ull));
+            pairs[2 * p] = i; pairs[2 * p + 1] = pick;
+            int bin = 0;
+            if (checkOrientation) {
+                float rot = kL[i].angle - kC[pick].angle;
+                if (rot < 0.0f) rot += 360.0f;
+                bin = (int)roundf(rot * factor);
+                if (bin == SD_HISTO) bin = 0;
+                atomicAdd(&s_hist[bin], 1);
+            }
+            s_bin[p] = (uint8_t)bin;
+        }
+        np += __popcll(pm);
+        __syncthreads();
+    }
+    int culled = 0;
+    if (checkOrientation) {
+        if (lane == 0) {
+            // ORBmatcher::ComputeThreeMaxima (ORBmatcher.cc:1758-1799)
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int b = 0; b < SD_HISTO; b++) {
+                const int s = s_hist[b];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = b; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = b; }
+                else if (s > max3) { max3 = s; ind3 = b; }
+            }
+            if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+            s_ind[0] = ind1; s_ind[1] = ind2; s_ind[2] = ind3;
+        }
+        __syncthreads();
+        const int i1 = s_ind[0], i2 = s_ind[1], i3 = s_ind[2];
+        for (int p = lane; p < np; p += 64) {
+            const int b = s_bin[p];
+            if (b != i1 && b != i2 && b != i3) { s_match[pairs[2 * p + 1]] = -1; culled++; }
+        }
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) culled += __shfl_xor(culled, s, 64);
+        __syncthreads();
+    }
+    for (int i = lane; i < Nc; i += 64) matchOut[(size_t)pair * cap + i] = s_match[i];
+    if (lane == 0) { npairsOut[pair] = np; nmatchOut[pair] = np - culled; }
 }

@@ -25,9 +25,10 @@ struct sd_extractor {
     SdParams prm;
 };
 
-enum KernelId { K_PYR0, K_PYR, K_FAST, K_QTREE, K_ORIENT, K_BLUR, K_DESC, K_STEREO, K_STEREO_F, K_RGBD, K_COUNT };
+enum KernelId { K_PYR0, K_PYR, K_FAST, K_QTREE, K_ORIENT, K_BLUR, K_DESC, K_STEREO, K_STEREO_F, K_RGBD, K_GRID, K_UNPROJ, K_PROJ_A, K_PROJ_B, K_COUNT };
 static const char* kKernelNames[K_COUNT] = {"k_pyr_level0", "k_pyr_level", "k_fast_cells", "k_quadtree", "k_orient",
-                                            "k_blur", "k_describe", "k_stereo_match", "k_stereo_filter", "k_rgbd"};
+                                            "k_blur", "k_describe", "k_stereo_match", "k_stereo_filter", "k_rgbd",
+                                            "k_grid_cells", "k_unproject", "k_proj_candidates", "k_proj_resolve"};
 
 struct sd_batch {
     sd_extractor* ex = nullptr;
@@ -59,6 +60,17 @@ struct sd_batch {
     float* d_uright = nullptr;
     float* d_depth = nullptr;
     int* d_sad = nullptr;
+    short* d_cellOf = nullptr;      // grid cell of every keypoint
+    float* d_xw = nullptr;          // map-point world positions [maxImages][cap][3]
+    uint8_t* d_flags = nullptr;     // bit0: has map point (not outlier); bit1: Observations() > 0
+    unsigned short* d_pcand = nullptr;
+    uint8_t* d_pncand = nullptr;
+    int* d_match = nullptr;
+    int* d_pairs = nullptr;
+    int* d_npairs = nullptr;
+    int* d_nmatch = nullptr;
+    float* d_pose = nullptr;        // staging for host poses: [2][maxImages][16]
+    int nPairs = 0;
     uint8_t* d_stage = nullptr;    // staging for host-image uploads
     size_t stageBytes = 0;
     int qtMN = 0, qtSortP = 0;
@@ -164,7 +176,8 @@ static void batch_free(sd_batch* b)
     if (!b) return;
     void* ptrs[] = {b->d_plan, b->d_cells, b->d_tabs, b->d_pyr, b->d_blur, b->d_cellList, b->d_cellCount, b->d_cand,
                     b->d_nodeOf, b->d_lvlCount, b->d_candCount, b->d_lvlKp, b->d_rot, b->d_kp, b->d_desc, b->d_count,
-                    b->d_err, b->d_uright, b->d_depth, b->d_sad, b->d_stage};
+                    b->d_err, b->d_uright, b->d_depth, b->d_sad, b->d_stage, b->d_cellOf, b->d_xw, b->d_flags,
+                    b->d_pcand, b->d_pncand, b->d_match, b->d_pairs, b->d_npairs, b->d_nmatch, b->d_pose};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& r : b->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : b->pool) (void)hipEventDestroy(e);
@@ -242,6 +255,16 @@ int sd_batch_create(sd_batch** out, sd_extractor* ex, int width, int height, int
     ALLOC(b->d_uright, nI * P.kpCap * 4);
     ALLOC(b->d_depth, nI * P.kpCap * 4);
     ALLOC(b->d_sad, nI * P.kpCap * 4);
+    ALLOC(b->d_cellOf, nI * P.kpCap * 2);
+    ALLOC(b->d_xw, nI * P.kpCap * 12);
+    ALLOC(b->d_flags, nI * P.kpCap);
+    ALLOC(b->d_pcand, nI * P.kpCap * SD_PROJ_K * 2);
+    ALLOC(b->d_pncand, nI * P.kpCap);
+    ALLOC(b->d_match, nI * P.kpCap * 4);
+    ALLOC(b->d_pairs, nI * P.kpCap * 8);
+    ALLOC(b->d_npairs, nI * 4);
+    ALLOC(b->d_nmatch, nI * 4);
+    ALLOC(b->d_pose, nI * 2 * 16 * 4);
 #undef ALLOC
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMemcpy(b->d_plan, &D, sizeof(D), hipMemcpyHostToDevice);
@@ -387,7 +410,7 @@ int sd_batch_sync(sd_batch* b)
     HIPCHK(hipMemcpy(&err, b->d_err, 4, hipMemcpyDeviceToHost));
     if (err) {
         (void)hipMemset(b->d_err, 0, 4);
-        return set_err(SD_ERR_UNSUPPORTED, "quadtree node capacity exceeded (flag " + std::to_string(err) + ")");
+        return set_err(SD_ERR_UNSUPPORTED, "device capacity exceeded: 1|2 quadtree nodes, 4 projection candidates (flag " + std::to_string(err) + ")");
     }
     return SD_OK;
 }
@@ -540,7 +563,7 @@ int sd_batch_download_stereo(sd_batch* b, int frame, float* uright, float* depth
     int cnt = 0;
     HIPCHK(hipMemcpy(&cnt, b->d_count + 2 * frame, 4, hipMemcpyDeviceToHost));
     if (cnt > cap) return set_err(SD_ERR_CAPACITY, "stereo buffer too small");
-    const size_t off = (size_t)frame * b->plan.kpCap;
+    const size_t off = (size_t)(2 * frame) * b->plan.kpCap;
     if (cnt > 0) {
         if (uright) HIPCHK(hipMemcpy(uright, b->d_uright + off, (size_t)cnt * 4, hipMemcpyDeviceToHost));
         if (depth) HIPCHK(hipMemcpy(depth, b->d_depth + off, (size_t)cnt * 4, hipMemcpyDeviceToHost));
@@ -644,6 +667,169 @@ int sd_hamming_matrix_device(const uint8_t* d_a, int na, const uint8_t* d_b, int
     dim3 blk(64, 4), grd((nb + 63) / 64, (na + 3) / 4);
     hipLaunchKernelGGL(k_hamming_matrix, grd, blk, 0, (hipStream_t)stream, d_a, na, d_b, nb, d_out);
     LAUNCH_CHECK("k_hamming_matrix");
+    return SD_OK;
+}
+
+
+// ---------------------------------------------------------------- grid / unproject / projection matcher
+static int cam_ok(const sd_camera* c)
+{
+    return c && c->fx > 0 && c->fy > 0 && c->mnMaxX > c->mnMinX && c->mnMaxY > c->mnMinY;
+}
+static SdCamera to_cam(const sd_camera* c)
+{
+    SdCamera k = {c->fx, c->fy, c->cx, c->cy, c->mbf, c->mb, c->mnMinX, c->mnMaxX, c->mnMinY, c->mnMaxY};
+    return k;
+}
+
+int sd_batch_assign_grid(sd_batch* b, int n_images, const sd_camera* cam, void* stream_)
+{
+    if (!b || n_images < 0 || !cam_ok(cam)) return set_err(SD_ERR_INVALID, "bad grid arguments");
+    if (n_images > b->nExtracted) return set_err(SD_ERR_STATE, "grid needs extracted images");
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
+    b->lastStream = s;
+    if (n_images == 0) return SD_OK;
+    {
+        ProfScope ps(b, s, K_GRID);
+        dim3 grd((b->plan.kpCap + 255) / 256, n_images);
+        hipLaunchKernelGGL(k_grid_cells, grd, dim3(256), 0, s, b->d_kp, b->d_count, b->d_cellOf, to_cam(cam), b->plan.kpCap);
+    }
+    LAUNCH_CHECK("k_grid_cells");
+    return SD_OK;
+}
+
+int sd_batch_download_grid(sd_batch* b, int image, int16_t* cell, int cap)
+{
+    if (!b || !cell || image < 0 || image >= b->nExtracted) return SD_ERR_INVALID;
+    int rc = sd_batch_sync(b);
+    if (rc != SD_OK) return rc;
+    int cnt = 0;
+    HIPCHK(hipMemcpy(&cnt, b->d_count + image, 4, hipMemcpyDeviceToHost));
+    if (cnt > cap) return set_err(SD_ERR_CAPACITY, "grid buffer too small");
+    if (cnt > 0) HIPCHK(hipMemcpy(cell, b->d_cellOf + (size_t)image * b->plan.kpCap, (size_t)cnt * 2, hipMemcpyDeviceToHost));
+    return SD_OK;
+}
+
+int sd_batch_unproject(sd_batch* b, int first_image, int image_step, int n_frames, const sd_camera* cam, const float* Twc_host,
+                       void* stream_)
+{
+    if (!b || n_frames < 0 || first_image != 0 || image_step < 1 || !cam_ok(cam) || !Twc_host)
+        return set_err(SD_ERR_INVALID, "bad unproject arguments");
+    if ((n_frames - 1) * image_step >= b->nExtracted && n_frames > 0) return set_err(SD_ERR_STATE, "unproject needs extracted images");
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
+    b->lastStream = s;
+    if (n_frames == 0) return SD_OK;
+    HIPCHK(hipMemcpyAsync(b->d_pose, Twc_host, (size_t)n_frames * 64, hipMemcpyHostToDevice, s));
+    {
+        ProfScope ps(b, s, K_UNPROJ);
+        dim3 grd((b->plan.kpCap + 255) / 256, n_frames);
+        hipLaunchKernelGGL(k_unproject, grd, dim3(256), 0, s, b->d_kp, b->d_count, b->d_depth, b->d_pose, b->d_xw, b->d_flags,
+                           to_cam(cam), b->plan.kpCap, image_step);
+    }
+    LAUNCH_CHECK("k_unproject");
+    return SD_OK;
+}
+
+int sd_batch_mappoints_device(sd_batch* b, float** d_xw, uint8_t** d_flags, int* cap)
+{
+    if (!b) return SD_ERR_INVALID;
+    if (d_xw) *d_xw = b->d_xw;
+    if (d_flags) *d_flags = b->d_flags;
+    if (cap) *cap = b->plan.kpCap;
+    return SD_OK;
+}
+
+int sd_batch_set_mappoints(sd_batch* b, int image, const float* xw, const uint8_t* flags, int n)
+{
+    if (!b || image < 0 || image >= b->maxImages || n < 0 || n > b->plan.kpCap || !xw || !flags) return SD_ERR_INVALID;
+    int rc = sd_batch_sync(b);
+    if (rc != SD_OK) return rc;
+    if (n > 0) {
+        HIPCHK(hipMemcpy(b->d_xw + (size_t)image * b->plan.kpCap * 3, xw, (size_t)n * 12, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(b->d_flags + (size_t)image * b->plan.kpCap, flags, (size_t)n, hipMemcpyHostToDevice));
+    }
+    return SD_OK;
+}
+
+int sd_batch_download_mappoints(sd_batch* b, int image, float* xw, uint8_t* flags, int cap)
+{
+    if (!b || image < 0 || image >= b->nExtracted) return SD_ERR_INVALID;
+    int rc = sd_batch_sync(b);
+    if (rc != SD_OK) return rc;
+    int cnt = 0;
+    HIPCHK(hipMemcpy(&cnt, b->d_count + image, 4, hipMemcpyDeviceToHost));
+    if (cnt > cap) return set_err(SD_ERR_CAPACITY, "map point buffer too small");
+    if (cnt > 0) {
+        if (xw) HIPCHK(hipMemcpy(xw, b->d_xw + (size_t)image * b->plan.kpCap * 3, (size_t)cnt * 12, hipMemcpyDeviceToHost));
+        if (flags) HIPCHK(hipMemcpy(flags, b->d_flags + (size_t)image * b->plan.kpCap, (size_t)cnt, hipMemcpyDeviceToHost));
+    }
+    return SD_OK;
+}
+
+int sd_batch_search_by_projection(sd_batch* b, int cur_first, int last_first, int image_step, int n_pairs,
+                                  const float* Tcw_host, const float* Tlw_host, const sd_camera* cam, float th, int bMono,
+                                  int checkOrientation, const uint8_t* d_occupied, const uint8_t* d_mp_desc, void* stream_)
+{
+    if (!b || n_pairs < 0 || image_step < 1 || cur_first < 0 || last_first < 0 || !cam_ok(cam) || !Tcw_host || !Tlw_host || !(th > 0))
+        return set_err(SD_ERR_INVALID, "bad search_by_projection arguments");
+    if (n_pairs > 0) {
+        int hi = std::max(cur_first, last_first) + (n_pairs - 1) * image_step;
+        if (hi >= b->nExtracted) return set_err(SD_ERR_STATE, "search_by_projection: frame index beyond the extracted images");
+    }
+    if (b->plan.kpCap > 65535) return set_err(SD_ERR_UNSUPPORTED, "more than 65535 keypoints per image");
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
+    b->lastStream = s;
+    b->nPairs = 0;
+    if (n_pairs == 0) return SD_OK;
+    float* dTc = b->d_pose;
+    float* dTl = b->d_pose + (size_t)b->maxImages * 16;
+    HIPCHK(hipMemcpyAsync(dTc, Tcw_host, (size_t)n_pairs * 64, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dTl, Tlw_host, (size_t)n_pairs * 64, hipMemcpyHostToDevice, s));
+    const int cap = b->plan.kpCap;
+    {
+        ProfScope ps(b, s, K_PROJ_A);
+        dim3 grd((cap + 3) / 4, n_pairs);
+        hipLaunchKernelGGL(k_proj_candidates, grd, dim3(256), 0, s, b->d_kp, b->d_desc, b->d_uright, b->d_count, b->d_cellOf, b->d_xw,
+                           b->d_flags, d_mp_desc ? d_mp_desc : b->d_desc, dTc, dTl, b->d_pcand, b->d_pncand, b->d_err, b->d_plan,
+                           to_cam(cam), th, bMono, cur_first, last_first, image_step);
+    }
+    LAUNCH_CHECK("k_proj_candidates");
+    {
+        ProfScope ps(b, s, K_PROJ_B);
+        size_t lds = (size_t)cap * 4 + ((cap + 15) & ~15) + cap + 16;
+        hipLaunchKernelGGL(k_proj_resolve, dim3(n_pairs), dim3(64), lds, s, b->d_kp, b->d_count, b->d_flags, b->d_pcand, b->d_pncand,
+                           d_occupied, b->d_match, b->d_pairs, b->d_npairs, b->d_nmatch, b->d_plan, checkOrientation, cur_first,
+                           last_first, image_step);
+    }
+    LAUNCH_CHECK("k_proj_resolve");
+    b->nPairs = n_pairs;
+    return SD_OK;
+}
+
+int sd_batch_matches_device(sd_batch* b, int32_t** d_match, int32_t** d_pairs, int32_t** d_npairs, int32_t** d_nmatches, int* cap)
+{
+    if (!b) return SD_ERR_INVALID;
+    if (d_match) *d_match = b->d_match;
+    if (d_pairs) *d_pairs = b->d_pairs;
+    if (d_npairs) *d_npairs = b->d_npairs;
+    if (d_nmatches) *d_nmatches = b->d_nmatch;
+    if (cap) *cap = b->plan.kpCap;
+    return SD_OK;
+}
+
+int sd_batch_download_matches(sd_batch* b, int pair, int32_t* match, int32_t* pairs, int cap, int* npairs, int* nmatches)
+{
+    if (!b || pair < 0 || pair >= b->nPairs) return SD_ERR_INVALID;
+    int rc = sd_batch_sync(b);
+    if (rc != SD_OK) return rc;
+    if (cap < b->plan.kpCap) return set_err(SD_ERR_CAPACITY, "match buffers need kp_capacity entries");
+    int np = 0, nm = 0;
+    HIPCHK(hipMemcpy(&np, b->d_npairs + pair, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&nm, b->d_nmatch + pair, 4, hipMemcpyDeviceToHost));
+    if (match) HIPCHK(hipMemcpy(match, b->d_match + (size_t)pair * b->plan.kpCap, (size_t)b->plan.kpCap * 4, hipMemcpyDeviceToHost));
+    if (pairs && np > 0) HIPCHK(hipMemcpy(pairs, b->d_pairs + (size_t)pair * b->plan.kpCap * 2, (size_t)np * 8, hipMemcpyDeviceToHost));
+    if (npairs) *npairs = np;
+    if (nmatches) *nmatches = nm;
     return SD_OK;
 }
 

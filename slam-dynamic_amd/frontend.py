@@ -69,6 +69,15 @@ def lib():
         L.sd_batch_rgbd_from_u16.argtypes = [vp, vp, sz, sz, i, f, f, vp]
         L.sd_batch_rgbd_from_f32.argtypes = [vp, vp, sz, sz, i, f, vp]
         L.sd_batch_download_rgbd.argtypes = [vp, i, vp, vp, i]
+        L.sd_batch_assign_grid.argtypes = [vp, i, vp, vp]
+        L.sd_batch_download_grid.argtypes = [vp, i, vp, i]
+        L.sd_batch_unproject.argtypes = [vp, i, i, i, vp, vp, vp]
+        L.sd_batch_mappoints_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i)]
+        L.sd_batch_set_mappoints.argtypes = [vp, i, vp, vp, i]
+        L.sd_batch_download_mappoints.argtypes = [vp, i, vp, vp, i]
+        L.sd_batch_search_by_projection.argtypes = [vp, i, i, i, i, vp, vp, vp, f, i, i, vp, vp, vp]
+        L.sd_batch_matches_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i)]
+        L.sd_batch_download_matches.argtypes = [vp, i, vp, vp, i, C.POINTER(i), C.POINTER(i)]
         L.sd_cvt_gray_device.argtypes = [vp, i, i, sz, sz, i, i, vp, sz, sz, i, vp]
         L.sd_depth_to_f32_device.argtypes = [vp, i, i, sz, f, vp, i, sz, vp]
         L.sd_descriptor_distance.argtypes = [vp, vp]
@@ -231,6 +240,45 @@ class Batch:
         check(lib().sd_batch_download_rgbd(self.h, image, _p(ur), _p(dep), self.cap))
         return ur, dep
 
+    # -- Frame grid / UnprojectStereo / ORBmatcher::SearchByProjection(Frame, Frame)
+    def assign_grid(self, n_images, cam, stream=None):
+        c = camera_array(cam)
+        check(lib().sd_batch_assign_grid(self.h, n_images, _p(c), C.c_void_p(stream or 0)))
+
+    def download_grid(self, image):
+        out = np.zeros(self.cap, np.int16)
+        check(lib().sd_batch_download_grid(self.h, image, _p(out), self.cap))
+        return out
+
+    def unproject(self, image_step, n_frames, cam, Twc, stream=None):
+        c = camera_array(cam)
+        T = np.ascontiguousarray(Twc, np.float32).reshape(n_frames, 16)
+        check(lib().sd_batch_unproject(self.h, 0, image_step, n_frames, _p(c), _p(T), C.c_void_p(stream or 0)))
+
+    def set_mappoints(self, image, xw, flags):
+        xw = np.ascontiguousarray(xw, np.float32); flags = np.ascontiguousarray(flags, np.uint8)
+        check(lib().sd_batch_set_mappoints(self.h, image, _p(xw), _p(flags), len(flags)))
+
+    def download_mappoints(self, image):
+        xw = np.zeros((self.cap, 3), np.float32); fl = np.zeros(self.cap, np.uint8)
+        check(lib().sd_batch_download_mappoints(self.h, image, _p(xw), _p(fl), self.cap))
+        return xw, fl
+
+    def search_by_projection(self, cur_first, last_first, image_step, n_pairs, Tcw, Tlw, cam, th, bMono=False,
+                             checkOrientation=True, d_occupied=None, d_mp_desc=None, stream=None):
+        c = camera_array(cam)
+        Tc = np.ascontiguousarray(Tcw, np.float32).reshape(n_pairs, 16)
+        Tl = np.ascontiguousarray(Tlw, np.float32).reshape(n_pairs, 16)
+        check(lib().sd_batch_search_by_projection(self.h, cur_first, last_first, image_step, n_pairs, _p(Tc), _p(Tl), _p(c),
+                                                  th, int(bMono), int(checkOrientation), C.c_void_p(d_occupied or 0),
+                                                  C.c_void_p(d_mp_desc or 0), C.c_void_p(stream or 0)))
+
+    def download_matches(self, pair):
+        match = np.zeros(self.cap, np.int32); pairs = np.zeros((self.cap, 2), np.int32)
+        npairs = C.c_int(); nm = C.c_int()
+        check(lib().sd_batch_download_matches(self.h, pair, _p(match), _p(pairs), self.cap, C.byref(npairs), C.byref(nm)))
+        return match, pairs[:npairs.value].copy(), nm.value
+
     # -- profiling
     def set_profiling(self, on):
         check(lib().sd_batch_set_profiling(self.h, int(bool(on))))
@@ -247,6 +295,19 @@ class Batch:
             check(lib().sd_batch_kernel_times(self.h, i, C.byref(name), C.byref(ms), C.byref(cnt)))
             out[name.value.decode()] = (ms.value, cnt.value)
         return out
+
+
+def make_camera(cfg):
+    """Frame statics for an undistorted camera: bounds = image rectangle (Frame.cc:864-870), mb = mbf/fx."""
+    fx = np.float32(cfg["fx"]); bf = np.float32(cfg["bf"])
+    return dict(fx=fx, fy=np.float32(cfg["fy"]), cx=np.float32(cfg["cx"]), cy=np.float32(cfg["cy"]), mbf=bf,
+                mb=np.float32(bf / fx), mnMinX=np.float32(0), mnMaxX=np.float32(cfg["width"]), mnMinY=np.float32(0),
+                mnMaxY=np.float32(cfg["height"]))
+
+
+def camera_array(cam):
+    return np.array([cam[k] for k in ("fx", "fy", "cx", "cy", "mbf", "mb", "mnMinX", "mnMaxX", "mnMinY", "mnMaxY")],
+                    np.float32)
 
 
 def DescriptorDistance(a, b):

@@ -1,0 +1,97 @@
+"""GPU parity of the Frame grid, UnprojectStereo and ORBmatcher::SearchByProjection(Frame, Frame)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def seq(gpu, fe, orc, synth):
+    """4 consecutive stereo frames extracted + stereo-matched on the GPU, and the same through the oracle."""
+    cfg = synth.KITTI_STEREO
+    T = 4
+    frames = [synth.stereo_frame(seq=5, t=t) for t in range(T)]
+    ex = fe.ORBextractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+    b = fe.Batch(ex, cfg["width"], cfg["height"], 2 * T)
+    b.extract_host(np.stack([im for (l, r, _) in frames for im in (l, r)]))
+    b.stereo_match(T, cfg["bf"], cfg["fx"])
+    cam = fe.make_camera(cfg)
+    b.assign_grid(2 * T, cam)
+    ref = []
+    for (l, r, _) in frames:
+        oL = orc.Extractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+        oR = orc.Extractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+        kL, dL = oL(l); kR, dR = oR(r)
+        ur, dep, _, _ = orc.stereo_matches(oL, oR, kL, dL, kR, dR, cfg["bf"], cfg["fx"])
+        ref.append(dict(kp=kL, desc=dL, ur=ur, depth=dep, scale=oL.scale.copy()))
+    yield dict(b=b, cfg=cfg, cam=cam, ref=ref, T=T)
+    b.close()
+
+
+def test_grid_cells(seq, fe, orc):
+    cam10 = fe.camera_array(seq["cam"])
+    for t in range(seq["T"]):
+        r = seq["ref"][t]
+        got = seq["b"].download_grid(2 * t)[:len(r["kp"])]
+        assert np.array_equal(got.astype(np.int32), orc.grid_cells(r["kp"], cam10))
+
+
+def test_unproject(seq, fe, orc):
+    b, T = seq["b"], seq["T"]
+    cam10 = fe.camera_array(seq["cam"])
+    rng = np.random.default_rng(5)
+    Twc = np.tile(np.eye(4, dtype=np.float32), (T, 1, 1))
+    for t in range(T):     # a small rotation + translation so every term of the product matters
+        a = 0.02 * (t + 1)
+        Twc[t, :3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+        Twc[t, :3, 3] = rng.normal(size=3).astype(np.float32)
+    b.unproject(2, T, seq["cam"], Twc)
+    for t in range(T):
+        r = seq["ref"][t]
+        xw, fl = b.download_mappoints(2 * t)
+        oxw, ovalid = orc.unproject(r["kp"], r["depth"], cam10, Twc[t])
+        n = len(r["kp"])
+        assert ovalid.sum() > 100
+        assert np.array_equal(fl[:n], ovalid)
+        assert np.array_equal(xw[:n].view(np.uint32), oxw.view(np.uint32))
+
+
+@pytest.mark.parametrize("th,obs_frac,occ_frac", [(7.0, 0.0, 0.0), (15.0, 0.0, 0.0), (15.0, 0.6, 0.05), (40.0, 1.0, 0.1)])
+def test_search_by_projection(seq, fe, orc, th, obs_frac, occ_frac):
+    """Frame t matched against frame t-1.  obs_frac > 0 marks Last-frame points as map points with
+    observations (they lock the keypoint they take, ORBmatcher.cc:462-465); occ_frac marks Current
+    keypoints as already holding such a point.  th = 40 forces many contested keypoints."""
+    import torch
+    b, T, cam = seq["b"], seq["T"], seq["cam"]
+    cam10 = fe.camera_array(cam)
+    rng = np.random.default_rng(int(th * 10 + obs_frac * 100))
+    I = np.eye(4, dtype=np.float32)
+    b.unproject(2, T, cam, np.tile(I, (T, 1, 1)))
+    flags_all = []
+    for t in range(T):
+        xw, fl = b.download_mappoints(2 * t)
+        n = len(seq["ref"][t]["kp"])
+        fl = fl[:n].copy()
+        fl |= ((rng.random(n) < obs_frac) & (fl > 0)).astype(np.uint8) << 1
+        b.set_mappoints(2 * t, xw[:n], fl)
+        flags_all.append((xw[:n].copy(), fl))
+    npairs = T - 1
+    occ = (rng.random((npairs, b.cap)) < occ_frac).astype(np.uint8)
+    d_occ = torch.from_numpy(occ).cuda()
+    # a small forward motion as the predicted pose: exercises bForward and the full product
+    Tcw = np.tile(I, (npairs, 1, 1)); Tcw[:, 2, 3] = -0.8
+    Tlw = np.tile(I, (npairs, 1, 1))
+    b.search_by_projection(2, 0, 2, npairs, Tcw, Tlw, cam, th, False, True, d_occupied=d_occ.data_ptr())
+    total = 0
+    for p in range(npairs):
+        cur, last = seq["ref"][p + 1], seq["ref"][p]
+        xw, fl = flags_all[p]
+        om, opairs, onm = orc.search_by_projection(cur["kp"], cur["desc"], cur["ur"], last["kp"], last["desc"], xw, fl,
+                                                   Tcw[p], Tlw[p], cam10, cur["scale"], th, False, True,
+                                                   occupied=occ[p, :len(cur["kp"])])
+        m, pairs, nm = b.download_matches(p)
+        assert nm == onm, "nmatches pair %d: %d vs %d" % (p, nm, onm)
+        assert np.array_equal(pairs, opairs), "point pairs, pair %d" % p
+        assert np.array_equal(m[:len(cur["kp"])], om), "mvpMapPoints assignment, pair %d" % p
+        total += onm
+    assert total > 50 * npairs, "expected plenty of matches, got %d" % total
