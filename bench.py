@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""bench.py — tracking front-end frames/s (extract + match [+ dynamic cull]) on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic frames that are already
+resident in HBM.  At N=1 the workload is BASELINE.json configs[1]:
+    KITTI-03 RGB-D 1241x376, 2000 features/frame, ORB extract + match, no semantic mask
+i.e. per frame (reference call stack SURVEY 3.2, 3-argument TrackRGBD):
+    cvtColor RGB->gray                      Tracking.cc:256-269
+    ORBextractor::operator()                ORBextractor.cc:1043-1105
+    depth scaling + ComputeStereoFromRGBD   Tracking.cc:271-272, Frame.cc:1051-1072
+    AssignFeaturesToGrid                    Frame.cc:463-478
+    UnprojectStereo of the frame's points   Frame.cc:1074-1088
+    SearchByProjection(cur, last, th=15)    ORBmatcher.cc:1485-1627 (th: Tracking.cc:990-994)
+    mLastFrame = Frame(mCurrentFrame)       (slot copy)
+`--workload stereo` runs BASELINE configs[2] without the detector: 2x extract + ComputeStereoMatches
++ the same grid/unproject/projection match (th=7).
+
+Multi-GPU (driver launches one rank per GPU through torch.distributed.run): independent frames are
+sharded, every rank runs the same per-GPU batch (weak scaling), there is no data-path collective.
+Start-up: RCCL broadcast of the packed ORB vocabulary (synthetic k=10, L=6 tree, ~45 MB) from rank 0.
+Per step: all_gather of the fixed-stride per-frame result records.  value = frames of ALL ranks / max
+rank time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming)
+
+
+# --------------------------------------------------------------------------- host logic (also used by CPU tests)
+def shard_sequences(n_sequences, lengths, world):
+    """Longest-first greedy assignment of whole sequences to ranks."""
+    order = sorted(range(n_sequences), key=lambda s: (-lengths[s], s))
+    load = [0] * world
+    owner = [None] * n_sequences
+    for s in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        owner[s] = r
+        load[r] += lengths[s]
+    return owner
+
+
+def level_sizes(width, height, inv_scale):
+    return [(int(np.rint(np.float32(width) * s)), int(np.rint(np.float32(height) * s))) for s in inv_scale]
+
+
+def algorithmic_bytes(width, height, inv_scale, n_features):
+    """Compulsory HBM bytes per image and per kernel: each plane read/written once."""
+    sizes = level_sizes(width, height, inv_scale)
+    interior = [w * h for (w, h) in sizes]
+    padded = [(w + 38) * (h + 38) for (w, h) in sizes]
+    b = {
+        "k_pyr_level0": width * height + padded[0],
+        "k_pyr_level": sum(interior[:-1]) + sum(padded[1:]),
+        "k_fast_cells": sum(interior),
+        "k_blur": 2 * sum(interior),
+        "k_orient": n_features * 749,
+        "k_describe": n_features * 512 + n_features * 32,
+        "k_quadtree": 0,
+    }
+    b["image_total"] = (width * height + sum(padded) + sum(interior[:-1]) + 3 * sum(interior) + n_features * 749 +
+                        n_features * 512 + n_features * 60)
+    return b
+
+
+def max_over_ranks(dist, seconds, device):
+    import torch
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_records(dist, local, world):
+    """all_gather of one rank's fixed-stride result block (uint8 tensor) -> [world, nbytes]."""
+    import torch
+    if dist is None or world == 1:
+        return local.unsqueeze(0)
+    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local)
+    return out
+
+
+# --------------------------------------------------------------------------- CPU baseline (oracle; rank 0, N=1 only)
+def cpu_baseline(workload, cfg, n_frames, seq):
+    orc = graft.load_oracle()
+    pkg = graft.load_package()
+    synth, fe = pkg.synth, pkg.frontend
+    cam10 = fe.camera_array(fe.make_camera(cfg))
+    I = np.eye(4, dtype=np.float32)
+    frames = []
+    for t in range(n_frames):
+        frames.append(synth.rgbd_frame(seq, t, cfg) if workload == "rgbd" else synth.stereo_frame(seq, t, cfg))
+    th = 15.0 if workload == "rgbd" else 7.0
+    exL = orc.Extractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+    exR = orc.Extractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+    last = None
+    t0 = time.perf_counter()
+    for fr in frames:
+        if workload == "rgbd":
+            rgb, depth, _ = fr
+            gray = orc.cvt_gray(rgb, 1)
+            kp, desc = exL(gray)
+            dep32 = orc.depth_to_f32(depth, float(np.float32(1.0) / np.float32(cfg["depth_map_factor"])))
+            ur, dep = orc.stereo_from_rgbd(kp, dep32, cfg["bf"])
+        else:
+            l, r, _ = fr
+            kp, desc = exL(l)
+            kpR, descR = exR(r)
+            ur, dep, _, _ = orc.stereo_matches(exL, exR, kp, desc, kpR, descR, cfg["bf"], cfg["fx"])
+        xw, valid = orc.unproject(kp, dep, cam10, I)
+        if last is not None:
+            orc.search_by_projection(kp, desc, ur, last[0], last[1], last[2], last[3], I, I, cam10, exL.scale, th)
+        else:
+            orc.grid_cells(kp, cam10)
+        last = (kp, desc, xw, valid)
+    dt = time.perf_counter() - t0
+    return n_frames / dt, dt
+
+
+# --------------------------------------------------------------------------- main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
+    ap.add_argument("--workload", choices=["rgbd", "stereo"], default="rgbd")
+    ap.add_argument("--cpu-frames", type=int, default=96, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist = dist_mod
+
+    pkg = graft.load_package()
+    fe, synth = pkg.frontend, pkg.synth
+    if fe.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+
+    B = args.batch
+    if args.workload == "rgbd":
+        cfg = synth.KITTI03_RGBD
+        workload_name = "KITTI-03 RGB-D 1241x376, 2000 feat/frame, ORB extract+match, no semantic mask (BASELINE configs[1])"
+        imgs_per_frame, th = 1, 15.0
+    else:
+        cfg = synth.KITTI_STEREO
+        workload_name = "KITTI stereo 1241x376, 2000 feat/frame, 2x ORB extract + stereo match + projection match, detector off (BASELINE configs[2] minus YOLOv3)"
+        imgs_per_frame, th = 2, 7.0
+    W, H = cfg["width"], cfg["height"]
+
+    # ---- synthetic inputs, resident in HBM before the timed region
+    seq = 10 + rank
+    if args.workload == "rgbd":
+        fr = [synth.rgbd_frame(seq, t, cfg) for t in range(B)]
+        d_rgb = torch.from_numpy(np.stack([f[0] for f in fr])).to(dev)
+        d_depth = torch.from_numpy(np.stack([f[1] for f in fr]).view(np.int16)).to(dev)
+        d_gray = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    else:
+        fr = [synth.stereo_frame(seq, t, cfg) for t in range(B)]
+        d_gray = torch.from_numpy(np.stack([im for f in fr for im in (f[0], f[1])])).to(dev)
+    del fr
+
+    # ---- start-up collective: packed ORB vocabulary (k=10, L=6 -> 1,111,111 nodes x 41 B), rank 0 -> all (RCCL)
+    voc_bytes = 1111111 * (32 + 4 + 4 + 1)
+    voc_ms = None
+    if rank == 0:
+        g = torch.Generator(device=dev); g.manual_seed(1234)
+        voc = torch.randint(0, 256, (voc_bytes,), dtype=torch.uint8, device=dev, generator=g)
+    else:
+        voc = torch.empty((voc_bytes,), dtype=torch.uint8, device=dev)
+    if dist is not None:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dist.broadcast(voc, src=0)
+        torch.cuda.synchronize()
+        voc_ms = (time.perf_counter() - t0) * 1e3
+
+    ex = fe.ORBextractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+    n_img = B * imgs_per_frame
+    batch = fe.Batch(ex, W, H, n_img + 1)          # + 1 slot: mLastFrame carried across steps
+    cam = fe.make_camera(cfg)
+    stream = torch.cuda.current_stream().cuda_stream
+    I = np.tile(np.eye(4, dtype=np.float32), (B, 1, 1))
+    cur_idx = np.arange(B, dtype=np.int32) * imgs_per_frame
+    last_idx = np.concatenate([[n_img], cur_idx[:-1]]).astype(np.int32)
+    depth_factor = float(np.float32(1.0) / np.float32(cfg.get("depth_map_factor", 1.0)))
+    rec = None
+    if dist is not None:
+        kp_p, desc_p, cnt_p, cap = batch.results_device()
+        rec = dict(kp=fe.as_torch_u8(kp_p, n_img * cap * 28), desc=fe.as_torch_u8(desc_p, n_img * cap * 32))
+
+    def step(first=False):
+        if args.workload == "rgbd":
+            fe.cvt_gray_device(d_rgb.data_ptr(), W, H, W * 3, W * H * 3, 3, 1, d_gray.data_ptr(), W, W * H, B, stream)
+        batch.extract_device(d_gray.data_ptr(), W, W * H, n_img, stream)
+        if args.workload == "rgbd":
+            batch.rgbd_from_u16(d_depth.data_ptr(), W, W * H, B, depth_factor, cfg["bf"], stream)
+        else:
+            batch.stereo_match(B, cfg["bf"], cfg["fx"], stream)
+        batch.assign_grid(n_img, cam, stream)
+        batch.unproject(imgs_per_frame, B, cam, I, stream)
+        if first:
+            batch.search_by_projection(cur_idx[1:], last_idx[1:], I[1:], I[1:], cam, th, False, True, stream=stream)
+        else:
+            batch.search_by_projection(cur_idx, last_idx, I, I, cam, th, False, True, stream=stream)
+        batch.copy_frame(int(cur_idx[-1]), n_img, stream)
+        if dist is not None:
+            gather_records(dist, rec["kp"], world)
+            gather_records(dist, rec["desc"], world)
+
+    step(first=True)                      # priming: fills the carried mLastFrame slot (setup, untimed)
+    for _ in range(args.warmup):
+        step()
+    batch.sync()
+    torch.cuda.synchronize()
+    if not args.no_profile:
+        batch.set_profiling(True)
+        batch.reset_kernel_times()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(dist, elapsed, dev)
+    batch.sync()
+
+    kt = batch.kernel_times() if not args.no_profile else {}
+    counts = batch.counts(n_img)
+    m, pairs, nm = batch.download_matches(B - 1)
+
+    if rank == 0:
+        total_frames = world * B * args.steps
+        value = total_frames / elapsed
+        alg = algorithmic_bytes(W, H, ex.mvInvScaleFactor, cfg["n_features"])
+        roof = None
+        if kt:
+            dom = max((k for k in kt if kt[k][1] > 0), key=lambda k: kt[k][0])
+            ms, launches = kt[dom]
+            avg_ms = ms / launches
+            per_launch = {"k_pyr_level": alg["k_pyr_level"] / 7.0}.get(dom, alg.get(dom, 0)) * n_img
+            achieved = per_launch / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    j = json.load(open(pmc))
+                    e = j.get(dom)
+                    if e and e.get("batch_images") == n_img:
+                        traffic = e.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": int(per_launch), "avg_launch_ms": round(avg_ms, 4),
+                    "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in kt.items() if v[1] > 0},
+                    "pipeline_achieved_GBs": round(alg["image_total"] * imgs_per_frame * value / 1e9, 2)}
+        cpu = None
+        if world == 1 and args.cpu_frames > 0:
+            v, dt = cpu_baseline(args.workload, cfg, args.cpu_frames, seq)
+            cpu = {"value": round(v, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                   "sample": "%d consecutive frames of the same synthetic workload through the CPU oracle (oracle/), "
+                             "1 thread, %.1f s; host has %d logical cores" % (args.cpu_frames, dt, os.cpu_count() or 0)}
+        out = {
+            "metric": "tracking frames/sec (extract+match+dynamic-cull), KITTI 1241x376",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": workload_name, "frames_per_step_per_gpu": B, "images_per_frame": imgs_per_frame,
+                       "features_per_image": int(np.mean(counts)), "projection_matches_last_pair": int(nm),
+                       "sharding": "independent frame batches per rank, no data-path collective; per-step all_gather of results"
+                       if world > 1 else "single GPU"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if voc_ms is not None:
+            out["vocabulary_broadcast_ms"] = round(voc_ms, 3)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    batch.close()
+
+
+if __name__ == "__main__":
+    main()

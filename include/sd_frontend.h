@@ -142,18 +142,21 @@ int sd_batch_download_mappoints(sd_batch* b, int image, float* xw, uint8_t* flag
 
 /* ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, th, bMono[, points_last, points_current])
  * (src/ORBmatcher.cc:1485-1627 and the pair-emitting overload :407-559, called from Tracking::TrackHomo,
- * Tracking.cc:998-1010, and TrackWithMotionModel).  Pair p matches Current = image cur_first + p*image_step
- * against Last = image last_first + p*image_step of the same batch (sd_batch_assign_grid must have run on
- * the Current images).  Tcw_host / Tlw_host: n_pairs row-major 4x4 poses (CurrentFrame.mTcw, LastFrame.mTcw).
+ * Tracking.cc:998-1010, and TrackWithMotionModel).  Pair p matches Current = slot cur_index[p] against
+ * Last = slot last_index[p] of the same batch (host index arrays; sd_batch_assign_grid must have run on the
+ * Current slots).  Tcw_host / Tlw_host: n_pairs row-major 4x4 poses (CurrentFrame.mTcw, LastFrame.mTcw).
  * d_occupied (nullable, [n_pairs][cap] u8): CurrentFrame.mvpMapPoints[i2] already holds a point with
  * Observations() > 0.  d_mp_desc (nullable, [max_images][cap][32]): pMP->GetDescriptor() of the Last frame's
  * points; NULL = the Last frame's own descriptors.
  * Results: match[i2] = index of the Last-frame point assigned to Current keypoint i2 or -1 (the new
  * CurrentFrame.mvpMapPoints); pairs = (i, i2) in order of i == points_last / points_current BEFORE the
  * rotation-histogram cull (ORBmatcher.cc:505-506); nmatches = the function's return value. */
-int sd_batch_search_by_projection(sd_batch* b, int cur_first, int last_first, int image_step, int n_pairs,
+int sd_batch_search_by_projection(sd_batch* b, int n_pairs, const int32_t* cur_index, const int32_t* last_index,
                                   const float* Tcw_host, const float* Tlw_host, const sd_camera* cam, float th, int bMono,
                                   int checkOrientation, const uint8_t* d_occupied, const uint8_t* d_mp_desc, void* stream);
+/* Frame copy constructor (src/Frame.cc:39-63), as in `mLastFrame = Frame(mCurrentFrame)`: copies the frame
+ * results of slot src (keypoints, descriptors, mvuRight/mvDepth, grid cells, map-point table) to slot dst. */
+int sd_batch_copy_frame(sd_batch* b, int src, int dst, void* stream);
 int sd_batch_matches_device(sd_batch* b, int32_t** d_match, int32_t** d_pairs, int32_t** d_npairs, int32_t** d_nmatches,
                             int* cap);
 int sd_batch_download_matches(sd_batch* b, int pair, int32_t* match, int32_t* pairs, int cap, int* npairs, int* nmatches);

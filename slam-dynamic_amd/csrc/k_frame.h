@@ -305,15 +305,15 @@ __global__ void __launch_bounds__(256) k_proj_candidates(
     const int* __restrict__ count, const short* __restrict__ cellOf, const float* __restrict__ xw,
     const uint8_t* __restrict__ flags, const uint8_t* __restrict__ dmp, const float* __restrict__ Tcw,
     const float* __restrict__ Tlw, unsigned short* __restrict__ cand, uint8_t* __restrict__ ncand,
-    int* __restrict__ errFlag, const SdDevPlan* __restrict__ PP, SdCamera cam, float th, int bMono, int curFirst,
-    int lastFirst, int step)
+    int* __restrict__ errFlag, const SdDevPlan* __restrict__ PP, SdCamera cam, float th, int bMono,
+    const int2* __restrict__ pairIdx)
 {
     const SdDevPlan& P = *PP;
     __shared__ unsigned long long s_keys[4][SD_PROJ_K];
     const int pair = blockIdx.y;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + wv;
-    const int imgC = curFirst + pair * step, imgL = lastFirst + pair * step;
+    const int imgC = pairIdx[pair].x, imgL = pairIdx[pair].y;
     const int cap = P.kpCap;
     const int Nl = count[imgL], Nc = count[imgC];
     if (i >= Nl) return;
@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(64) k_proj_resolve(
     const sd_keypoint* __restrict__ kp, const int* __restrict__ count, const uint8_t* __restrict__ flags,
     const unsigned short* __restrict__ cand, const uint8_t* __restrict__ ncand, const uint8_t* __restrict__ occupied,
     int* __restrict__ matchOut, int* __restrict__ pairsOut, int* __restrict__ npairsOut, int* __restrict__ nmatchOut,
-    const SdDevPlan* __restrict__ PP, int checkOrientation, int curFirst, int lastFirst, int step)
+    const SdDevPlan* __restrict__ PP, int checkOrientation, const int2* __restrict__ pairIdx)
 {
     const SdDevPlan& P = *PP;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(64) k_proj_resolve(
     __shared__ int s_hist[SD_HISTO];
     __shared__ int s_ind[3];
     const int pair = blockIdx.x, lane = threadIdx.x;
-    const int imgC = curFirst + pair * step, imgL = lastFirst + pair * step;
+    const int imgC = pairIdx[pair].x, imgL = pairIdx[pair].y;
     const int Nl = count[imgL], Nc = count[imgC];
     const sd_keypoint* kC = kp + (size_t)imgC * cap;
     const sd_keypoint* kL = kp + (size_t)imgL * cap;

@@ -35,7 +35,9 @@ struct sd_batch {
     SdPlan plan;
     SdDevPlan hplan;
     int maxImages = 0;
-    int nExtracted = 0;       // images valid from the last extract
+    int nExtracted = 0;       // images processed by the last extract
+    std::vector<uint8_t> slotValid;   // slot holds frame results (extracted or carried over)
+    int2* d_pairIdx = nullptr;
     int nStereo = 0;
     hipStream_t stream = nullptr;
     hipStream_t lastStream = nullptr;
@@ -177,7 +179,7 @@ static void batch_free(sd_batch* b)
     void* ptrs[] = {b->d_plan, b->d_cells, b->d_tabs, b->d_pyr, b->d_blur, b->d_cellList, b->d_cellCount, b->d_cand,
                     b->d_nodeOf, b->d_lvlCount, b->d_candCount, b->d_lvlKp, b->d_rot, b->d_kp, b->d_desc, b->d_count,
                     b->d_err, b->d_uright, b->d_depth, b->d_sad, b->d_stage, b->d_cellOf, b->d_xw, b->d_flags,
-                    b->d_pcand, b->d_pncand, b->d_match, b->d_pairs, b->d_npairs, b->d_nmatch, b->d_pose};
+                    b->d_pcand, b->d_pncand, b->d_match, b->d_pairs, b->d_npairs, b->d_nmatch, b->d_pose, b->d_pairIdx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& r : b->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : b->pool) (void)hipEventDestroy(e);
@@ -265,6 +267,8 @@ int sd_batch_create(sd_batch** out, sd_extractor* ex, int width, int height, int
     ALLOC(b->d_npairs, nI * 4);
     ALLOC(b->d_nmatch, nI * 4);
     ALLOC(b->d_pose, nI * 2 * 16 * 4);
+    ALLOC(b->d_pairIdx, nI * sizeof(int2));
+    b->slotValid.assign(nI, 0);
 #undef ALLOC
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMemcpy(b->d_plan, &D, sizeof(D), hipMemcpyHostToDevice);
@@ -329,6 +333,8 @@ static void drain_profile(sd_batch* b)
     }
     b->pending.clear();
 }
+
+static bool slot_ok(const sd_batch* b, int image) { return image >= 0 && image < b->maxImages && b->slotValid[image]; }
 
 static int check_launch(const char* name)
 {
@@ -398,6 +404,7 @@ int sd_batch_extract_device(sd_batch* b, const uint8_t* d_gray, size_t stride, s
     }
     LAUNCH_CHECK("k_describe");
     b->nExtracted = n_images;
+    for (int i = 0; i < n_images; i++) b->slotValid[i] = 1;
     return SD_OK;
 }
 
@@ -464,7 +471,7 @@ int sd_batch_download(sd_batch* b, int image, sd_keypoint* kp, uint8_t* desc, in
     if (rc != SD_OK) return rc;
     *n = 0;
     if (per_level) for (int l = 0; l < b->plan.nlevels; l++) per_level[l] = 0;
-    if (image >= b->nExtracted) return SD_OK;
+    if (!slot_ok(b, image)) return SD_OK;
     int cnt = 0;
     HIPCHK(hipMemcpy(&cnt, b->d_count + image, 4, hipMemcpyDeviceToHost));
     if (cnt > cap) { *n = cnt; return set_err(SD_ERR_CAPACITY, "keypoint buffer too small"); }
@@ -610,7 +617,7 @@ int sd_batch_rgbd_from_f32(sd_batch* b, const float* d_depth, size_t stride_elem
 
 int sd_batch_download_rgbd(sd_batch* b, int image, float* uright, float* depth, int cap)
 {
-    if (!b || image < 0 || image >= b->nExtracted) return SD_ERR_INVALID;
+    if (!b || !slot_ok(b, image)) return SD_ERR_INVALID;
     int rc = sd_batch_sync(b);
     if (rc != SD_OK) return rc;
     int cnt = 0;
@@ -700,7 +707,7 @@ int sd_batch_assign_grid(sd_batch* b, int n_images, const sd_camera* cam, void* 
 
 int sd_batch_download_grid(sd_batch* b, int image, int16_t* cell, int cap)
 {
-    if (!b || !cell || image < 0 || image >= b->nExtracted) return SD_ERR_INVALID;
+    if (!b || !cell || !slot_ok(b, image)) return SD_ERR_INVALID;
     int rc = sd_batch_sync(b);
     if (rc != SD_OK) return rc;
     int cnt = 0;
@@ -715,7 +722,7 @@ int sd_batch_unproject(sd_batch* b, int first_image, int image_step, int n_frame
 {
     if (!b || n_frames < 0 || first_image != 0 || image_step < 1 || !cam_ok(cam) || !Twc_host)
         return set_err(SD_ERR_INVALID, "bad unproject arguments");
-    if ((n_frames - 1) * image_step >= b->nExtracted && n_frames > 0) return set_err(SD_ERR_STATE, "unproject needs extracted images");
+    if (n_frames > 0 && !slot_ok(b, (n_frames - 1) * image_step)) return set_err(SD_ERR_STATE, "unproject needs extracted images");
     hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
     b->lastStream = s;
     if (n_frames == 0) return SD_OK;
@@ -753,7 +760,7 @@ int sd_batch_set_mappoints(sd_batch* b, int image, const float* xw, const uint8_
 
 int sd_batch_download_mappoints(sd_batch* b, int image, float* xw, uint8_t* flags, int cap)
 {
-    if (!b || image < 0 || image >= b->nExtracted) return SD_ERR_INVALID;
+    if (!b || !slot_ok(b, image)) return SD_ERR_INVALID;
     int rc = sd_batch_sync(b);
     if (rc != SD_OK) return rc;
     int cnt = 0;
@@ -766,15 +773,18 @@ int sd_batch_download_mappoints(sd_batch* b, int image, float* xw, uint8_t* flag
     return SD_OK;
 }
 
-int sd_batch_search_by_projection(sd_batch* b, int cur_first, int last_first, int image_step, int n_pairs,
+int sd_batch_search_by_projection(sd_batch* b, int n_pairs, const int32_t* cur_index, const int32_t* last_index,
                                   const float* Tcw_host, const float* Tlw_host, const sd_camera* cam, float th, int bMono,
                                   int checkOrientation, const uint8_t* d_occupied, const uint8_t* d_mp_desc, void* stream_)
 {
-    if (!b || n_pairs < 0 || image_step < 1 || cur_first < 0 || last_first < 0 || !cam_ok(cam) || !Tcw_host || !Tlw_host || !(th > 0))
+    if (!b || n_pairs < 0 || n_pairs > b->maxImages || !cam_ok(cam) || !Tcw_host || !Tlw_host || !(th > 0) ||
+        (n_pairs > 0 && (!cur_index || !last_index)))
         return set_err(SD_ERR_INVALID, "bad search_by_projection arguments");
-    if (n_pairs > 0) {
-        int hi = std::max(cur_first, last_first) + (n_pairs - 1) * image_step;
-        if (hi >= b->nExtracted) return set_err(SD_ERR_STATE, "search_by_projection: frame index beyond the extracted images");
+    std::vector<int2> idx(n_pairs);
+    for (int p = 0; p < n_pairs; p++) {
+        if (!slot_ok(b, cur_index[p]) || !slot_ok(b, last_index[p]))
+            return set_err(SD_ERR_STATE, "search_by_projection: frame slot holds no results");
+        idx[p] = make_int2(cur_index[p], last_index[p]);
     }
     if (b->plan.kpCap > 65535) return set_err(SD_ERR_UNSUPPORTED, "more than 65535 keypoints per image");
     hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
@@ -785,24 +795,43 @@ int sd_batch_search_by_projection(sd_batch* b, int cur_first, int last_first, in
     float* dTl = b->d_pose + (size_t)b->maxImages * 16;
     HIPCHK(hipMemcpyAsync(dTc, Tcw_host, (size_t)n_pairs * 64, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(dTl, Tlw_host, (size_t)n_pairs * 64, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->d_pairIdx, idx.data(), (size_t)n_pairs * sizeof(int2), hipMemcpyHostToDevice, s));
     const int cap = b->plan.kpCap;
     {
         ProfScope ps(b, s, K_PROJ_A);
         dim3 grd((cap + 3) / 4, n_pairs);
         hipLaunchKernelGGL(k_proj_candidates, grd, dim3(256), 0, s, b->d_kp, b->d_desc, b->d_uright, b->d_count, b->d_cellOf, b->d_xw,
                            b->d_flags, d_mp_desc ? d_mp_desc : b->d_desc, dTc, dTl, b->d_pcand, b->d_pncand, b->d_err, b->d_plan,
-                           to_cam(cam), th, bMono, cur_first, last_first, image_step);
+                           to_cam(cam), th, bMono, b->d_pairIdx);
     }
     LAUNCH_CHECK("k_proj_candidates");
     {
         ProfScope ps(b, s, K_PROJ_B);
         size_t lds = (size_t)cap * 4 + ((cap + 15) & ~15) + cap + 16;
         hipLaunchKernelGGL(k_proj_resolve, dim3(n_pairs), dim3(64), lds, s, b->d_kp, b->d_count, b->d_flags, b->d_pcand, b->d_pncand,
-                           d_occupied, b->d_match, b->d_pairs, b->d_npairs, b->d_nmatch, b->d_plan, checkOrientation, cur_first,
-                           last_first, image_step);
+                           d_occupied, b->d_match, b->d_pairs, b->d_npairs, b->d_nmatch, b->d_plan, checkOrientation, b->d_pairIdx);
     }
     LAUNCH_CHECK("k_proj_resolve");
     b->nPairs = n_pairs;
+    return SD_OK;
+}
+
+// Frame copy (mLastFrame = Frame(mCurrentFrame), Tracking.cc; Frame.cc:39-63): keypoints, descriptors,
+// stereo coordinates, grid cells and the map-point table of slot `src` into slot `dst`.
+int sd_batch_copy_frame(sd_batch* b, int src, int dst, void* stream_)
+{
+    if (!b || !slot_ok(b, src) || dst < 0 || dst >= b->maxImages || src == dst) return set_err(SD_ERR_INVALID, "bad copy_frame slots");
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
+    b->lastStream = s;
+    const size_t cap = b->plan.kpCap;
+#define CP(ptr, elemBytes) HIPCHK(hipMemcpyAsync((char*)(ptr) + dst * cap * (elemBytes), (const char*)(ptr) + src * cap * (elemBytes), cap * (elemBytes), hipMemcpyDeviceToDevice, s))
+    CP(b->d_kp, sizeof(sd_keypoint)); CP(b->d_desc, 32); CP(b->d_uright, 4); CP(b->d_depth, 4); CP(b->d_sad, 4);
+    CP(b->d_cellOf, 2); CP(b->d_xw, 12); CP(b->d_flags, 1);
+#undef CP
+    HIPCHK(hipMemcpyAsync(b->d_count + dst, b->d_count + src, 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->d_lvlCount + (size_t)dst * b->plan.nlevels, b->d_lvlCount + (size_t)src * b->plan.nlevels,
+                          (size_t)b->plan.nlevels * 4, hipMemcpyDeviceToDevice, s));
+    b->slotValid[dst] = 1;
     return SD_OK;
 }
 

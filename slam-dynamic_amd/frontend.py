@@ -75,7 +75,8 @@ def lib():
         L.sd_batch_mappoints_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i)]
         L.sd_batch_set_mappoints.argtypes = [vp, i, vp, vp, i]
         L.sd_batch_download_mappoints.argtypes = [vp, i, vp, vp, i]
-        L.sd_batch_search_by_projection.argtypes = [vp, i, i, i, i, vp, vp, vp, f, i, i, vp, vp, vp]
+        L.sd_batch_search_by_projection.argtypes = [vp, i, vp, vp, vp, vp, vp, f, i, i, vp, vp, vp]
+        L.sd_batch_copy_frame.argtypes = [vp, i, i, vp]
         L.sd_batch_matches_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i)]
         L.sd_batch_download_matches.argtypes = [vp, i, vp, vp, i, C.POINTER(i), C.POINTER(i)]
         L.sd_cvt_gray_device.argtypes = [vp, i, i, sz, sz, i, i, vp, sz, sz, i, vp]
@@ -264,14 +265,19 @@ class Batch:
         check(lib().sd_batch_download_mappoints(self.h, image, _p(xw), _p(fl), self.cap))
         return xw, fl
 
-    def search_by_projection(self, cur_first, last_first, image_step, n_pairs, Tcw, Tlw, cam, th, bMono=False,
+    def search_by_projection(self, cur_index, last_index, Tcw, Tlw, cam, th, bMono=False,
                              checkOrientation=True, d_occupied=None, d_mp_desc=None, stream=None):
         c = camera_array(cam)
+        ci = np.ascontiguousarray(cur_index, np.int32); li = np.ascontiguousarray(last_index, np.int32)
+        n_pairs = len(ci)
         Tc = np.ascontiguousarray(Tcw, np.float32).reshape(n_pairs, 16)
         Tl = np.ascontiguousarray(Tlw, np.float32).reshape(n_pairs, 16)
-        check(lib().sd_batch_search_by_projection(self.h, cur_first, last_first, image_step, n_pairs, _p(Tc), _p(Tl), _p(c),
+        check(lib().sd_batch_search_by_projection(self.h, n_pairs, _p(ci), _p(li), _p(Tc), _p(Tl), _p(c),
                                                   th, int(bMono), int(checkOrientation), C.c_void_p(d_occupied or 0),
                                                   C.c_void_p(d_mp_desc or 0), C.c_void_p(stream or 0)))
+
+    def copy_frame(self, src, dst, stream=None):
+        check(lib().sd_batch_copy_frame(self.h, src, dst, C.c_void_p(stream or 0)))
 
     def download_matches(self, pair):
         match = np.zeros(self.cap, np.int32); pairs = np.zeros((self.cap, 2), np.int32)
@@ -308,6 +314,36 @@ def make_camera(cfg):
 def camera_array(cam):
     return np.array([cam[k] for k in ("fx", "fy", "cx", "cy", "mbf", "mb", "mnMinX", "mnMaxX", "mnMinY", "mnMaxY")],
                     np.float32)
+
+
+def cvt_gray_device(d_src, width, height, src_stride, src_pitch, channels, rgb_order, d_dst, dst_stride, dst_pitch,
+                    n_images, stream=None):
+    """cvtColor(RGB|BGR[A] -> GRAY) of Tracking::GrabImage* (src/Tracking.cc:175-200,256-269) on device buffers."""
+    check(lib().sd_cvt_gray_device(C.c_void_p(d_src), width, height, src_stride, src_pitch, channels, int(rgb_order),
+                                   C.c_void_p(d_dst), dst_stride, dst_pitch, n_images, C.c_void_p(stream or 0)))
+
+
+def depth_to_f32_device(d_src, width, height, src_stride_elems, factor, d_dst, n_images, src_pitch_elems, stream=None):
+    check(lib().sd_depth_to_f32_device(C.c_void_p(d_src), width, height, src_stride_elems, factor, C.c_void_p(d_dst),
+                                       n_images, src_pitch_elems, C.c_void_p(stream or 0)))
+
+
+def hamming_matrix_device(d_a, na, d_b, nb, d_out, stream=None):
+    check(lib().sd_hamming_matrix_device(C.c_void_p(d_a), na, C.c_void_p(d_b), nb, C.c_void_p(d_out),
+                                         C.c_void_p(stream or 0)))
+
+
+class _DevBytes:
+    """Zero-copy view of library-owned HBM for torch (torch.distributed needs tensors)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def as_torch_u8(ptr, nbytes):
+    import torch
+    return torch.as_tensor(_DevBytes(ptr, nbytes), device="cuda")
 
 
 def DescriptorDistance(a, b):

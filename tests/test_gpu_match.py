@@ -81,7 +81,8 @@ def test_search_by_projection(seq, fe, orc, th, obs_frac, occ_frac):
     # a small forward motion as the predicted pose: exercises bForward and the full product
     Tcw = np.tile(I, (npairs, 1, 1)); Tcw[:, 2, 3] = -0.8
     Tlw = np.tile(I, (npairs, 1, 1))
-    b.search_by_projection(2, 0, 2, npairs, Tcw, Tlw, cam, th, False, True, d_occupied=d_occ.data_ptr())
+    b.search_by_projection([2 * (p + 1) for p in range(npairs)], [2 * p for p in range(npairs)], Tcw, Tlw, cam, th, False, True,
+                           d_occupied=d_occ.data_ptr())
     total = 0
     for p in range(npairs):
         cur, last = seq["ref"][p + 1], seq["ref"][p]
@@ -95,3 +96,17 @@ def test_search_by_projection(seq, fe, orc, th, obs_frac, occ_frac):
         assert np.array_equal(m[:len(cur["kp"])], om), "mvpMapPoints assignment, pair %d" % p
         total += onm
     assert total > 50 * npairs, "expected plenty of matches, got %d" % total
+
+
+def test_copy_frame_then_match(seq, fe, orc):
+    """mLastFrame = Frame(mCurrentFrame): matching against a copied slot equals matching against the original."""
+    b, T, cam = seq["b"], seq["T"], seq["cam"]
+    I = np.eye(4, dtype=np.float32)
+    b.unproject(2, T, cam, np.tile(I, (T, 1, 1)))
+    b.search_by_projection([2], [0], I[None], I[None], cam, 15.0)
+    m0, p0, n0 = b.download_matches(0)
+    b.copy_frame(0, 7)          # slot 7 (a right image's slot) now holds frame 0's results
+    b.search_by_projection([2], [7], I[None], I[None], cam, 15.0)
+    m1, p1, n1 = b.download_matches(0)
+    assert n0 == n1 and n0 > 50 and np.array_equal(m0, m1) and np.array_equal(p0, p1)
+    # restore slot 7 for other tests in this module is not needed: the fixture is read-only elsewhere
