@@ -87,9 +87,10 @@ def gather_records(dist, local, world):
     import torch
     if dist is None or world == 1:
         return local.unsqueeze(0)
-    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local)
-    return out
+    flat = local.reshape(-1)
+    out = torch.empty((world * flat.numel(),), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, flat)
+    return out.view((world,) + tuple(local.shape))
 
 
 # --------------------------------------------------------------------------- CPU baseline (oracle; rank 0, N=1 only)

@@ -1,0 +1,76 @@
+"""Host logic of bench.py and the synthetic harness (no GPU): sharding, byte accounting, gloo collectives."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_algorithmic_bytes_match_survey(fe):
+    ex = fe.ORBextractor(2000, 1.2, 8, 20, 7)
+    b = bench.algorithmic_bytes(1241, 376, ex.mvInvScaleFactor, 2000)
+    # 466,616 + 1,738,559 + 1,407,767 + 3*1,444,097 + 1,498,000 + 1,024,000 + 120,000
+    assert b["image_total"] == 10587233
+    assert b["k_fast_cells"] == 1444097 and b["k_blur"] == 2 * 1444097
+    assert b["k_pyr_level0"] + b["k_pyr_level"] == 466616 + 1738559 + 1407767
+    ex = fe.ORBextractor(1000, 1.2, 8, 20, 7)
+    assert bench.algorithmic_bytes(640, 480, ex.mvInvScaleFactor, 1000)["image_total"] == 6564354
+
+
+def test_shard_sequences_longest_first():
+    lengths = [4541, 1101, 4661, 801, 271, 2761, 1101, 1101, 4071, 1591, 1201]     # KITTI 00-10
+    owner = bench.shard_sequences(11, lengths, 8)
+    assert sorted(set(owner)) == list(range(8))
+    load = [sum(l for l, o in zip(lengths, owner) if o == r) for r in range(8)]
+    assert max(load) == 4661                                       # the longest sequence bounds the makespan
+    assert bench.shard_sequences(3, [5, 5, 5], 1) == [0, 0, 0]
+
+
+def test_synth_is_deterministic(synth):
+    a = synth.stereo_frame(seq=3, t=2)
+    b = synth.stereo_frame(seq=3, t=2)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    rgb, depth, ts = synth.rgbd_frame(seq=3, t=1)
+    assert rgb.shape == (376, 1241, 3) and depth.dtype == np.uint16 and abs(ts - 0.1) < 1e-9
+    assert depth.min() > 0
+    rows = synth.boxes_for_frame(3, 0)
+    rects = synth.rows_to_rects(rows)
+    assert rects.shape == (3, 4) and (rects[:, 2] >= 60).all()
+    m = synth.mask_from_boxes(rows, 1241, 376)
+    assert set(np.unique(m).tolist()) <= {0, 255} and (m == 255).any()
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    local = torch.full((5, 7), rank + 1, dtype=torch.uint8)
+    g = bench.gather_records(dist, local, world)
+    t = bench.max_over_ranks(dist, 1.0 + rank, torch.device("cpu"))
+    voc = torch.arange(100, dtype=torch.uint8) if rank == 0 else torch.zeros(100, dtype=torch.uint8)
+    dist.broadcast(voc, src=0)
+    q.put((rank, g.shape, [int(g[r].float().mean()) for r in range(world)], t, int(voc.sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_multi_rank_gather_and_timing_gloo():
+    """world_size 2 over gloo on CPU: the N>1 collectives bench.py uses (all_gather of result records,
+    MAX of rank times, vocabulary broadcast)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, shape, means, t, vsum in res:
+        assert tuple(shape) == (2, 5, 7) and means == [1, 2] and t == 2.0 and vsum == sum(range(100))
