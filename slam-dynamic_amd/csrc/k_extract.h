@@ -266,22 +266,11 @@ __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ 
 // a pass divides a set of nodes "in processing order" (list order for the plain passes, descending
 // (size, creation) for the sorted passes of ORBextractor.cc:673-738), children are created in that
 // order and end up reversed at the head of the list, exactly like repeated push_front.  The early
-// `break` of the sorted pass is a prefix-sum cut.  Per-candidate state (node id) lives in HBM/L2,
-// node arrays in LDS.
-struct SdQtShared {
-    // carved from dynamic LDS; all arrays have maxNodes (MN) entries unless noted
-    short4* rectA; short4* rectB;      // x = x0, y = x1, z = y0, w = y1
-    int* cntA; int* cntB;
-    int* child;                        // 4*MN? no: MN entries (child slots of one pass <= MN)
-    int* gidx;                         // MN
-    short* order;                      // MN: list positions in processing order
-    short* procRank;                   // MN: rank in processing order or -1
-    short* keptRank;                   // MN
-    unsigned long long* keys;          // sortP entries
-    unsigned* best;                    // MN
-};
-
-__device__ __forceinline__ int sd_block_excl_scan(int* a, int n, int* wsum /*[>=5]*/)
+// `break` of the sorted pass is a prefix-sum cut.  Node arrays live in LDS (list capacity L = quota+3,
+// child slots 4L); the candidates (packed x,y,score) and their node ids live in REGISTERS, CPT per
+// thread (8 or 32; a global-memory path covers levels with more than 8192 candidates), so a pass
+// touches no HBM/L2 at all.
+__device__ __forceinline__ int sd_block_excl_scan(int* a, int n, int* wsum /*[>=4]*/)
 {
     // in-place exclusive scan of a[0..n) by 256 threads; returns the total
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -314,220 +303,233 @@ __device__ __forceinline__ int sd_quadrant(short4 r, int x, int y)
     return (x < midx ? 0 : 1) + (y < midy ? 0 : 2);   // n1,n2,n3,n4 -> 0,1,2,3
 }
 
+struct SdQtLds {
+    unsigned long long* keys;      // [sortP]
+    short4* rectA; short4* rectB;  // [L]  x = x0, y = x1, z = y0, w = y1
+    int* cntA; int* cntB;          // [L]
+    int* tmp;                      // [L]
+    unsigned* best;                // [L]
+    int* child; int* gidx;         // [4L]
+    short* order; short* procRank; short* keptRank;   // [L]
+    int* wsum;                     // [8]
+    int* scal;                     // [4]
+};
+
+// CPT > 0: candidates c = tid + 256*k, k < CPT, in registers.  CPT == 0: candidates in global memory.
+template <int CPT>
+__device__ __forceinline__ void sd_qt_body(const SdQtLds S, const SdLevel& g, uint32_t* __restrict__ myCand,
+                                           uint16_t* __restrict__ myNode, const int M, const int L, const int sortP,
+                                           int* __restrict__ errFlag, int& nOutRef)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int R = CPT > 0 ? CPT : 1;
+    uint32_t cv[R];
+    int nd[R];
+#define SD_FOR_CAND(BODY)                                                                      \
+    if constexpr (CPT > 0) {                                                                   \
+        _Pragma("unroll") for (int k_ = 0; k_ < CPT; k_++) {                                   \
+            const int c = tid + 256 * k_;                                                      \
+            if (c < M) { const uint32_t V = cv[k_]; int& ND = nd[k_]; BODY }                   \
+        }                                                                                      \
+    } else {                                                                                   \
+        for (int c = tid; c < M; c += 256) {                                                   \
+            const uint32_t V = myCand[c]; int ND = myNode[c]; BODY myNode[c] = (uint16_t)ND;   \
+        }                                                                                      \
+    }
+    if constexpr (CPT > 0) {
+#pragma unroll
+        for (int k = 0; k < CPT; k++) { const int c = tid + 256 * k; cv[k] = c < M ? myCand[c] : 0u; nd[k] = 0; }
+    }
+    // ---- initial nodes (ORBextractor.cc:543-588)
+    const int N = g.quota, nIni = g.nIni;
+    const float hX = g.hX;
+    for (int i = tid; i < nIni; i += 256) S.child[i] = 0;
+    __syncthreads();
+    SD_FOR_CAND({
+        int idx = (int)((float)(V & 0xFFF) / hX);
+        idx = min(idx, nIni - 1);
+        ND = idx;
+        atomicAdd(&S.child[idx], 1);
+    })
+    __syncthreads();
+    for (int i = tid; i < nIni; i += 256) S.tmp[i] = S.child[i] > 0;
+    __syncthreads();
+    int n = sd_block_excl_scan(S.tmp, nIni, S.wsum);
+    for (int i = tid; i < nIni; i += 256) {
+        if (S.child[i] > 0) {
+            short4 r;
+            r.x = (short)(int)(hX * (float)i); r.y = (short)(int)(hX * (float)(i + 1));
+            r.z = 0; r.w = (short)(g.maxBY - g.minBY);
+            S.rectA[S.tmp[i]] = r; S.cntA[S.tmp[i]] = S.child[i];
+        }
+    }
+    __syncthreads();
+    SD_FOR_CAND({ ND = S.tmp[ND]; })
+    __syncthreads();
+
+    short4* rc = S.rectA; short4* rn = S.rectB; int* cc = S.cntA; int* cn = S.cntB;
+    bool sortedPhase = false;
+    for (int iter = 0; iter < 96; iter++) {
+        const int prev = n;
+        // ---- processing order
+        for (int i = tid; i < n; i += 256) { S.tmp[i] = cc[i] > 1; S.procRank[i] = -1; }
+        if (sortedPhase)
+            for (int i = tid; i < sortP; i += 256)
+                S.keys[i] = (i < n && cc[i] > 1) ? (((unsigned long long)(unsigned)cc[i] << 32) | (unsigned)(0xFFFF - i)) : 0ull;
+        __syncthreads();
+        const int m = sd_block_excl_scan(S.tmp, n, S.wsum);
+        if (!sortedPhase) {
+            for (int i = tid; i < n; i += 256) if (cc[i] > 1) S.order[S.tmp[i]] = (short)i;
+        } else {
+            for (int k = 2; k <= sortP; k <<= 1)        // bitonic sort, descending
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = tid; i < sortP; i += 256) {
+                        const int ixj = i ^ j;
+                        if (ixj > i) {
+                            const unsigned long long a = S.keys[i], b = S.keys[ixj];
+                            const bool desc = ((i & k) == 0);
+                            if (desc ? (a < b) : (a > b)) { S.keys[i] = b; S.keys[ixj] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (int i = tid; i < m; i += 256) S.order[i] = (short)(0xFFFF - (unsigned)(S.keys[i] & 0xFFFFu));
+        }
+        for (int i = tid; i < 4 * m; i += 256) S.child[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < m; i += 256) S.procRank[S.order[i]] = (short)i;
+        __syncthreads();
+        // ---- child counts of every node in `order`
+        SD_FOR_CAND({
+            const int t = S.procRank[ND];
+            if (t >= 0) atomicAdd(&S.child[4 * t + sd_quadrant(rc[ND], V & 0xFFF, (V >> 12) & 0xFFF)], 1);
+        })
+        __syncthreads();
+        // ---- sorted pass: cut at the first division that reaches N nodes (break at :731-732)
+        int mEff = m;
+        if (sortedPhase) {
+            if (tid == 0) S.scal[0] = m;
+            for (int i = tid; i < m; i += 256) {
+                const int e = (S.child[4 * i] > 0) + (S.child[4 * i + 1] > 0) + (S.child[4 * i + 2] > 0) + (S.child[4 * i + 3] > 0) - 1;
+                S.gidx[i] = e; S.tmp[i] = e;
+            }
+            __syncthreads();
+            sd_block_excl_scan(S.tmp, m, S.wsum);
+            for (int i = tid; i < m; i += 256)
+                if (n + S.tmp[i] + S.gidx[i] >= N) atomicMin(&S.scal[0], i);
+            __syncthreads();
+            mEff = min(m, S.scal[0] + 1);
+            __syncthreads();
+            for (int i = tid + mEff; i < m; i += 256) S.procRank[S.order[i]] = -1;
+            __syncthreads();
+        }
+        // ---- creation index of the non-empty children, in creation order
+        for (int i = tid; i < 4 * mEff; i += 256) S.gidx[i] = S.child[i] > 0;
+        for (int i = tid; i < n; i += 256) S.tmp[i] = S.procRank[i] < 0;
+        __syncthreads();
+        const int E = sd_block_excl_scan(S.gidx, 4 * mEff, S.wsum);
+        const int K = sd_block_excl_scan(S.tmp, n, S.wsum);
+        // ---- new list: children reversed at the head, untouched nodes behind in their old order
+        int nExp = 0;
+        for (int j = tid; j < 4 * mEff; j += 256) {
+            const int cj = S.child[j];
+            if (cj > 0) {
+                const short4 r = rc[S.order[j >> 2]];
+                const int q = j & 3;
+                const int midx = r.x + ((r.y - r.x + 1) >> 1), midy = r.z + ((r.w - r.z + 1) >> 1);
+                short4 o;
+                o.x = (q & 1) ? (short)midx : r.x; o.y = (q & 1) ? r.y : (short)midx;
+                o.z = (q & 2) ? (short)midy : r.z; o.w = (q & 2) ? r.w : (short)midy;
+                const int np = E - 1 - S.gidx[j];
+                rn[np] = o; cn[np] = cj;
+                nExp += (cj > 1);
+            }
+        }
+        for (int i = tid; i < n; i += 256)
+            if (S.procRank[i] < 0) { const int np = E + S.tmp[i]; rn[np] = rc[i]; cn[np] = cc[i]; S.keptRank[i] = (short)S.tmp[i]; }
+        __syncthreads();
+        SD_FOR_CAND({
+            const int t = S.procRank[ND];
+            if (t >= 0) ND = E - 1 - S.gidx[4 * t + sd_quadrant(rc[ND], V & 0xFFF, (V >> 12) & 0xFFF)];
+            else ND = E + S.keptRank[ND];
+        })
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nExp += __shfl_xor(nExp, o, 64);
+        if (lane == 0) S.wsum[4 + wv] = nExp;
+        __syncthreads();
+        const int nToExpand = S.wsum[4] + S.wsum[5] + S.wsum[6] + S.wsum[7];
+        n = E + K;
+        { short4* t1 = rc; rc = rn; rn = t1; int* t2 = cc; cc = cn; cn = t2; }
+        if (n >= N || n == prev) break;                       // ORBextractor.cc:666-669, 735-736
+        if (!sortedPhase && (n + nToExpand * 3) > N) sortedPhase = true;   // :670
+        if (n + 4 > L) { if (tid == 0) atomicOr(errFlag, 1); break; }
+    }
+    // ---- best response per node, first in candidate order on ties (ORBextractor.cc:741-760)
+    for (int i = tid; i < n; i += 256) S.best[i] = 0;
+    __syncthreads();
+    SD_FOR_CAND({ atomicMax(&S.best[ND], ((V >> 24) << 24) | (0xFFFFFFu - (unsigned)c)); })
+    __syncthreads();
+    nOutRef = n;
+#undef SD_FOR_CAND
+}
+
 __global__ void __launch_bounds__(256) k_quadtree(const uint32_t* __restrict__ cellList,
                                                   const int* __restrict__ cellCount, const SdCell* __restrict__ cells,
                                                   uint32_t* __restrict__ cand, uint16_t* __restrict__ nodeOf,
                                                   int* __restrict__ lvlCount, int* __restrict__ candCount,
                                                   uint32_t* __restrict__ lvlKp, int* __restrict__ errFlag,
-                                                  const SdDevPlan* __restrict__ PP, int MN, int sortP)
+                                                  const SdDevPlan* __restrict__ PP, int L, int sortP)
 {
     const SdDevPlan& P = *PP;
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int s_wsum[8];
-    __shared__ int s_scal[8];
+    __shared__ int s_scal[4];
     const int level = blockIdx.x, img = blockIdx.y;
     const SdLevel& g = P.lv[level];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // carve
+    SdQtLds S;
     unsigned char* p = smem;
-    unsigned long long* keys = (unsigned long long*)p; p += (size_t)sortP * 8;
-    short4* rectA = (short4*)p; p += (size_t)MN * 8;
-    short4* rectB = (short4*)p; p += (size_t)MN * 8;
-    int* cntA = (int*)p; p += (size_t)MN * 4;
-    int* cntB = (int*)p; p += (size_t)MN * 4;
-    int* child = (int*)p; p += (size_t)MN * 4;
-    int* gidx = (int*)p; p += (size_t)MN * 4;
-    int* tmp = (int*)p; p += (size_t)MN * 4;
-    unsigned* best = (unsigned*)p; p += (size_t)MN * 4;
-    short* order = (short*)p; p += (size_t)MN * 2;
-    short* procRank = (short*)p; p += (size_t)MN * 2;
-    short* keptRank = (short*)p; p += (size_t)MN * 2;
+    S.keys = (unsigned long long*)p; p += (size_t)sortP * 8;
+    S.rectA = (short4*)p; p += (size_t)L * 8;
+    S.rectB = (short4*)p; p += (size_t)L * 8;
+    S.cntA = (int*)p; p += (size_t)L * 4;
+    S.cntB = (int*)p; p += (size_t)L * 4;
+    S.tmp = (int*)p; p += (size_t)L * 4;
+    S.best = (unsigned*)p; p += (size_t)L * 4;
+    S.child = (int*)p; p += (size_t)L * 16;
+    S.gidx = (int*)p; p += (size_t)L * 16;
+    S.order = (short*)p; p += (size_t)L * 2;
+    S.procRank = (short*)p; p += (size_t)L * 2;
+    S.keptRank = (short*)p; p += (size_t)L * 2;
+    S.wsum = s_wsum; S.scal = s_scal;
 
     uint32_t* myCand = cand + (size_t)img * P.cellListCap + g.candOffset;
     uint16_t* myNode = nodeOf + (size_t)img * P.cellListCap + g.candOffset;
     const int* myCellCount = cellCount + (size_t)img * P.cellTotal + g.cell0;
     const uint32_t* myList = cellList + (size_t)img * P.cellListCap;
 
-    // ---- 1. compact the per-cell candidate lists in cell order (row-major cells, row-major pixels)
-    for (int i = tid; i < g.nCells; i += 256) tmp[i] = myCellCount[i];
+    // ---- compact the per-cell candidate lists in cell order (row-major cells, row-major pixels)
+    for (int i = tid; i < g.nCells; i += 256) S.tmp[i] = myCellCount[i];
     __syncthreads();
-    int M;
-    {
-        // nCells may exceed MN only for tiny quotas; scan in tmp needs nCells <= MN (checked on host)
-        M = sd_block_excl_scan(tmp, g.nCells, s_wsum);
-    }
+    const int M = sd_block_excl_scan(S.tmp, g.nCells, S.wsum);
     for (int ci = wv; ci < g.nCells; ci += 4) {
-        const SdCell c = cells[g.cell0 + ci];
-        const int n = myCellCount[ci], off = tmp[ci];
-        for (int r = lane; r < n; r += 64) myCand[off + r] = myList[c.listOffset + r];
+        const int n = myCellCount[ci], off = S.tmp[ci];
+        const int lo = cells[g.cell0 + ci].listOffset;
+        for (int r = lane; r < n; r += 64) myCand[off + r] = myList[lo + r];
     }
-    __syncthreads();
+    __syncthreads();     // workgroup-scope: myCand is re-read below by other threads of this workgroup
     if (tid == 0) candCount[(size_t)img * P.nlevels + level] = M;
 
-    // ---- 2. initial nodes (ORBextractor.cc:543-588)
-    const int N = g.quota;
-    const int nIni = g.nIni;
-    const float hX = g.hX;
-    for (int i = tid; i < nIni; i += 256) child[i] = 0;
-    __syncthreads();
-    for (int c = tid; c < M; c += 256) {
-        const uint32_t v = myCand[c];
-        const int x = v & 0xFFF;
-        int idx = (int)((float)x / hX);
-        idx = min(idx, nIni - 1);
-        myNode[c] = (uint16_t)idx;
-        atomicAdd(&child[idx], 1);
-    }
-    __syncthreads();
-    for (int i = tid; i < nIni; i += 256) tmp[i] = child[i] > 0;
-    __syncthreads();
-    int n = sd_block_excl_scan(tmp, nIni, s_wsum);
-    for (int i = tid; i < nIni; i += 256) {
-        if (child[i] > 0) {
-            short4 r;
-            r.x = (short)(int)(hX * (float)i); r.y = (short)(int)(hX * (float)(i + 1));
-            r.z = 0; r.w = (short)(g.maxBY - g.minBY);
-            rectA[tmp[i]] = r; cntA[tmp[i]] = child[i];
-        }
-    }
-    __syncthreads();
-    for (int c = tid; c < M; c += 256) myNode[c] = (uint16_t)tmp[myNode[c]];
-    __syncthreads();
+    int n = 0;
+    if (M <= 256 * 8) sd_qt_body<8>(S, g, myCand, myNode, M, L, sortP, errFlag, n);
+    else if (M <= 256 * 32) sd_qt_body<32>(S, g, myCand, myNode, M, L, sortP, errFlag, n);
+    else sd_qt_body<0>(S, g, myCand, myNode, M, L, sortP, errFlag, n);
 
-    short4* rc = rectA; short4* rn = rectB; int* cc = cntA; int* cn = cntB;
-    bool sortedPhase = false;
-    for (int iter = 0; iter < 96; iter++) {
-        const int prev = n;
-        // ---- processing order
-        int m;
-        if (!sortedPhase) {
-            for (int i = tid; i < n; i += 256) tmp[i] = cc[i] > 1;
-            __syncthreads();
-            m = sd_block_excl_scan(tmp, n, s_wsum);
-            for (int i = tid; i < n; i += 256) if (cc[i] > 1) order[tmp[i]] = (short)i;
-        } else {
-            for (int i = tid; i < sortP; i += 256)
-                keys[i] = (i < n && cc[i] > 1) ? (((unsigned long long)(unsigned)cc[i] << 32) | (unsigned)(0xFFFF - i)) : 0ull;
-            __syncthreads();
-            // bitonic sort, descending
-            for (int k = 2; k <= sortP; k <<= 1)
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int i = tid; i < sortP; i += 256) {
-                        int ixj = i ^ j;
-                        if (ixj > i) {
-                            unsigned long long a = keys[i], b = keys[ixj];
-                            bool desc = ((i & k) == 0);
-                            if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[ixj] = a; }
-                        }
-                    }
-                    __syncthreads();
-                }
-            for (int i = tid; i < n; i += 256) tmp[i] = cc[i] > 1;
-            __syncthreads();
-            m = sd_block_excl_scan(tmp, n, s_wsum);
-            for (int i = tid; i < m; i += 256) order[i] = (short)(0xFFFF - (unsigned)(keys[i] & 0xFFFFu));
-        }
-        __syncthreads();
-        // ---- child counts for every node in `order`
-        for (int i = tid; i < n; i += 256) procRank[i] = -1;
-        for (int i = tid; i < 4 * m; i += 256) child[i] = 0;
-        __syncthreads();
-        for (int i = tid; i < m; i += 256) procRank[order[i]] = (short)i;
-        __syncthreads();
-        for (int c = tid; c < M; c += 256) {
-            const int pos = myNode[c];
-            const int t = procRank[pos];
-            if (t >= 0) {
-                const uint32_t v = myCand[c];
-                const int q = sd_quadrant(rc[pos], v & 0xFFF, (v >> 12) & 0xFFF);
-                atomicAdd(&child[4 * t + q], 1);
-            }
-        }
-        __syncthreads();
-        // ---- sorted pass: cut at the first division that reaches N nodes (break at :731-732)
-        int mEff = m;
-        if (sortedPhase) {
-            if (tid == 0) s_scal[0] = m;
-            for (int i = tid; i < m; i += 256)
-                gidx[i] = (child[4 * i] > 0) + (child[4 * i + 1] > 0) + (child[4 * i + 2] > 0) + (child[4 * i + 3] > 0) - 1;
-            __syncthreads();
-            for (int i = tid; i < m; i += 256) tmp[i] = gidx[i];
-            __syncthreads();
-            sd_block_excl_scan(tmp, m, s_wsum);
-            for (int i = tid; i < m; i += 256)
-                if (n + tmp[i] + gidx[i] >= N) atomicMin(&s_scal[0], i);
-            __syncthreads();
-            mEff = min(m, s_scal[0] + 1);
-            __syncthreads();
-            for (int i = tid + mEff; i < m; i += 256) procRank[order[i]] = -1;
-            __syncthreads();
-        }
-        // ---- creation index of the non-empty children, in creation order
-        for (int i = tid; i < 4 * mEff; i += 256) gidx[i] = child[i] > 0;
-        __syncthreads();
-        const int E = sd_block_excl_scan(gidx, 4 * mEff, s_wsum);
-        for (int i = tid; i < n; i += 256) tmp[i] = procRank[i] < 0;
-        __syncthreads();
-        const int K = sd_block_excl_scan(tmp, n, s_wsum);
-        for (int i = tid; i < n; i += 256) keptRank[i] = (short)tmp[i];
-        __syncthreads();
-        // ---- new list: children reversed at the head, untouched nodes behind in their old order
-        int nExp = 0;
-        for (int j = tid; j < 4 * mEff; j += 256) {
-            const int cj = child[j];
-            if (cj > 0) {
-                const short4 r = rc[order[j >> 2]];
-                const int q = j & 3;
-                const int midx = r.x + ((r.y - r.x + 1) >> 1), midy = r.z + ((r.w - r.z + 1) >> 1);
-                short4 o;
-                o.x = (q & 1) ? (short)midx : r.x; o.y = (q & 1) ? r.y : (short)midx;
-                o.z = (q & 2) ? (short)midy : r.z; o.w = (q & 2) ? r.w : (short)midy;
-                const int np = E - 1 - gidx[j];
-                rn[np] = o; cn[np] = cj;
-                nExp += (cj > 1);
-            }
-        }
-        for (int i = tid; i < n; i += 256)
-            if (procRank[i] < 0) { const int np = E + keptRank[i]; rn[np] = rc[i]; cn[np] = cc[i]; }
-        for (int c = tid; c < M; c += 256) {
-            const int pos = myNode[c];
-            const int t = procRank[pos];
-            int np;
-            if (t >= 0) {
-                const uint32_t v = myCand[c];
-                const int q = sd_quadrant(rc[pos], v & 0xFFF, (v >> 12) & 0xFFF);
-                np = E - 1 - gidx[4 * t + q];
-            } else np = E + keptRank[pos];
-            myNode[c] = (uint16_t)np;
-        }
-        // nToExpand (block sum)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) nExp += __shfl_xor(nExp, o, 64);
-        __syncthreads();
-        if (lane == 0) s_wsum[4 + wv] = nExp;
-        __syncthreads();
-        const int nToExpand = s_wsum[4] + s_wsum[5] + s_wsum[6] + s_wsum[7];
-        n = E + K;
-        { short4* t1 = rc; rc = rn; rn = t1; int* t2 = cc; cc = cn; cn = t2; }
-        __syncthreads();
-        if (n >= N || n == prev) break;                       // ORBextractor.cc:666-669, 735-736
-        if (!sortedPhase && (n + nToExpand * 3) > N) sortedPhase = true;   // :670
-        if (n + 4 > MN) { if (tid == 0) atomicOr(errFlag, 1); break; }
-    }
-
-    // ---- 3. best response per node, first in candidate order on ties (ORBextractor.cc:741-760)
-    for (int i = tid; i < n; i += 256) best[i] = 0;
-    __syncthreads();
-    for (int c = tid; c < M; c += 256) {
-        const uint32_t v = myCand[c];
-        atomicMax(&best[myNode[c]], ((v >> 24) << 24) | (0xFFFFFFu - (unsigned)c));
-    }
-    __syncthreads();
     const int nOut = min(n, g.kpCap);
     if (n > g.kpCap && tid == 0) atomicOr(errFlag, 2);
     uint32_t* out = lvlKp + (size_t)img * P.kpCapLevels + g.kpOffset;
     for (int i = tid; i < nOut; i += 256) {
-        const unsigned c = 0xFFFFFFu - (best[i] & 0xFFFFFFu);
+        const unsigned c = 0xFFFFFFu - (S.best[i] & 0xFFFFFFu);
         out[i] = myCand[c];
     }
     if (tid == 0) lvlCount[(size_t)img * P.nlevels + level] = nOut;

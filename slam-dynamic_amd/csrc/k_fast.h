@@ -1,0 +1,303 @@
+// k_fast_cells_staged — FAST-9/16 + NMS + threshold fallback per cell, staged so that the expensive
+// work only runs on dense survivor lists (src/ORBextractor.cc:789-829, cv::FAST).
+//
+//   phase 0  window -> LDS tile (unaligned dword loads, 4 B/lane), tile column c = window x + 1 so that
+//            the scanned pixels start on a word boundary
+//   phase 1  ALL scanned pixels, 4 per thread from packed words: compass test.  Any 9-arc of the
+//            16-ring holds two ADJACENT compass points (ring 0,4,8,12), so a corner needs an adjacent
+//            compass pair both darker than v-T or both brighter than v+T (T = minTh).  ~25 ops/px.
+//   phase 2  survivors (wave-ballot compacted): exact 16-bit dark/bright ring masks, 9-contiguous test
+//   phase 3  corners (compacted again): cornerScore (sliding 9-window min/max) -> score tile
+//   phase 4  3x3 strict-maximum NMS on the corner list; cell threshold = iniTh if any survivor >= iniTh
+//   phase 5  row-major ordered emission (prefix sum over the score tile)
+// Same results as k_fast_cells (kept as the generic path for windows > 52 px); see that kernel's header
+// comment for why the threshold-free score map reproduces OpenCV's two-threshold behaviour.
+#pragma once
+#include "k_extract.h"
+
+#define SD_FS_MAXWIN 52            // largest window side handled here
+#define SD_FS_TW 56                // tile row stride (bytes) = 14 words
+#define SD_FS_SW 48                // score tile row stride (bytes), 1-px zero frame included
+#define SD_FS_MAXSCAN (46 * 46)
+
+typedef uint32_t __attribute__((aligned(1))) sd_u32_unaligned;
+
+__device__ __forceinline__ int sd_wave_append(bool pred, int* counter)
+{
+    // returns the slot for lanes with pred, using one LDS atomic per wave
+    const unsigned long long m = __ballot(pred);
+    if (m == 0) return -1;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1, 64);
+    return pred ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
+
+__global__ void __launch_bounds__(256) k_fast_cells_staged(const uint8_t* __restrict__ pyr,
+                                                           const SdCell* __restrict__ cells,
+                                                           uint32_t* __restrict__ cellList, int* __restrict__ cellCount,
+                                                           const SdDevPlan* __restrict__ PP)
+{
+    const SdDevPlan& P = *PP;
+    __shared__ __align__(16) uint8_t tile[SD_FS_MAXWIN * SD_FS_TW];
+    __shared__ __align__(16) uint8_t score[SD_FS_SW * SD_FS_SW];
+    __shared__ unsigned short list1[SD_FS_MAXSCAN];
+    __shared__ unsigned short list2[SD_FS_MAXSCAN];
+    __shared__ int s_cnt1, s_cnt2, s_any, s_wsum[4];
+    const int img = blockIdx.y;
+    const SdCell c = cells[blockIdx.x];
+    const SdLevel& g = P.lv[c.level];
+    const int ww = c.x1 - c.x0, wh = c.y1 - c.y0;
+    const int sw = ww - 6, sh = wh - 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (sw <= 0 || sh <= 0) { if (tid == 0) cellCount[(size_t)img * P.cellTotal + blockIdx.x] = 0; return; }
+    if (tid == 0) { s_cnt1 = 0; s_cnt2 = 0; s_any = 0; }
+    // ---- phase 0
+    const uint8_t* src = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)(SD_EDGE + c.y0) * g.stride +
+                         SD_XOFF + c.x0 - 1;
+    uint32_t* tileW = (uint32_t*)tile;
+    for (int i = tid; i < wh * 14; i += 256) {
+        const int y = i / 14, wd = i - y * 14;
+        tileW[i] = *(const sd_u32_unaligned*)(src + (size_t)y * g.stride + 4 * wd);
+    }
+    uint32_t* scoreW = (uint32_t*)score;
+    for (int i = tid; i < SD_FS_SW * SD_FS_SW / 4; i += 256) scoreW[i] = 0;
+    __syncthreads();
+    const int T = P.minTh;
+    // ---- phase 1: compass quick test, 4 px per thread
+    const int ng = (sw + 3) >> 2;
+    const int nitems = sh * ng;
+    for (int it0 = 0; it0 < nitems; it0 += 256) {
+        const int it = it0 + tid;
+        const bool live = it < nitems;
+        int sy = 0, gq = 0;
+        uint32_t C = 0, E = 0, Wst = 0, N = 0, S = 0;
+        if (live) {
+            sy = it / ng; gq = it - sy * ng;
+            const uint32_t* row = tileW + (sy + 3) * 14 + gq;
+            const uint32_t w0 = row[0], w1 = row[1], w2 = row[2];
+            C = w1;
+            E = __builtin_amdgcn_alignbyte(w2, w1, 3);
+            Wst = __builtin_amdgcn_alignbyte(w1, w0, 1);
+            N = tileW[sy * 14 + gq + 1];
+            S = tileW[(sy + 6) * 14 + gq + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int cc = (C >> (8 * j)) & 255;
+            const int lo = cc - T, hi = cc + T;
+            const int e = (E >> (8 * j)) & 255, w = (Wst >> (8 * j)) & 255, n = (N >> (8 * j)) & 255, s = (S >> (8 * j)) & 255;
+            // ring order S(0), E(4), N(8), W(12)
+            const unsigned dk = (unsigned)(s < lo) | ((unsigned)(e < lo) << 1) | ((unsigned)(n < lo) << 2) | ((unsigned)(w < lo) << 3);
+            const unsigned br = (unsigned)(s > hi) | ((unsigned)(e > hi) << 1) | ((unsigned)(n > hi) << 2) | ((unsigned)(w > hi) << 3);
+            const unsigned dr = dk | (dk << 4), bq = br | (br << 4);
+            const bool pass = live && (4 * gq + j < sw) && ((((dr & (dr >> 1)) | (bq & (bq >> 1))) & 0xF) != 0);
+            const int slot = sd_wave_append(pass, &s_cnt1);
+            if (pass) list1[slot] = (unsigned short)((sy << 8) | (4 * gq + j));
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: exact ring test on the survivors
+    const int n1 = s_cnt1;
+    for (int i0 = 0; i0 < n1; i0 += 256) {
+        const int i = i0 + tid;
+        bool corner = false;
+        unsigned short ent = 0;
+        if (i < n1) {
+            ent = list1[i];
+            const int sx = ent & 255, sy = ent >> 8;
+            const uint8_t* p = tile + (sy + 3) * SD_FS_TW + sx + 4;
+            const int v = p[0];
+            const int a = T - v, b = v + T;      // sign(r + a) -> darker ; sign(b - r) -> brighter
+            unsigned dark = 0, bright = 0;
+            const int S = SD_FS_TW;
+#define SD_RING(off) { const int r = p[off]; dark = __builtin_amdgcn_alignbit(dark, (unsigned)(r + a), 31); \
+                       bright = __builtin_amdgcn_alignbit(bright, (unsigned)(b - r), 31); }
+            SD_RING(3 * S) SD_RING(3 * S + 1) SD_RING(2 * S + 2) SD_RING(S + 3) SD_RING(3) SD_RING(-S + 3)
+            SD_RING(-2 * S + 2) SD_RING(-3 * S + 1) SD_RING(-3 * S) SD_RING(-3 * S - 1) SD_RING(-2 * S - 2)
+            SD_RING(-S - 3) SD_RING(-3) SD_RING(S - 3) SD_RING(2 * S - 2) SD_RING(3 * S - 1)
+#undef SD_RING
+            corner = sd_has9(dark & 0xFFFFu) || sd_has9(bright & 0xFFFFu);
+        }
+        const int slot = sd_wave_append(corner, &s_cnt2);
+        if (corner) list2[slot] = ent;
+    }
+    __syncthreads();
+    // ---- phase 3: corner score into the score tile
+    const int n2 = s_cnt2;
+    for (int i = tid; i < n2; i += 256) {
+        const unsigned short ent = list2[i];
+        const int sx = ent & 255, sy = ent >> 8;
+        const uint8_t* p = tile + (sy + 3) * SD_FS_TW + sx + 4;
+        const int S = SD_FS_TW;
+        const int v = p[0];
+        int d[16];
+        d[0] = v - p[3 * S];       d[1] = v - p[3 * S + 1];   d[2] = v - p[2 * S + 2];   d[3] = v - p[S + 3];
+        d[4] = v - p[3];           d[5] = v - p[-S + 3];      d[6] = v - p[-2 * S + 2];  d[7] = v - p[-3 * S + 1];
+        d[8] = v - p[-3 * S];      d[9] = v - p[-3 * S - 1];  d[10] = v - p[-2 * S - 2]; d[11] = v - p[-S - 3];
+        d[12] = v - p[-3];         d[13] = v - p[S - 3];      d[14] = v - p[2 * S - 2];  d[15] = v - p[3 * S - 1];
+        int mn2[16], mx2[16], mn4[16], mx4[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+        for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+        int A = -1000, B = 1000;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            A = max(A, min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]));
+            B = min(B, max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]));
+        }
+        const int s = max(A, -B) - 1;                       // >= T for a corner at T
+        score[(sy + 1) * SD_FS_SW + sx + 1] = (uint8_t)s;
+    }
+    __syncthreads();
+    // ---- phase 4: 3x3 NMS over the corner list (zero frame = pixels outside the scanned area)
+    unsigned supp = 0;
+    int any = 0;
+    {
+        int k = 0;
+        for (int i = tid; i < n2; i += 256, k++) {
+            const unsigned short ent = list2[i];
+            const uint8_t* q = score + ((ent >> 8) + 1) * SD_FS_SW + (ent & 255) + 1;
+            const int s = q[0];
+            const bool ok = s > q[-SD_FS_SW - 1] && s > q[-SD_FS_SW] && s > q[-SD_FS_SW + 1] && s > q[-1] && s > q[1] &&
+                            s > q[SD_FS_SW - 1] && s > q[SD_FS_SW] && s > q[SD_FS_SW + 1];
+            if (!ok) supp |= 1u << k;
+            any |= (ok && s >= P.iniTh);
+        }
+    }
+    if (any) s_any = 1;
+    __syncthreads();
+    {
+        int k = 0;
+        for (int i = tid; i < n2; i += 256, k++)
+            if (supp & (1u << k)) { const unsigned short ent = list2[i]; score[((ent >> 8) + 1) * SD_FS_SW + (ent & 255) + 1] = 0; }
+    }
+    __syncthreads();
+    const int Tc = s_any ? P.iniTh : P.minTh;
+    // ---- phase 5: ordered emission; word index = sy*12 + wd over rows 1..sh of the score tile
+    const int nwords = sh * 12;
+    const int chunk = (nwords + 255) / 256;
+    const int beg = min(tid * chunk, nwords), end = min(beg + chunk, nwords);
+    int cnt = 0;
+    for (int i = beg; i < end; i++) {
+        const int sy = i / 12, wd = i - sy * 12;
+        const uint32_t w = scoreW[(sy + 1) * 12 + wd];
+#pragma unroll
+        for (int k = 0; k < 4; k++) cnt += (int)((w >> (8 * k)) & 255) >= Tc;
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; w++) base += s_wsum[w];
+    const int total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    int pos = base + incl - cnt;
+    uint32_t* out = cellList + (size_t)img * P.cellListCap + c.listOffset;
+    for (int i = beg; i < end; i++) {
+        const int sy = i / 12, wd = i - sy * 12;
+        const uint32_t w = scoreW[(sy + 1) * 12 + wd];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int s = (w >> (8 * k)) & 255;
+            if (s >= Tc) {
+                const int sx = 4 * wd + k - 1;
+                const uint32_t px = (uint32_t)(sx + 3 + c.jw), py = (uint32_t)(sy + 3 + c.ih);
+                if (pos < c.cap) out[pos] = px | (py << 12) | ((uint32_t)s << 24);
+                pos++;
+            }
+        }
+    }
+    if (tid == 0) cellCount[(size_t)img * P.cellTotal + blockIdx.x] = min(total, c.cap);
+}
+
+// ------------------------------------------------------------------ Gaussian blur 7x7, wide-access version
+// Tile = 128 x 16 output pixels per 256-thread workgroup.  Horizontal pass straight from HBM with aligned
+// dword loads (the pyramid's own REFLECT_101 frame supplies the halo): per output pixel two
+// v_dot4_u32_u8 against the packed taps; exact 8.8 sums go to LDS as packed u16.  Vertical pass from
+// LDS (ds_read_b64), 7 mads per pixel, (sum + 0x8000) >> 16, one dword store per 4 pixels.
+__global__ void __launch_bounds__(256) k_blur_wide(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
+                                                   const SdDevPlan* __restrict__ PP)
+{
+    const SdDevPlan& P = *PP;
+    __shared__ uint2 hbuf[22][32];
+    const int zi = blockIdx.z;
+    const int img = zi / P.nlevels, level = zi - img * P.nlevels;
+    const SdLevel& g = P.lv[level];
+    const int x0 = blockIdx.x * 128, y0 = blockIdx.y * 16;
+    if (x0 >= g.W || y0 >= g.H) return;
+    const int tid = threadIdx.x;
+    const uint32_t tapsLo = (uint32_t)P.taps[0] | ((uint32_t)P.taps[1] << 8) | ((uint32_t)P.taps[2] << 16) | ((uint32_t)P.taps[3] << 24);
+    const uint32_t tapsHi = (uint32_t)P.taps[4] | ((uint32_t)P.taps[5] << 8) | ((uint32_t)P.taps[6] << 16);
+    const uint8_t* src = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)SD_EDGE * g.stride + SD_XOFF;
+    for (int it = tid; it < 22 * 32; it += 256) {
+        const int r = it >> 5, gq = it & 31;
+        const int y = min(y0 + r - 3, g.H + 2);
+        const uint32_t* rowp = (const uint32_t*)(src + (ptrdiff_t)y * g.stride + x0 + 4 * gq - 4);
+        const uint32_t w0 = rowp[0], w1 = rowp[1], w2 = rowp[2];
+        uint32_t h[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t A = j == 3 ? w1 : __builtin_amdgcn_alignbyte(w1, w0, j + 1);
+            const uint32_t B = j == 3 ? w2 : __builtin_amdgcn_alignbyte(w2, w1, j + 1);
+            h[j] = __builtin_amdgcn_udot4(A, tapsLo, __builtin_amdgcn_udot4(B, tapsHi, 0u, false), false);
+        }
+        hbuf[r][gq] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    }
+    __syncthreads();
+    uint8_t* dst = blur + (size_t)img * P.blurImageBytes + g.blurOffset;
+    for (int it = tid; it < 16 * 32; it += 256) {
+        const int r = it >> 5, gq = it & 31;
+        const int x = x0 + 4 * gq, y = y0 + r;
+        if (x < g.W && y < g.H) {
+            uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                const uint2 v = hbuf[r + k][gq];
+                const uint32_t t = (uint32_t)P.taps[k];
+                s0 += t * (v.x & 0xFFFFu); s1 += t * (v.x >> 16);
+                s2 += t * (v.y & 0xFFFFu); s3 += t * (v.y >> 16);
+            }
+            const uint32_t o0 = min((s0 + 0x8000u) >> 16, 255u), o1 = min((s1 + 0x8000u) >> 16, 255u);
+            const uint32_t o2 = min((s2 + 0x8000u) >> 16, 255u), o3 = min((s3 + 0x8000u) >> 16, 255u);
+            *(uint32_t*)(dst + (size_t)y * g.blurStride + x) = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ cvtColor -> gray, 4 px per thread with dword accesses
+__global__ void __launch_bounds__(256) k_cvt_gray3_wide(const uint8_t* __restrict__ src, int W, int H, size_t sstride,
+                                                        size_t spitch, int rgbOrder, uint8_t* __restrict__ dst,
+                                                        size_t dstride, size_t dpitch)
+{
+    const int img = blockIdx.z;
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (y >= H || x0 + 3 >= W) {
+        if (y < H && x0 < W) {      // ragged tail of the row: byte path
+            const uint8_t* s = src + (size_t)img * spitch + (size_t)y * sstride + (size_t)x0 * 3;
+            uint8_t* d = dst + (size_t)img * dpitch + (size_t)y * dstride + x0;
+            for (int k = 0; k < W - x0; k++) {
+                const uint8_t* p = s + 3 * k;
+                const int r = rgbOrder ? p[0] : p[2], gg = p[1], b = rgbOrder ? p[2] : p[0];
+                d[k] = (uint8_t)((r * 4899 + gg * 9617 + b * 1868 + (1 << 13)) >> 14);
+            }
+        }
+        return;
+    }
+    const sd_u32_unaligned* s = (const sd_u32_unaligned*)(src + (size_t)img * spitch + (size_t)y * sstride + (size_t)x0 * 3);
+    const uint32_t a = s[0], b = s[1], c = s[2];     // 12 bytes = 4 pixels x 3 channels
+    const int cr = rgbOrder ? 4899 : 1868, cb = rgbOrder ? 1868 : 4899;
+    // pixel k: bytes 3k, 3k+1, 3k+2
+    const uint32_t p0 = ((a & 255) * cr + ((a >> 8) & 255) * 9617 + ((a >> 16) & 255) * cb + 8192) >> 14;
+    const uint32_t p1 = ((a >> 24) * cr + (b & 255) * 9617 + ((b >> 8) & 255) * cb + 8192) >> 14;
+    const uint32_t p2 = (((b >> 16) & 255) * cr + (b >> 24) * 9617 + (c & 255) * cb + 8192) >> 14;
+    const uint32_t p3 = (((c >> 8) & 255) * cr + ((c >> 16) & 255) * 9617 + (c >> 24) * cb + 8192) >> 14;
+    *(sd_u32_unaligned*)(dst + (size_t)img * dpitch + (size_t)y * dstride + x0) = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
+}

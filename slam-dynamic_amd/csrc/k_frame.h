@@ -264,6 +264,43 @@ __global__ void __launch_bounds__(256) k_grid_cells(const sd_keypoint* __restric
     cellOf[(size_t)img * cap + i] = (short)(in ? px * SD_GRID_ROWS + py : -1);
 }
 
+// The device form of mGrid[64][48]: keypoint indices sorted by (cell, index) + the start of every cell
+// in that order (cellStart[3072] = number of in-grid keypoints).  One workgroup per image, bitonic sort in LDS.
+#define SD_GRID_CELLS (SD_GRID_COLS * SD_GRID_ROWS)
+__global__ void __launch_bounds__(256) k_grid_sort(const short* __restrict__ cellOf, const int* __restrict__ count,
+                                                   unsigned short* __restrict__ sortedIdx,
+                                                   unsigned short* __restrict__ cellStart, int cap, int sortN)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* keys = (uint32_t*)smem;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int N = count[img];
+    for (int i = tid; i < sortN; i += 256) {
+        const int cell = i < N ? cellOf[(size_t)img * cap + i] : -1;
+        keys[i] = cell >= 0 ? (((uint32_t)cell << 16) | (uint32_t)i) : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (int k = 2; k <= sortN; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < sortN; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint32_t a = keys[i], b = keys[ixj];
+                    const bool asc = ((i & k) == 0);
+                    if (asc ? (a > b) : (a < b)) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < N; i += 256) sortedIdx[(size_t)img * cap + i] = (unsigned short)(keys[i] & 0xFFFFu);
+    for (int c = tid; c <= SD_GRID_CELLS; c += 256) {
+        const uint32_t target = (uint32_t)c << 16;
+        int lo = 0, hi = sortN;                      // lower_bound
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < target) lo = mid + 1; else hi = mid; }
+        cellStart[(size_t)img * (SD_GRID_CELLS + 8) + c] = (unsigned short)lo;
+    }
+}
+
 __device__ __forceinline__ void sd_mat3_mul_add(const float* __restrict__ T /*row-major 4x4*/, float x, float y, float z,
                                                 float& ox, float& oy, float& oz)
 {
@@ -302,7 +339,8 @@ __global__ void __launch_bounds__(256) k_unproject(const sd_keypoint* __restrict
 // distance <= TH_HIGH sorted by (distance, visiting order).  No assignment state is touched here.
 __global__ void __launch_bounds__(256) k_proj_candidates(
     const sd_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc, const float* __restrict__ uRight,
-    const int* __restrict__ count, const short* __restrict__ cellOf, const float* __restrict__ xw,
+    const int* __restrict__ count, const short* __restrict__ cellOf, const unsigned short* __restrict__ sortedIdx,
+    const unsigned short* __restrict__ cellStart, const float* __restrict__ xw,
     const uint8_t* __restrict__ flags, const uint8_t* __restrict__ dmp, const float* __restrict__ Tcw,
     const float* __restrict__ Tlw, unsigned short* __restrict__ cand, uint8_t* __restrict__ ncand,
     int* __restrict__ errFlag, const SdDevPlan* __restrict__ PP, SdCamera cam, float th, int bMono,
@@ -365,14 +403,17 @@ __global__ void __launch_bounds__(256) k_proj_candidates(
             const float* urC = uRight + (size_t)imgC * cap;
             const uint8_t* dC = desc + (size_t)imgC * cap * 32;
             const float ur = u - cam.mbf * invzc;
-            for (int base = 0; base < Nc; base += 64) {
-                const int i2 = base + lane;
-                bool hit = false;
-                unsigned long long key = 0;
-                if (i2 < Nc) {
-                    const int cell = cellC[i2];
-                    const int cx = cell / SD_GRID_ROWS, cy = cell - cx * SD_GRID_ROWS;
-                    if (cell >= 0 && cx >= nMinCellX && cx <= nMaxCellX && cy >= nMinCellY && cy <= nMaxCellY) {
+            const unsigned short* sorted = sortedIdx + (size_t)imgC * cap;
+            const unsigned short* cs = cellStart + (size_t)imgC * (SD_GRID_CELLS + 8);
+            // GetFeaturesInArea visits cells ix-major / iy-minor: cells (ix, minY..maxY) are one contiguous run
+            for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+                const int s0 = cs[ix * SD_GRID_ROWS + nMinCellY], e0 = cs[ix * SD_GRID_ROWS + nMaxCellY + 1];
+                for (int base = s0; base < e0; base += 64) {
+                    const int p = base + lane;
+                    bool hit = false;
+                    unsigned long long key = 0;
+                    if (p < e0) {
+                        const int i2 = sorted[p];
                         const sd_keypoint k = kC[i2];
                         bool lv = true;
                         if (bCheckLevels) {
@@ -389,18 +430,18 @@ __global__ void __launch_bounds__(256) k_proj_candidates(
                                 const int dist = sd_hamming256(l0, l1, dr[0], dr[1]);
                                 if (dist <= SD_TH_HIGH) {
                                     hit = true;
-                                    key = ((unsigned long long)dist << 32) | ((unsigned long long)cell << 16) | (unsigned)i2;
+                                    key = ((unsigned long long)dist << 32) | ((unsigned long long)cellC[i2] << 16) | (unsigned)i2;
                                 }
                             }
                         }
                     }
+                    const unsigned long long m = __ballot(hit);
+                    if (hit) {
+                        const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+                        if (pos < SD_PROJ_K) s_keys[wv][pos] = key;
+                    }
+                    n += __popcll(m);
                 }
-                const unsigned long long m = __ballot(hit);
-                if (hit) {
-                    const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-                    if (pos < SD_PROJ_K) s_keys[wv][pos] = key;
-                }
-                n += __popcll(m);
             }
         }
     }

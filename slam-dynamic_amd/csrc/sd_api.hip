@@ -9,6 +9,7 @@
 #include <vector>
 #include "k_extract.h"
 #include "k_frame.h"
+#include "k_fast.h"
 
 static thread_local std::string g_err;
 static int set_err(int code, const std::string& msg) { g_err = msg; return code; }
@@ -63,6 +64,9 @@ struct sd_batch {
     float* d_depth = nullptr;
     int* d_sad = nullptr;
     short* d_cellOf = nullptr;      // grid cell of every keypoint
+    unsigned short* d_sortedIdx = nullptr;   // keypoint indices sorted by (cell, index)
+    unsigned short* d_cellStart = nullptr;   // [maxImages][3072 + 8]
+    int gridSortN = 0;
     float* d_xw = nullptr;          // map-point world positions [maxImages][cap][3]
     uint8_t* d_flags = nullptr;     // bit0: has map point (not outlier); bit1: Observations() > 0
     unsigned short* d_pcand = nullptr;
@@ -137,6 +141,7 @@ int sd_extractor_set_blur_taps(sd_extractor* ex, const uint16_t taps[7])
     unsigned sum = 0;
     for (int i = 0; i < 7; i++) sum += taps[i];
     if (sum > 257) return set_err(SD_ERR_INVALID, "blur taps must sum to <= 257 (8.8 fixed point)");
+    for (int i = 0; i < 7; i++) if (taps[i] > 255) return set_err(SD_ERR_INVALID, "each blur tap must be <= 255");
     memcpy(ex->prm.blurTaps, taps, 14);
     return SD_OK;
 }
@@ -179,7 +184,7 @@ static void batch_free(sd_batch* b)
     void* ptrs[] = {b->d_plan, b->d_cells, b->d_tabs, b->d_pyr, b->d_blur, b->d_cellList, b->d_cellCount, b->d_cand,
                     b->d_nodeOf, b->d_lvlCount, b->d_candCount, b->d_lvlKp, b->d_rot, b->d_kp, b->d_desc, b->d_count,
                     b->d_err, b->d_uright, b->d_depth, b->d_sad, b->d_stage, b->d_cellOf, b->d_xw, b->d_flags,
-                    b->d_pcand, b->d_pncand, b->d_match, b->d_pairs, b->d_npairs, b->d_nmatch, b->d_pose, b->d_pairIdx};
+                    b->d_pcand, b->d_pncand, b->d_match, b->d_pairs, b->d_npairs, b->d_nmatch, b->d_pose, b->d_pairIdx, b->d_sortedIdx, b->d_cellStart};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& r : b->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : b->pool) (void)hipEventDestroy(e);
@@ -213,16 +218,16 @@ int sd_batch_create(sd_batch** out, sd_extractor* ex, int width, int height, int
     D.pyrImageBytes = P.pyrImageBytes; D.blurImageBytes = P.blurImageBytes;
     for (int i = 0; i < 16; i++) D.umax[i] = ex->prm.umax[i];
     for (int i = 0; i < 7; i++) D.taps[i] = ex->prm.blurTaps[i];
-    // quadtree LDS sizing
+    // quadtree LDS sizing: list capacity L (quota + 3, the initial nodes, or the cell count of a level)
     int MN = 0;
     for (int l = 0; l < P.nlevels; l++) {
-        MN = std::max(MN, P.lv[l].maxNodes);
+        MN = std::max(MN, P.lv[l].kpCap + 8);
         MN = std::max(MN, P.lv[l].nCells + 16);
     }
     MN = (MN + 7) & ~7;
     int sortP = 1;
     while (sortP < MN) sortP <<= 1;
-    size_t lds = (size_t)sortP * 8 + (size_t)MN * (8 + 8 + 4 * 6 + 2 * 3) + 64;
+    size_t lds = (size_t)sortP * 8 + (size_t)MN * (8 + 8 + 4 * 4 + 16 * 2 + 2 * 3) + 64;
     if (lds > 160 * 1024 - 256 || MN > 30000)
         { delete b; return set_err(SD_ERR_UNSUPPORTED, "per-level feature quota too large for the LDS quadtree (nfeatures too high)"); }
     b->qtMN = MN; b->qtSortP = sortP; b->qtLds = lds;
@@ -258,6 +263,9 @@ int sd_batch_create(sd_batch** out, sd_extractor* ex, int width, int height, int
     ALLOC(b->d_depth, nI * P.kpCap * 4);
     ALLOC(b->d_sad, nI * P.kpCap * 4);
     ALLOC(b->d_cellOf, nI * P.kpCap * 2);
+    ALLOC(b->d_sortedIdx, nI * P.kpCap * 2);
+    ALLOC(b->d_cellStart, nI * (SD_GRID_CELLS + 8) * 2);
+    { int sn = 1; while (sn < P.kpCap) sn <<= 1; b->gridSortN = sn; }
     ALLOC(b->d_xw, nI * P.kpCap * 12);
     ALLOC(b->d_flags, nI * P.kpCap);
     ALLOC(b->d_pcand, nI * P.kpCap * SD_PROJ_K * 2);
@@ -374,7 +382,10 @@ int sd_batch_extract_device(sd_batch* b, const uint8_t* d_gray, size_t stride, s
     {
         ProfScope ps(b, s, K_FAST);
         dim3 grd((unsigned)P.cells.size(), n_images);
-        hipLaunchKernelGGL(k_fast_cells, grd, dim3(256), 0, s, b->d_pyr, b->d_cells, b->d_cellList, b->d_cellCount, b->d_plan);
+        if (P.maxWin <= SD_FS_MAXWIN)
+            hipLaunchKernelGGL(k_fast_cells_staged, grd, dim3(256), 0, s, b->d_pyr, b->d_cells, b->d_cellList, b->d_cellCount, b->d_plan);
+        else
+            hipLaunchKernelGGL(k_fast_cells, grd, dim3(256), 0, s, b->d_pyr, b->d_cells, b->d_cellList, b->d_cellCount, b->d_plan);
     }
     LAUNCH_CHECK("k_fast_cells");
     {
@@ -386,8 +397,8 @@ int sd_batch_extract_device(sd_batch* b, const uint8_t* d_gray, size_t stride, s
     LAUNCH_CHECK("k_quadtree");
     {
         ProfScope ps(b, s, K_BLUR);
-        dim3 grd((P.lv[0].W + 63) / 64, (P.lv[0].H + 15) / 16, n_images * nl);
-        hipLaunchKernelGGL(k_blur, grd, dim3(256), 0, s, b->d_pyr, b->d_blur, b->d_plan);
+        dim3 grd((P.lv[0].W + 127) / 128, (P.lv[0].H + 15) / 16, n_images * nl);
+        hipLaunchKernelGGL(k_blur_wide, grd, dim3(256), 0, s, b->d_pyr, b->d_blur, b->d_plan);
     }
     LAUNCH_CHECK("k_blur");
     {
@@ -638,8 +649,12 @@ int sd_cvt_gray_device(const uint8_t* d_src, int width, int height, size_t src_s
     if (!d_src || !d_dst || width < 1 || height < 1 || n_images < 0 || (channels != 3 && channels != 4)) return SD_ERR_INVALID;
     if (n_images == 0) return SD_OK;
     dim3 blk(64, 4), grd(((width + 3) / 4 + 63) / 64, (height + 3) / 4, n_images);
-    hipLaunchKernelGGL(k_cvt_gray, grd, blk, 0, (hipStream_t)stream, d_src, width, height, src_stride, src_pitch, channels,
-                       rgb_order, d_dst, dst_stride, dst_pitch);
+    if (channels == 3)
+        hipLaunchKernelGGL(k_cvt_gray3_wide, grd, blk, 0, (hipStream_t)stream, d_src, width, height, src_stride, src_pitch,
+                           rgb_order, d_dst, dst_stride, dst_pitch);
+    else
+        hipLaunchKernelGGL(k_cvt_gray, grd, blk, 0, (hipStream_t)stream, d_src, width, height, src_stride, src_pitch, channels,
+                           rgb_order, d_dst, dst_stride, dst_pitch);
     LAUNCH_CHECK("k_cvt_gray");
     return SD_OK;
 }
@@ -702,6 +717,13 @@ int sd_batch_assign_grid(sd_batch* b, int n_images, const sd_camera* cam, void* 
         hipLaunchKernelGGL(k_grid_cells, grd, dim3(256), 0, s, b->d_kp, b->d_count, b->d_cellOf, to_cam(cam), b->plan.kpCap);
     }
     LAUNCH_CHECK("k_grid_cells");
+    if ((size_t)b->gridSortN * 4 > 64 * 1024) return set_err(SD_ERR_UNSUPPORTED, "too many keypoints per image for the grid sort");
+    {
+        ProfScope ps(b, s, K_GRID);
+        hipLaunchKernelGGL(k_grid_sort, dim3(n_images), dim3(256), (size_t)b->gridSortN * 4, s, b->d_cellOf, b->d_count, b->d_sortedIdx,
+                           b->d_cellStart, b->plan.kpCap, b->gridSortN);
+    }
+    LAUNCH_CHECK("k_grid_sort");
     return SD_OK;
 }
 
@@ -800,7 +822,8 @@ int sd_batch_search_by_projection(sd_batch* b, int n_pairs, const int32_t* cur_i
     {
         ProfScope ps(b, s, K_PROJ_A);
         dim3 grd((cap + 3) / 4, n_pairs);
-        hipLaunchKernelGGL(k_proj_candidates, grd, dim3(256), 0, s, b->d_kp, b->d_desc, b->d_uright, b->d_count, b->d_cellOf, b->d_xw,
+        hipLaunchKernelGGL(k_proj_candidates, grd, dim3(256), 0, s, b->d_kp, b->d_desc, b->d_uright, b->d_count, b->d_cellOf, b->d_sortedIdx,
+                           b->d_cellStart, b->d_xw,
                            b->d_flags, d_mp_desc ? d_mp_desc : b->d_desc, dTc, dTl, b->d_pcand, b->d_pncand, b->d_err, b->d_plan,
                            to_cam(cam), th, bMono, b->d_pairIdx);
     }
@@ -826,8 +849,10 @@ int sd_batch_copy_frame(sd_batch* b, int src, int dst, void* stream_)
     const size_t cap = b->plan.kpCap;
 #define CP(ptr, elemBytes) HIPCHK(hipMemcpyAsync((char*)(ptr) + dst * cap * (elemBytes), (const char*)(ptr) + src * cap * (elemBytes), cap * (elemBytes), hipMemcpyDeviceToDevice, s))
     CP(b->d_kp, sizeof(sd_keypoint)); CP(b->d_desc, 32); CP(b->d_uright, 4); CP(b->d_depth, 4); CP(b->d_sad, 4);
-    CP(b->d_cellOf, 2); CP(b->d_xw, 12); CP(b->d_flags, 1);
+    CP(b->d_cellOf, 2); CP(b->d_xw, 12); CP(b->d_flags, 1); CP(b->d_sortedIdx, 2);
 #undef CP
+    HIPCHK(hipMemcpyAsync(b->d_cellStart + (size_t)dst * (SD_GRID_CELLS + 8), b->d_cellStart + (size_t)src * (SD_GRID_CELLS + 8),
+                          (size_t)(SD_GRID_CELLS + 8) * 2, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(b->d_count + dst, b->d_count + src, 4, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(b->d_lvlCount + (size_t)dst * b->plan.nlevels, b->d_lvlCount + (size_t)src * b->plan.nlevels,
                           (size_t)b->plan.nlevels * 4, hipMemcpyDeviceToDevice, s));

@@ -101,6 +101,7 @@ struct SdPlan {
     int kpCapLevels = 0;     // sum of kpCap over levels
     int kpCap = 0;           // capacity of the final per-image keypoint array
     int maxNodesAll = 0;
+    int maxWin = 0;          // largest FAST window side over all cells
     std::string error;
 };
 
@@ -159,6 +160,8 @@ static inline bool sd_plan_build(SdPlan& P, const SdParams& prm, int W, int H)
                 int sw = c.x1 - c.x0 - 6, sh = c.y1 - c.y0 - 6;   // scanned area (FAST skips a 3-px frame)
                 c.cap = (sw > 0 && sh > 0) ? ((sw + 1) / 2) * ((sh + 1) / 2) : 0;
                 c.listOffset = listOff;
+                if (c.x1 - c.x0 > P.maxWin) P.maxWin = c.x1 - c.x0;
+                if (c.y1 - c.y0 > P.maxWin) P.maxWin = c.y1 - c.y0;
                 listOff += c.cap;
                 P.cells.push_back(c);
                 cellTotal++;
