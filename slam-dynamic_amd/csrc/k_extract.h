@@ -590,14 +590,19 @@ __global__ void __launch_bounds__(256) k_orient(const uint8_t* __restrict__ pyr,
     const int u = l32 - SD_HALF_PATCH;
     int m10 = 0, m01 = 0;
     if (l32 < 31) {
+        // umax of ORBextractor.cc:452-470 depends only on HALF_PATCH_SIZE = 15 (checked against the plan on the
+        // host); a compile-time table lets all 31 row loads be issued back to back instead of one per L2 round trip.
+        constexpr int kUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
         const int au = u < 0 ? -u : u;
-        for (int vv = -SD_HALF_PATCH; vv <= SD_HALF_PATCH; vv++) {
-            const int d = P.umax[vv < 0 ? -vv : vv];
-            if (au <= d) {
-                const int val = center[(ptrdiff_t)vv * g.stride + u];
-                m10 += u * val;
-                m01 += vv * val;
-            }
+        int vals[31];
+#pragma unroll
+        for (int r = 0; r < 31; r++) vals[r] = center[(ptrdiff_t)(r - SD_HALF_PATCH) * g.stride + u];
+#pragma unroll
+        for (int r = 0; r < 31; r++) {
+            const int vv = r - SD_HALF_PATCH;
+            const int val = au <= kUmax[vv < 0 ? -vv : vv] ? vals[r] : 0;
+            m10 += u * val;
+            m01 += vv * val;
         }
     }
 #pragma unroll
@@ -661,15 +666,22 @@ __global__ void __launch_bounds__(256) k_blur(const uint8_t* __restrict__ pyr, u
 }
 
 // ------------------------------------------------------------------ steered rBRIEF
-// One wave per keypoint: lane i evaluates pairs i, i+64, i+128, i+192; the four 64-bit wave
-// ballots ARE the descriptor (bit k of the descriptor = pair k, LSB first within each byte).
+// One wave per keypoint.  The 37x37 neighbourhood of the blurred plane (pattern radius <= 18.4 px after
+// rotation) is staged in LDS with dword loads, 10 per row; the 512 taps are then LDS byte reads.  Lane i
+// evaluates pairs i, i+64, i+128, i+192; the four 64-bit wave ballots ARE the descriptor (bit k of the
+// descriptor = pair k, LSB first within each byte).
+#define SD_DP_W 40    // staged bytes per patch row
+#define SD_DP_R 18    // patch radius
+typedef uint32_t __attribute__((aligned(1))) sd_u32_ua;
 __global__ void __launch_bounds__(256) k_describe(const uint8_t* __restrict__ blur, const uint32_t* __restrict__ lvlKp,
                                                   const int* __restrict__ lvlCount, const float2* __restrict__ rot,
                                                   uint8_t* __restrict__ descOut, const SdDevPlan* __restrict__ PP)
 {
     const SdDevPlan& P = *PP;
+    __shared__ __align__(16) uint8_t patch[4][37 * SD_DP_W];
     const int img = blockIdx.y;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wv = threadIdx.x >> 6;
+    const int slot = blockIdx.x * 4 + wv;
     const int lane = threadIdx.x & 63;
     if (slot >= P.kpCapLevels) return;
     int level = 0;
@@ -687,7 +699,19 @@ __global__ void __launch_bounds__(256) k_describe(const uint8_t* __restrict__ bl
     const float2 ab = rot[(size_t)img * P.kpCapLevels + slot];
     const float a = ab.x, b = ab.y;
     const int step = g.blurStride;
-    const uint8_t* center = blur + (size_t)img * P.blurImageBytes + g.blurOffset + (size_t)py * step + px;
+    const uint8_t* corner = blur + (size_t)img * P.blurImageBytes + g.blurOffset + (size_t)(py - SD_DP_R) * step + (px - SD_DP_R);
+    uint32_t* pw = (uint32_t*)patch[wv];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int i = lane + 64 * k;
+        if (i < 370) {
+            const int r = i / 10, c = i - r * 10;
+            pw[i] = *(const sd_u32_ua*)(corner + (size_t)r * step + 4 * c);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave's LDS writes are done
+    const uint8_t* center = patch[wv] + SD_DP_R * SD_DP_W + SD_DP_R;
     unsigned long long words[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -696,8 +720,8 @@ __global__ void __launch_bounds__(256) k_describe(const uint8_t* __restrict__ bl
         const float x1 = (float)c_pattern[pi + 2], y1 = (float)c_pattern[pi + 3];
         const int iy0 = __float2int_rn(x0 * b + y0 * a), ix0 = __float2int_rn(x0 * a - y0 * b);
         const int iy1 = __float2int_rn(x1 * b + y1 * a), ix1 = __float2int_rn(x1 * a - y1 * b);
-        const int t0 = center[iy0 * step + ix0];
-        const int t1 = center[iy1 * step + ix1];
+        const int t0 = center[iy0 * SD_DP_W + ix0];
+        const int t1 = center[iy1 * SD_DP_W + ix1];
         words[r] = __ballot(t0 < t1);
     }
     if (lane < 4) {

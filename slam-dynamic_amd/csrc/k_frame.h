@@ -264,41 +264,60 @@ __global__ void __launch_bounds__(256) k_grid_cells(const sd_keypoint* __restric
     cellOf[(size_t)img * cap + i] = (short)(in ? px * SD_GRID_ROWS + py : -1);
 }
 
-// The device form of mGrid[64][48]: keypoint indices sorted by (cell, index) + the start of every cell
-// in that order (cellStart[3072] = number of in-grid keypoints).  One workgroup per image, bitonic sort in LDS.
+// The device form of mGrid[64][48]: keypoint indices grouped by cell, ascending index inside a cell (the
+// reference's push_back order), + the start of every cell (cellStart[3072] = number of in-grid keypoints).
+// One workgroup per image: LDS histogram -> exclusive scan -> scatter -> per-cell insertion sort (cells hold
+// ~0.7 keypoints on average, so the sort is a handful of compares).
 #define SD_GRID_CELLS (SD_GRID_COLS * SD_GRID_ROWS)
 __global__ void __launch_bounds__(256) k_grid_sort(const short* __restrict__ cellOf, const int* __restrict__ count,
                                                    unsigned short* __restrict__ sortedIdx,
-                                                   unsigned short* __restrict__ cellStart, int cap, int sortN)
+                                                   unsigned short* __restrict__ cellStart, int cap, int /*sortN*/)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t* keys = (uint32_t*)smem;
-    const int img = blockIdx.x, tid = threadIdx.x;
+    int* start = (int*)smem;                                   // [3072 + 1]
+    int* fill = start + SD_GRID_CELLS + 8;                     // [3072]
+    unsigned short* out = (unsigned short*)(fill + SD_GRID_CELLS);   // [cap]
+    __shared__ int s_wsum[4];
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int N = count[img];
-    for (int i = tid; i < sortN; i += 256) {
-        const int cell = i < N ? cellOf[(size_t)img * cap + i] : -1;
-        keys[i] = cell >= 0 ? (((uint32_t)cell << 16) | (uint32_t)i) : 0xFFFFFFFFu;
+    const short* cells = cellOf + (size_t)img * cap;
+    for (int c = tid; c < SD_GRID_CELLS; c += 256) { start[c] = 0; fill[c] = 0; }
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) { const int c = cells[i]; if (c >= 0) atomicAdd(&start[c], 1); }
+    __syncthreads();
+    // exclusive scan of 3072 counts: 12 consecutive cells per thread
+    int local[12], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) { local[k] = start[tid * 12 + k]; sum += local[k]; }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < wv; w++) run += s_wsum[w];
+    const int total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+#pragma unroll
+    for (int k = 0; k < 12; k++) { start[tid * 12 + k] = run; run += local[k]; }
+    if (tid == 0) start[SD_GRID_CELLS] = total;
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) {
+        const int c = cells[i];
+        if (c >= 0) out[start[c] + atomicAdd(&fill[c], 1)] = (unsigned short)i;
     }
     __syncthreads();
-    for (int k = 2; k <= sortN; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < sortN; i += 256) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const uint32_t a = keys[i], b = keys[ixj];
-                    const bool asc = ((i & k) == 0);
-                    if (asc ? (a > b) : (a < b)) { keys[i] = b; keys[ixj] = a; }
-                }
-            }
-            __syncthreads();
+    for (int c = tid; c < SD_GRID_CELLS; c += 256) {            // insertion sort inside each cell
+        const int s0 = start[c], e0 = start[c + 1];
+        for (int i = s0 + 1; i < e0; i++) {
+            const unsigned short v = out[i];
+            int j = i - 1;
+            while (j >= s0 && out[j] > v) { out[j + 1] = out[j]; j--; }
+            out[j + 1] = v;
         }
-    for (int i = tid; i < N; i += 256) sortedIdx[(size_t)img * cap + i] = (unsigned short)(keys[i] & 0xFFFFu);
-    for (int c = tid; c <= SD_GRID_CELLS; c += 256) {
-        const uint32_t target = (uint32_t)c << 16;
-        int lo = 0, hi = sortN;                      // lower_bound
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < target) lo = mid + 1; else hi = mid; }
-        cellStart[(size_t)img * (SD_GRID_CELLS + 8) + c] = (unsigned short)lo;
     }
+    __syncthreads();
+    for (int i = tid; i < total; i += 256) sortedIdx[(size_t)img * cap + i] = out[i];
+    for (int c = tid; c <= SD_GRID_CELLS; c += 256) cellStart[(size_t)img * (SD_GRID_CELLS + 8) + c] = (unsigned short)start[c];
 }
 
 __device__ __forceinline__ void sd_mat3_mul_add(const float* __restrict__ T /*row-major 4x4*/, float x, float y, float z,
@@ -405,43 +424,61 @@ __global__ void __launch_bounds__(256) k_proj_candidates(
             const float ur = u - cam.mbf * invzc;
             const unsigned short* sorted = sortedIdx + (size_t)imgC * cap;
             const unsigned short* cs = cellStart + (size_t)imgC * (SD_GRID_CELLS + 8);
-            // GetFeaturesInArea visits cells ix-major / iy-minor: cells (ix, minY..maxY) are one contiguous run
-            for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
-                const int s0 = cs[ix * SD_GRID_ROWS + nMinCellY], e0 = cs[ix * SD_GRID_ROWS + nMaxCellY + 1];
-                for (int base = s0; base < e0; base += 64) {
-                    const int p = base + lane;
-                    bool hit = false;
-                    unsigned long long key = 0;
-                    if (p < e0) {
-                        const int i2 = sorted[p];
-                        const sd_keypoint k = kC[i2];
-                        bool lv = true;
-                        if (bCheckLevels) {
-                            if (k.octave < minLevel) lv = false;
-                            if (maxLevel >= 0 && k.octave > maxLevel) lv = false;
-                        }
-                        const float distx = k.x - u, disty = k.y - v;
-                        if (lv && fabsf(distx) < radius && fabsf(disty) < radius) {
-                            bool rOk = true;
-                            const float r2 = urC[i2];
-                            if (r2 > 0) { const float er = fabsf(ur - r2); if (er > radius) rOk = false; }
-                            if (rOk) {
-                                const uint4* dr = (const uint4*)(dC + (size_t)i2 * 32);
-                                const int dist = sd_hamming256(l0, l1, dr[0], dr[1]);
-                                if (dist <= SD_TH_HIGH) {
-                                    hit = true;
-                                    key = ((unsigned long long)dist << 32) | ((unsigned long long)cellC[i2] << 16) | (unsigned)i2;
-                                }
+            // GetFeaturesInArea visits cells ix-major / iy-minor: cells (ix, minY..maxY) are one contiguous run of
+            // the sorted list.  Lane j < nCols fetches the run of column ix = nMinCellX + j; a wave prefix sum
+            // turns the <= 64 runs into one flat range so that 64 candidates are tested per step.
+            const int nColsA = nMaxCellX - nMinCellX + 1;
+            int runS = 0, runN = 0;
+            if (lane < nColsA) {
+                const int ix = nMinCellX + lane;
+                runS = cs[ix * SD_GRID_ROWS + nMinCellY];
+                runN = cs[ix * SD_GRID_ROWS + nMaxCellY + 1] - runS;
+            }
+            int incl = runN;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            const int total = __shfl(incl, 63, 64);
+            const int excl = incl - runN;
+            for (int base = 0; base < total; base += 64) {
+                const int t = base + lane;
+                bool hit = false;
+                unsigned long long key = 0;
+                // owner column of flat index t: the last lane whose exclusive prefix is <= t
+                int col = 0;
+                for (int j = 1; j < nColsA; j++) {            // nColsA is wave-uniform and small (window / cell width)
+                    const int ej = __shfl(excl, j, 64);
+                    if (ej <= t) col = j;
+                }
+                const int cS = __shfl(runS, col, 64), cE = __shfl(excl, col, 64);
+                if (t < total) {
+                    const int i2 = sorted[cS + (t - cE)];
+                    const sd_keypoint k = kC[i2];
+                    bool lv = true;
+                    if (bCheckLevels) {
+                        if (k.octave < minLevel) lv = false;
+                        if (maxLevel >= 0 && k.octave > maxLevel) lv = false;
+                    }
+                    const float distx = k.x - u, disty = k.y - v;
+                    if (lv && fabsf(distx) < radius && fabsf(disty) < radius) {
+                        bool rOk = true;
+                        const float r2 = urC[i2];
+                        if (r2 > 0) { const float er = fabsf(ur - r2); if (er > radius) rOk = false; }
+                        if (rOk) {
+                            const uint4* dr = (const uint4*)(dC + (size_t)i2 * 32);
+                            const int dist = sd_hamming256(l0, l1, dr[0], dr[1]);
+                            if (dist <= SD_TH_HIGH) {
+                                hit = true;
+                                key = ((unsigned long long)dist << 32) | ((unsigned long long)cellC[i2] << 16) | (unsigned)i2;
                             }
                         }
                     }
-                    const unsigned long long m = __ballot(hit);
-                    if (hit) {
-                        const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-                        if (pos < SD_PROJ_K) s_keys[wv][pos] = key;
-                    }
-                    n += __popcll(m);
                 }
+                const unsigned long long m = __ballot(hit);
+                if (hit) {
+                    const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < SD_PROJ_K) s_keys[wv][pos] = key;
+                }
+                n += __popcll(m);
             }
         }
     }

@@ -717,10 +717,11 @@ int sd_batch_assign_grid(sd_batch* b, int n_images, const sd_camera* cam, void* 
         hipLaunchKernelGGL(k_grid_cells, grd, dim3(256), 0, s, b->d_kp, b->d_count, b->d_cellOf, to_cam(cam), b->plan.kpCap);
     }
     LAUNCH_CHECK("k_grid_cells");
-    if ((size_t)b->gridSortN * 4 > 64 * 1024) return set_err(SD_ERR_UNSUPPORTED, "too many keypoints per image for the grid sort");
+    const size_t gridLds = (size_t)(SD_GRID_CELLS + 8) * 4 + (size_t)SD_GRID_CELLS * 4 + (size_t)b->plan.kpCap * 2 + 16;
+    if (gridLds > 64 * 1024) return set_err(SD_ERR_UNSUPPORTED, "too many keypoints per image for the grid sort");
     {
         ProfScope ps(b, s, K_GRID);
-        hipLaunchKernelGGL(k_grid_sort, dim3(n_images), dim3(256), (size_t)b->gridSortN * 4, s, b->d_cellOf, b->d_count, b->d_sortedIdx,
+        hipLaunchKernelGGL(k_grid_sort, dim3(n_images), dim3(256), gridLds, s, b->d_cellOf, b->d_count, b->d_sortedIdx,
                            b->d_cellStart, b->plan.kpCap, b->gridSortN);
     }
     LAUNCH_CHECK("k_grid_sort");
