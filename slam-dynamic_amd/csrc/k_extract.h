@@ -45,7 +45,11 @@ __device__ __forceinline__ int sd_reflect101(int p, int len)
 
 // ------------------------------------------------------------------ pyramid, level 0
 // Padded copy of the gray input with BORDER_REFLECT_101 (ORBextractor.cc:1127-1128).
-// Thread = 4 consecutive padded pixels (one aligned u32 store); block 64x4.
+// Thread = 4 consecutive padded pixels (one aligned u32 store); block 64x4.  Groups that lie inside the
+// interior columns are one (unaligned) dword load; only the 19-px frame takes the per-byte reflect path.
+typedef uint32_t __attribute__((aligned(1))) sd_u32_una;
+typedef unsigned long long __attribute__((aligned(1))) sd_u64_una;
+
 __global__ void __launch_bounds__(256) k_pyr_level0(const uint8_t* __restrict__ gray, size_t gstride, size_t gpitch,
                                                     uint8_t* __restrict__ pyr, const SdDevPlan* __restrict__ PP)
 {
@@ -60,11 +64,15 @@ __global__ void __launch_bounds__(256) k_pyr_level0(const uint8_t* __restrict__ 
     const int sy = sd_reflect101(Yp - SD_EDGE, g.H);
     const uint8_t* srow = gray + (size_t)img * gpitch + (size_t)sy * gstride;
     uint32_t pack = 0;
+    if (X0 >= 0 && X0 + 3 < g.W) {
+        pack = *(const sd_u32_una*)(srow + X0);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        int X = X0 + k;
-        X = X < -SD_EDGE ? -SD_EDGE : (X > g.W + SD_EDGE - 1 ? g.W + SD_EDGE - 1 : X);
-        pack |= (uint32_t)srow[sd_reflect101(X, g.W)] << (8 * k);
+        for (int k = 0; k < 4; k++) {
+            int X = X0 + k;
+            X = X < -SD_EDGE ? -SD_EDGE : (X > g.W + SD_EDGE - 1 ? g.W + SD_EDGE - 1 : X);
+            pack |= (uint32_t)srow[sd_reflect101(X, g.W)] << (8 * k);
+        }
     }
     uint8_t* drow = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)Yp * g.stride;
     *(uint32_t*)(drow + SD_XOFF + X0) = pack;
@@ -73,8 +81,18 @@ __global__ void __launch_bounds__(256) k_pyr_level0(const uint8_t* __restrict__ 
 // ------------------------------------------------------------------ pyramid, level >= 1
 // cv::resize(INTER_LINEAR) of level-1's interior + REFLECT_101 border in one pass: every padded
 // pixel is the resized value at its reflected interior position (no second pass, no dependency
-// between threads).  Coefficient tables come from the host plan (sd_plan.h).
-__global__ void __launch_bounds__(256) k_pyr_level(uint8_t* __restrict__ pyr, const int16_t* __restrict__ tabs,
+// between threads).  Coefficient tables come from the host plan (sd_plan.h) as 8-byte entries.
+// Interior groups: the 4 columns' entries are two 16-B loads, the <= 7 source bytes per row one 8-B load.
+__device__ __forceinline__ int sd_lerp_px(int s00, int s01, int s10, int s11, int a0, int a1, int b0, int b1)
+{
+    // all operands are < 2^16 and products < 2^27: full-rate 24-bit multiplies instead of v_mul_lo_u32
+    const int h0 = __mul24(s00, a0) + __mul24(s01, a1);
+    const int h1 = __mul24(s10, a0) + __mul24(s11, a1);
+    return (((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2) & 255;
+}
+
+#define SD_PYR_ROWS 4     // padded rows per thread: keeps 4x the loads in flight per wave (the kernel is latency-bound)
+__global__ void __launch_bounds__(256) k_pyr_level(uint8_t* __restrict__ pyr, const short4* __restrict__ tabs,
                                                    const SdDevPlan* __restrict__ PP, int level)
 {
     const SdDevPlan& P = *PP;
@@ -82,35 +100,70 @@ __global__ void __launch_bounds__(256) k_pyr_level(uint8_t* __restrict__ pyr, co
     const SdLevel& s = P.lv[level - 1];
     const int img = blockIdx.z;
     const int gx = blockIdx.x * 64 + threadIdx.x;
-    const int Yp = blockIdx.y * 4 + threadIdx.y;
-    if (Yp >= g.H + 2 * SD_EDGE) return;
     const int X0 = -20 + 4 * gx;
     if (X0 > g.W + SD_EDGE - 1) return;
-    const int16_t* xo = tabs + g.tabOffset; const int16_t* a0t = xo + g.W; const int16_t* a1t = a0t + g.W;
-    const int16_t* yo = a1t + g.W; const int16_t* b0t = yo + g.H; const int16_t* b1t = b0t + g.H;
-    const int y = sd_reflect101(Yp - SD_EDGE, g.H);
-    const int sy0 = yo[y];
-    const int r0 = min(max(sy0, 0), s.H - 1), r1 = min(max(sy0 + 1, 0), s.H - 1);
-    const int b0 = b0t[y], b1 = b1t[y];
+    const int HP = g.H + 2 * SD_EDGE;
+    const int Yb = blockIdx.y * (4 * SD_PYR_ROWS) + threadIdx.y;      // rows Yb, Yb+4, Yb+8, Yb+12
+    if (Yb >= HP) return;
+    const short4* ct = tabs + g.tabOffset;
+    const short4* rt = ct + g.W;
     const uint8_t* sbase = pyr + (size_t)img * P.pyrImageBytes + s.pyrOffset + (size_t)SD_EDGE * s.stride + SD_XOFF;
-    const uint8_t* S0 = sbase + (size_t)r0 * s.stride;
-    const uint8_t* S1 = sbase + (size_t)r1 * s.stride;
-    uint32_t pack = 0;
+    uint8_t* dbase = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + SD_XOFF + X0;
+    short4 re[SD_PYR_ROWS];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        int X = X0 + k;
-        X = X < -SD_EDGE ? -SD_EDGE : (X > g.W + SD_EDGE - 1 ? g.W + SD_EDGE - 1 : X);
-        const int x = sd_reflect101(X, g.W);
-        const int sx = xo[x];
-        const int sx1 = min(sx + 1, s.W - 1);
-        const int a0 = a0t[x], a1 = a1t[x];
-        const int h0 = S0[sx] * a0 + S0[sx1] * a1;
-        const int h1 = S1[sx] * a0 + S1[sx1] * a1;
-        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-        pack |= (uint32_t)(v & 255) << (8 * k);
+    for (int r = 0; r < SD_PYR_ROWS; r++) re[r] = rt[sd_reflect101(min(Yb + 4 * r, HP - 1) - SD_EDGE, g.H)];
+    if (X0 >= 0 && X0 + 3 < g.W) {
+        const short4 c0 = ct[X0], c1 = ct[X0 + 1], c2 = ct[X0 + 2], c3 = ct[X0 + 3];
+        const int sx0 = c0.x;
+        const int o1 = 8 * (c1.x - sx0), o2 = 8 * (c2.x - sx0), o3 = 8 * (c3.x - sx0);
+        unsigned long long w0[SD_PYR_ROWS], w1[SD_PYR_ROWS];
+#pragma unroll
+        for (int r = 0; r < SD_PYR_ROWS; r++) {
+            const int sy0 = re[r].x;
+            const int r0 = min(max(sy0, 0), s.H - 1), r1 = min(max(sy0 + 1, 0), s.H - 1);
+            // a column at the right edge has a1 == 0, so reading the byte after it (the frame) is harmless
+            w0[r] = *(const sd_u64_una*)(sbase + (size_t)r0 * s.stride + sx0);
+            w1[r] = *(const sd_u64_una*)(sbase + (size_t)r1 * s.stride + sx0);
+        }
+#pragma unroll
+        for (int r = 0; r < SD_PYR_ROWS; r++) {
+            const int Yp = Yb + 4 * r;
+            if (Yp < HP) {
+                const int b0 = re[r].y, b1 = re[r].z;
+                const unsigned long long a = w0[r], b = w1[r];
+                const uint32_t p0 = sd_lerp_px((int)(a & 255), (int)((a >> 8) & 255), (int)(b & 255), (int)((b >> 8) & 255), c0.y, c0.z, b0, b1);
+                const uint32_t p1 = sd_lerp_px((int)((a >> o1) & 255), (int)((a >> (o1 + 8)) & 255), (int)((b >> o1) & 255), (int)((b >> (o1 + 8)) & 255), c1.y, c1.z, b0, b1);
+                const uint32_t p2 = sd_lerp_px((int)((a >> o2) & 255), (int)((a >> (o2 + 8)) & 255), (int)((b >> o2) & 255), (int)((b >> (o2 + 8)) & 255), c2.y, c2.z, b0, b1);
+                const uint32_t p3 = sd_lerp_px((int)((a >> o3) & 255), (int)((a >> (o3 + 8)) & 255), (int)((b >> o3) & 255), (int)((b >> (o3 + 8)) & 255), c3.y, c3.z, b0, b1);
+                *(uint32_t*)(dbase + (size_t)Yp * g.stride) = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
+            }
+        }
+    } else {
+        short4 ce[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int X = X0 + k;
+            X = X < -SD_EDGE ? -SD_EDGE : (X > g.W + SD_EDGE - 1 ? g.W + SD_EDGE - 1 : X);
+            ce[k] = ct[sd_reflect101(X, g.W)];
+        }
+#pragma unroll
+        for (int r = 0; r < SD_PYR_ROWS; r++) {
+            const int Yp = Yb + 4 * r;
+            if (Yp < HP) {
+                const int sy0 = re[r].x, b0 = re[r].y, b1 = re[r].z;
+                const int r0 = min(max(sy0, 0), s.H - 1), r1 = min(max(sy0 + 1, 0), s.H - 1);
+                const uint8_t* S0 = sbase + (size_t)r0 * s.stride;
+                const uint8_t* S1 = sbase + (size_t)r1 * s.stride;
+                uint32_t pack = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int sx = ce[k].x, sx1 = min(sx + 1, s.W - 1);
+                    pack |= (uint32_t)sd_lerp_px(S0[sx], S0[sx1], S1[sx], S1[sx1], ce[k].y, ce[k].z, b0, b1) << (8 * k);
+                }
+                *(uint32_t*)(dbase + (size_t)Yp * g.stride) = pack;
+            }
+        }
     }
-    uint8_t* drow = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)Yp * g.stride;
-    *(uint32_t*)(drow + SD_XOFF + X0) = pack;
 }
 
 // ------------------------------------------------------------------ FAST-9/16 per cell

@@ -375,8 +375,8 @@ int sd_batch_extract_device(sd_batch* b, const uint8_t* d_gray, size_t stride, s
     for (int l = 1; l < nl; l++) {
         ProfScope ps(b, s, K_PYR);
         const SdLevel& g = P.lv[l];
-        dim3 blk(64, 4), grd(((g.W + 39 + 3) / 4 + 63) / 64, (g.H + 2 * SD_EDGE + 3) / 4, n_images);
-        hipLaunchKernelGGL(k_pyr_level, grd, blk, 0, s, b->d_pyr, b->d_tabs, b->d_plan, l);
+        dim3 blk(64, 4), grd(((g.W + 39 + 3) / 4 + 63) / 64, (g.H + 2 * SD_EDGE + 4 * SD_PYR_ROWS - 1) / (4 * SD_PYR_ROWS), n_images);
+        hipLaunchKernelGGL(k_pyr_level, grd, blk, 0, s, b->d_pyr, (const short4*)b->d_tabs, b->d_plan, l);
     }
     LAUNCH_CHECK("k_pyr_level");
     {

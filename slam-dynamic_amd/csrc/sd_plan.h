@@ -93,7 +93,7 @@ struct SdPlan {
     int W = 0, H = 0, nlevels = 0;
     SdLevel lv[SD_MAX_LEVELS];
     std::vector<SdCell> cells;
-    // resize tables for levels >= 1, concatenated: per level [xofs(W) | a0(W) | a1(W) | yofs(H) | b0(H) | b1(H)] as int16
+    // resize tables for levels >= 1, concatenated: per level W column entries {xofs,a0,a1,0} + H row entries {yofs,b0,b1,0}
     std::vector<int16_t> tabs;
     size_t pyrImageBytes = 0, blurImageBytes = 0;
     int cellListCap = 0;     // slots per image in the cell-list array
@@ -187,29 +187,29 @@ static inline bool sd_plan_build(SdPlan& P, const SdParams& prm, int W, int H)
         if (l > 0) {
             const SdLevel& s = P.lv[l - 1];
             const double scale_x = 1. / ((double)g.W / s.W), scale_y = 1. / ((double)g.H / s.H);
+            // layout per level: W entries {xofs, a0, a1, 0} then H entries {yofs, b0, b1, 0}; tabOffset counts ENTRIES (4 x int16)
             size_t base = P.tabs.size();
-            P.tabs.resize(base + 3 * (size_t)g.W + 3 * (size_t)g.H);
-            int16_t* xo = &P.tabs[base]; int16_t* a0 = xo + g.W; int16_t* a1 = a0 + g.W;
-            int16_t* yo = a1 + g.W; int16_t* b0 = yo + g.H; int16_t* b1 = b0 + g.H;
+            P.tabs.resize(base + 4 * ((size_t)g.W + (size_t)g.H));
+            int16_t* ct = &P.tabs[base]; int16_t* rt = ct + 4 * (size_t)g.W;
             for (int dx = 0; dx < g.W; dx++) {
                 float fx = (float)((dx + 0.5) * scale_x - 0.5);
                 int sx = (int)floorf(fx);
                 fx -= sx;
                 if (sx < 0) { fx = 0; sx = 0; }
                 if (sx >= s.W - 1) { fx = 0; sx = s.W - 1; }
-                xo[dx] = (int16_t)sx;
                 float c0 = 1.f - fx, c1 = fx;
-                a0[dx] = (int16_t)sd_cvRoundf(c0 * 2048); a1[dx] = (int16_t)sd_cvRoundf(c1 * 2048);
+                ct[4 * dx] = (int16_t)sx; ct[4 * dx + 1] = (int16_t)sd_cvRoundf(c0 * 2048);
+                ct[4 * dx + 2] = (int16_t)sd_cvRoundf(c1 * 2048); ct[4 * dx + 3] = 0;
             }
             for (int dy = 0; dy < g.H; dy++) {
                 float fy = (float)((dy + 0.5) * scale_y - 0.5);
                 int sy = (int)floorf(fy);
                 fy -= sy;
-                yo[dy] = (int16_t)sy;
                 float c0 = 1.f - fy, c1 = fy;
-                b0[dy] = (int16_t)sd_cvRoundf(c0 * 2048); b1[dy] = (int16_t)sd_cvRoundf(c1 * 2048);
+                rt[4 * dy] = (int16_t)sy; rt[4 * dy + 1] = (int16_t)sd_cvRoundf(c0 * 2048);
+                rt[4 * dy + 2] = (int16_t)sd_cvRoundf(c1 * 2048); rt[4 * dy + 3] = 0;
             }
-            tabOff = (int)P.tabs.size();
+            tabOff = (int)(P.tabs.size() / 4);
         }
     }
     P.pyrImageBytes = (pyrOff + 255) / 256 * 256;
@@ -218,6 +218,6 @@ static inline bool sd_plan_build(SdPlan& P, const SdParams& prm, int W, int H)
     P.candCapTotal = listOff;
     P.kpCapLevels = kpOff;
     P.kpCap = kpOff;
-    if (P.tabs.empty()) P.tabs.push_back(0);
+    if (P.tabs.empty()) P.tabs.resize(4, 0);
     return true;
 }
