@@ -136,10 +136,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=128, help="frames per step per GPU")
     ap.add_argument("--workload", choices=["rgbd", "stereo"], default="rgbd")
     ap.add_argument("--cpu-frames", type=int, default=96, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="split the per-GPU batch over this many HIP streams (latency-bound kernels of one stream overlap "
+                         "with throughput-bound kernels of another)")
     args = ap.parse_args()
 
     import torch
@@ -163,6 +166,10 @@ def main():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
 
     B = args.batch
+    S = max(1, args.streams)
+    if B % S:
+        raise SystemExit("--batch must be a multiple of --streams")
+    Bs = B // S
     if args.workload == "rgbd":
         cfg = synth.KITTI03_RGBD
         workload_name = "KITTI-03 RGB-D 1241x376, 2000 feat/frame, ORB extract+match, no semantic mask (BASELINE configs[1])"
@@ -201,46 +208,66 @@ def main():
         voc_ms = (time.perf_counter() - t0) * 1e3
 
     ex = fe.ORBextractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
-    n_img = B * imgs_per_frame
-    batch = fe.Batch(ex, W, H, n_img + 1)          # + 1 slot: mLastFrame carried across steps
+    n_img = Bs * imgs_per_frame                     # images per stream
     cam = fe.make_camera(cfg)
-    stream = torch.cuda.current_stream().cuda_stream
-    I = np.tile(np.eye(4, dtype=np.float32), (B, 1, 1))
-    cur_idx = np.arange(B, dtype=np.int32) * imgs_per_frame
+    main_stream = torch.cuda.current_stream()
+    streams = [main_stream] + [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
+    batches = [fe.Batch(ex, W, H, n_img + 1) for _ in range(S)]     # + 1 slot: mLastFrame carried across steps
+    batch = batches[0]
+    I = np.tile(np.eye(4, dtype=np.float32), (Bs, 1, 1))
+    cur_idx = np.arange(Bs, dtype=np.int32) * imgs_per_frame
     last_idx = np.concatenate([[n_img], cur_idx[:-1]]).astype(np.int32)
     depth_factor = float(np.float32(1.0) / np.float32(cfg.get("depth_map_factor", 1.0)))
-    rec = None
+    recs = None
     if dist is not None:
-        kp_p, desc_p, cnt_p, cap = batch.results_device()
-        rec = dict(kp=fe.as_torch_u8(kp_p, n_img * cap * 28), desc=fe.as_torch_u8(desc_p, n_img * cap * 32))
+        recs = []
+        for bt in batches:
+            kp_p, desc_p, cnt_p, cap = bt.results_device()
+            recs.append(dict(kp=fe.as_torch_u8(kp_p, n_img * cap * 28), desc=fe.as_torch_u8(desc_p, n_img * cap * 32)))
+
+    def run_stream(k, first):
+        bt, st = batches[k], streams[k].cuda_stream
+        f0 = k * Bs
+        g0 = d_gray[f0 * imgs_per_frame:]
+        if args.workload == "rgbd":
+            fe.cvt_gray_device(d_rgb[f0:].data_ptr(), W, H, W * 3, W * H * 3, 3, 1, g0.data_ptr(), W, W * H, Bs, st)
+        bt.extract_device(g0.data_ptr(), W, W * H, n_img, st)
+        if args.workload == "rgbd":
+            bt.rgbd_from_u16(d_depth[f0:].data_ptr(), W, W * H, Bs, depth_factor, cfg["bf"], st)
+        else:
+            bt.stereo_match(Bs, cfg["bf"], cfg["fx"], st)
+        bt.assign_grid(n_img, cam, st)
+        bt.unproject(imgs_per_frame, Bs, cam, I, st)
+        if first:
+            bt.search_by_projection(cur_idx[1:], last_idx[1:], I[1:], I[1:], cam, th, False, True, stream=st)
+        else:
+            bt.search_by_projection(cur_idx, last_idx, I, I, cam, th, False, True, stream=st)
+        bt.copy_frame(int(cur_idx[-1]), n_img, st)
 
     def step(first=False):
-        if args.workload == "rgbd":
-            fe.cvt_gray_device(d_rgb.data_ptr(), W, H, W * 3, W * H * 3, 3, 1, d_gray.data_ptr(), W, W * H, B, stream)
-        batch.extract_device(d_gray.data_ptr(), W, W * H, n_img, stream)
-        if args.workload == "rgbd":
-            batch.rgbd_from_u16(d_depth.data_ptr(), W, W * H, B, depth_factor, cfg["bf"], stream)
-        else:
-            batch.stereo_match(B, cfg["bf"], cfg["fx"], stream)
-        batch.assign_grid(n_img, cam, stream)
-        batch.unproject(imgs_per_frame, B, cam, I, stream)
-        if first:
-            batch.search_by_projection(cur_idx[1:], last_idx[1:], I[1:], I[1:], cam, th, False, True, stream=stream)
-        else:
-            batch.search_by_projection(cur_idx, last_idx, I, I, cam, th, False, True, stream=stream)
-        batch.copy_frame(int(cur_idx[-1]), n_img, stream)
+        for k in range(S):
+            run_stream(k, first)
+        if S > 1:                                   # join the side streams into the main one
+            for k in range(1, S):
+                main_stream.wait_stream(streams[k])
         if dist is not None:
-            gather_records(dist, rec["kp"], world)
-            gather_records(dist, rec["desc"], world)
+            for r in recs:
+                gather_records(dist, r["kp"], world)
+                gather_records(dist, r["desc"], world)
+        if S > 1:                                   # next step's side-stream work must not overtake the gather
+            for k in range(1, S):
+                streams[k].wait_stream(main_stream)
 
     step(first=True)                      # priming: fills the carried mLastFrame slot (setup, untimed)
     for _ in range(args.warmup):
         step()
-    batch.sync()
+    for bt in batches:
+        bt.sync()
     torch.cuda.synchronize()
     if not args.no_profile:
-        batch.set_profiling(True)
-        batch.reset_kernel_times()
+        for bt in batches:
+            bt.set_profiling(True)
+            bt.reset_kernel_times()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -253,11 +280,17 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(dist, elapsed, dev)
-    batch.sync()
+    for bt in batches:
+        bt.sync()
 
-    kt = batch.kernel_times() if not args.no_profile else {}
+    kt = {}
+    if not args.no_profile:
+        for bt in batches:
+            for k, (ms, n) in bt.kernel_times().items():
+                a, c = kt.get(k, (0.0, 0))
+                kt[k] = (a + ms, c + n)
     counts = batch.counts(n_img)
-    m, pairs, nm = batch.download_matches(B - 1)
+    m, pairs, nm = batch.download_matches(Bs - 1)
 
     if rank == 0:
         total_frames = world * B * args.steps
@@ -268,7 +301,7 @@ def main():
             dom = max((k for k in kt if kt[k][1] > 0), key=lambda k: kt[k][0])
             ms, launches = kt[dom]
             avg_ms = ms / launches
-            per_launch = {"k_pyr_level": alg["k_pyr_level"] / 7.0}.get(dom, alg.get(dom, 0)) * n_img
+            per_launch = {"k_pyr_level": alg["k_pyr_level"] / 7.0}.get(dom, alg.get(dom, 0)) * n_img   # images per launch
             achieved = per_launch / (avg_ms * 1e-3) / 1e9
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -284,6 +317,7 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(per_launch), "avg_launch_ms": round(avg_ms, 4),
                     "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in kt.items() if v[1] > 0},
+                    "streams": S,
                     "pipeline_achieved_GBs": round(alg["image_total"] * imgs_per_frame * value / 1e9, 2)}
         cpu = None
         if world == 1 and args.cpu_frames > 0:
@@ -308,7 +342,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    batch.close()
+    for bt in batches:
+        bt.close()
 
 
 if __name__ == "__main__":
