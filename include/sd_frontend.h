@@ -161,6 +161,48 @@ int sd_batch_matches_device(sd_batch* b, int32_t** d_match, int32_t** d_pairs, i
                             int* cap);
 int sd_batch_download_matches(sd_batch* b, int pair, int32_t* match, int32_t* pairs, int cap, int* npairs, int* nmatches);
 
+/* ---- dynamic-object handling (src/Frame.cc:481-641, src/Tracking.cc:1093-1367) ---- */
+#define SD_MAX_BOXES 32
+/* Frame::boxTrack(boxes, last_frame) (src/Frame.cc:481-552), host code (f64, a handful of boxes).  boxes: [cap][4]
+ * (x, y, width, height) in/out — unmatched last-frame boxes are re-injected once, so *n_out may exceed n_box.
+ * Outputs box_idx / omit / velocity ([cap], [cap], [cap][2]) are the frame's members of the same names. */
+int sd_box_track(double* boxes, int n_box, int cap, const double* last_objects, int n_last, const int32_t* last_box_idx,
+                 const uint8_t* last_omit, const double* last_velocity, int img_cols, int img_rows, int32_t* box_idx,
+                 uint8_t* omit, double* velocity, int* n_out);
+/* Frame::firstSeparate + the ctor split (src/Frame.cc:555-604, 336-367) for n_frames frame slots: keypoints
+ * inside any box become dynamic (class_id = pre-split index), arrays are reordered static-first, N becomes
+ * N_s, empty boxes are erased exactly as the reference does it (quirk included), per-box keypoint lists
+ * (mvdynKeys/mdynDescriptors/mvudynRight/mvdynDepth) are index lists into the frame's arrays.
+ * boxes: [n_frames][SD_MAX_BOXES][4], box_idx: [n_frames][SD_MAX_BOXES] (boxTrack outputs).  Run after the
+ * stereo / RGB-D step (the lookup is per keypoint, so the order relative to the reorder is immaterial). */
+int sd_batch_first_separate(sd_batch* b, int n_frames, const int32_t* slots, const double* boxes, const int32_t* n_boxes,
+                            const int32_t* box_idx, void* stream);
+/* Frame::objects / box_idx / box_status and the per-box lists of a slot.  kept_orig[j] = index (before the
+ * erase) of surviving box j — apply the same selection to omit / box_velocity on the host.  box_start has nb+1
+ * entries; box_items index the frame's DYNAMIC keypoint arrays (sd_batch_download_dynamic): the keypoints that
+ * fell inside boxes, in original order — mvdynKeys[b][k] == dynamic[box_items[box_start[b] + k]]. */
+int sd_batch_download_boxes(sd_batch* b, int slot, int* nb, double* boxes, int32_t* box_idx, int32_t* box_status,
+                            int32_t* kept_orig, int32_t* box_start, int32_t* box_items, int items_cap, int* n_all,
+                            int* n_static);
+/* The dynamic keypoints of a slot (class_id = index before the split), their descriptors, mvuRight and mvDepth. */
+int sd_batch_download_dynamic(sd_batch* b, int slot, sd_keypoint* kp, uint8_t* desc, float* uright, float* depth, int cap, int* n);
+/* Tracking::Separate(HorF, flag, dynStatus) (src/Tracking.cc:1093-1239) for n_pairs (current, reference) slots:
+ * per box with the same id in both frames cv::BFMatcher(NORM_HAMMING, crossCheck).match, the <3 / <20 % skip,
+ * classifyH (flag 1, :1241-1309) or classifyF (flag 2, :1311-1367) with H/F row-major 3x3 f32, the static /
+ * dynamic box decision and box_status update against mLastFrame's (last_box_idx / last_box_status, [n_pairs][32]). */
+int sd_batch_separate(sd_batch* b, int n_pairs, const int32_t* cur_index, const int32_t* ref_index, const float* HorF,
+                      const int32_t* flag, const int32_t* last_box_idx, const int32_t* last_box_status,
+                      const int32_t* n_last, void* stream);
+/* ret = Separate's return value; dyn_start[33] / dyn_status = dynStatus as CSR over the current frame's boxes
+ * (entries: index into the box list or -1); matches = (queryIdx, trainIdx) per entry. */
+int sd_batch_download_separate(sd_batch* b, int pair, int32_t* ret, int32_t* dyn_start, int32_t* dyn_status, int32_t* matches,
+                               int cap);
+/* Frame::UpdateFrame(dynStatus) (src/Frame.cc:607-641) on the current frames of the last sd_batch_separate:
+ * re-admitted keypoints are appended behind the static ones (class_id de-duplicated, push_back order), N grows.
+ * only_if_static != 0 applies it only where Separate returned 1 (Tracking.cc:651-653).  Re-run
+ * sd_batch_assign_grid afterwards (UpdateFeaturesToGrid). */
+int sd_batch_update_frame(sd_batch* b, int only_if_static, void* stream);
+
 /* ---- Tracking::GrabImage* preprocessing (src/Tracking.cc:170-343) ---- */
 /* cvtColor(RGB|BGR|RGBA|BGRA -> GRAY); rgb_order = Camera.RGB.  channels 3 or 4. */
 int sd_cvt_gray_device(const uint8_t* d_src, int width, int height, size_t src_stride, size_t src_pitch, int channels,

@@ -17,7 +17,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 
 def build(force=False):
     so = os.path.join(_HERE, "libsd_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("sd_oracle.cpp", "cv_leaves.h", "orb_pattern.inc", "frame_oracle.inc")]
+    srcs = [os.path.join(_HERE, f) for f in ("sd_oracle.cpp", "cv_leaves.h", "orb_pattern.inc", "frame_oracle.inc", "cull_oracle.inc")]
     srcs = [s for s in srcs if os.path.exists(s)]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -192,3 +192,87 @@ def search_by_projection(kpC, descC, uRightC, kpL, dMP, xw, flags, Tcw, Tlw, cam
            C.c_float(th), int(bMono), int(checkOrientation), _p(occ) if occ is not None else None, _p(match), _p(pairs),
            C.byref(npairs))
     return match, pairs[:npairs.value].copy(), nm
+
+
+MAXB = 32
+
+
+def box_track(boxes, last_objects, last_box_idx, last_omit, last_velocity, img_cols, img_rows, cap=MAXB):
+    """Frame::boxTrack.  boxes (n,4) f64 -> (boxes', box_idx, omit, velocity) with re-injected boxes appended."""
+    n = len(boxes)
+    bx = np.zeros((cap, 4), np.float64); bx[:n] = boxes
+    lo = np.ascontiguousarray(last_objects, np.float64).reshape(-1, 4)
+    li = np.ascontiguousarray(last_box_idx, np.int32); lm = np.ascontiguousarray(last_omit, np.uint8)
+    lv = np.ascontiguousarray(last_velocity, np.float64).reshape(-1, 2)
+    idx = np.zeros(cap, np.int32); om = np.zeros(cap, np.uint8); vel = np.zeros((cap, 2), np.float64)
+    f = lib().orc_box_track
+    f.restype = C.c_int
+    n2 = f(_p(bx), n, cap, _p(lo), len(lo), _p(li), _p(lm), _p(lv), int(img_cols), int(img_rows), _p(idx), _p(om), _p(vel))
+    assert n2 >= 0
+    return bx[:n2].copy(), idx[:n2].copy(), om[:n2].copy(), vel[:n2].copy()
+
+
+def first_separate(kp, desc, boxes, box_idx, omit, velocity):
+    """Frame::firstSeparate + ctor split.  Returns dict(kp, desc, perm, Ns, Nd, boxes, box_idx, omit, velocity, boxStart, boxItems)."""
+    kp = np.ascontiguousarray(kp).copy(); desc = np.ascontiguousarray(desc, np.uint8).copy()
+    N = len(kp); nb = len(boxes)
+    bx = np.ascontiguousarray(boxes, np.float64).copy().reshape(-1, 4)
+    bi = np.ascontiguousarray(box_idx, np.int32).copy(); bo = np.ascontiguousarray(omit, np.uint8).copy()
+    bv = np.ascontiguousarray(velocity, np.float64).copy().reshape(-1, 2)
+    perm = np.zeros(N, np.int32); Ns = C.c_int(); Nd = C.c_int()
+    boxStart = np.zeros(nb + 1, np.int32); cap = 4 * N + 16
+    items = np.zeros(cap, np.int32)
+    f = lib().orc_first_separate
+    f.restype = C.c_int
+    nb2 = f(_p(kp), _p(desc), N, _p(bx), nb, _p(bi), _p(bo), _p(bv), _p(perm), C.byref(Ns), C.byref(Nd), _p(boxStart), _p(items), cap)
+    assert nb2 >= 0
+    return dict(kp=kp, desc=desc, perm=perm, Ns=Ns.value, Nd=Nd.value, boxes=bx[:nb2], box_idx=bi[:nb2], omit=bo[:nb2],
+                velocity=bv[:nb2], boxStart=boxStart[:nb2 + 1].copy(), boxItems=items[:boxStart[nb2]].copy())
+
+
+def inv3x3(M):
+    M = np.ascontiguousarray(M, np.float32).reshape(9); D = np.zeros(9, np.float32)
+    lib().orc_inv3x3(_p(M), _p(D))
+    return D.reshape(3, 3)
+
+
+def bf_match_crosscheck(q, t):
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32); t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    m = np.zeros((max(len(q), 1), 2), np.int32)
+    f = lib().orc_bf_match_crosscheck
+    f.restype = C.c_int
+    n = f(_p(q), len(q), _p(t), len(t), _p(m))
+    return m[:n].copy()
+
+
+def separate(HorF, flag, cur, ref, box_idx_last, box_status_last, box_status_cur):
+    """Tracking::Separate.  cur/ref: dicts with kp, desc, boxStart, boxItems, box_idx.  Returns
+    (ret, box_status_cur', dynStart, dynStatus, matches)."""
+    M = np.ascontiguousarray(HorF, np.float32).reshape(9)
+    nbC, nbR = len(cur["box_idx"]), len(ref["box_idx"])
+    bl = np.ascontiguousarray(box_idx_last, np.int32); sl = np.ascontiguousarray(box_status_last, np.int32)
+    sc = np.ascontiguousarray(box_status_cur, np.int32).copy()
+    tot = int(cur["boxStart"][-1]) + 1
+    dynStart = np.zeros(nbC + 1, np.int32); dyn = np.zeros(tot, np.int32); mt = np.zeros((tot, 2), np.int32)
+    f = lib().orc_separate
+    f.restype = C.c_int
+    args = []
+    for fr in (cur, ref):
+        args += [np.ascontiguousarray(fr["kp"]), np.ascontiguousarray(fr["desc"], np.uint8),
+                 np.ascontiguousarray(fr["boxStart"], np.int32), np.ascontiguousarray(fr["boxItems"], np.int32),
+                 np.ascontiguousarray(fr["box_idx"], np.int32)]
+    ret = f(_p(M), int(flag), _p(args[0]), _p(args[1]), _p(args[2]), _p(args[3]), _p(args[4]), nbC,
+            _p(args[5]), _p(args[6]), _p(args[7]), _p(args[8]), _p(args[9]), nbR, _p(bl), _p(sl), len(bl), _p(sc),
+            _p(dynStart), _p(dyn), _p(mt))
+    n = dynStart[nbC]
+    return ret, sc, dynStart, dyn[:n].copy(), mt[:n].copy()
+
+
+def update_frame(kp, boxStart, boxItems, dynStart, dynStatus):
+    kp = np.ascontiguousarray(kp); bs = np.ascontiguousarray(boxStart, np.int32); it = np.ascontiguousarray(boxItems, np.int32)
+    ds = np.ascontiguousarray(dynStart, np.int32); dy = np.ascontiguousarray(dynStatus, np.int32)
+    out = np.zeros(len(dy) + 1, np.int32)
+    f = lib().orc_update_frame
+    f.restype = C.c_int
+    n = f(_p(kp), _p(bs), _p(it), len(bs) - 1, _p(ds), _p(dy), _p(out))
+    return out[:n].copy()

@@ -633,5 +633,6 @@ int orc_stereo_matches(void* hL, void* hR, const void* kL_, const uint8_t* dL, i
 }
 
 #include "frame_oracle.inc"
+#include "cull_oracle.inc"
 
 } // extern "C"

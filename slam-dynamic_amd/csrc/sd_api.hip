@@ -10,6 +10,7 @@
 #include "k_extract.h"
 #include "k_frame.h"
 #include "k_fast.h"
+#include "k_cull.h"
 
 static thread_local std::string g_err;
 static int set_err(int code, const std::string& msg) { g_err = msg; return code; }
@@ -26,10 +27,11 @@ struct sd_extractor {
     SdParams prm;
 };
 
-enum KernelId { K_PYR0, K_PYR, K_FAST, K_QTREE, K_ORIENT, K_BLUR, K_DESC, K_STEREO, K_STEREO_F, K_RGBD, K_GRID, K_UNPROJ, K_PROJ_A, K_PROJ_B, K_COUNT };
+enum KernelId { K_PYR0, K_PYR, K_FAST, K_QTREE, K_ORIENT, K_BLUR, K_DESC, K_STEREO, K_STEREO_F, K_RGBD, K_GRID, K_UNPROJ, K_PROJ_A, K_PROJ_B, K_BOXSEP, K_SEPARATE, K_UPDATE, K_COUNT };
 static const char* kKernelNames[K_COUNT] = {"k_pyr_level0", "k_pyr_level", "k_fast_cells", "k_quadtree", "k_orient",
                                             "k_blur", "k_describe", "k_stereo_match", "k_stereo_filter", "k_rgbd",
-                                            "k_grid_cells", "k_unproject", "k_proj_candidates", "k_proj_resolve"};
+                                            "k_grid_cells", "k_unproject", "k_proj_candidates", "k_proj_resolve",
+                                            "k_box_separate", "k_separate", "k_update_frame"};
 
 struct sd_batch {
     sd_extractor* ex = nullptr;
@@ -77,6 +79,17 @@ struct sd_batch {
     int* d_nmatch = nullptr;
     float* d_pose = nullptr;        // staging for host poses: [2][maxImages][16]
     int nPairs = 0;
+    // dynamic-object cull
+    SdFrameBoxes* d_fb = nullptr;
+    int* d_boxItems = nullptr;
+    sd_keypoint* d_kpT = nullptr; uint8_t* d_descT = nullptr; float* d_urT = nullptr; float* d_depT = nullptr;
+    sd_keypoint* d_kpD = nullptr; uint8_t* d_descD = nullptr; float* d_urD = nullptr; float* d_depD = nullptr;
+    int* d_slots = nullptr;
+    float* d_HorF = nullptr; int* d_sepFlag = nullptr; int* d_lastIdx = nullptr; int* d_lastStatus = nullptr; int* d_nLast = nullptr;
+    int* d_dynStart = nullptr; int* d_dynStatus = nullptr; int* d_sepMatches = nullptr; int* d_sepRet = nullptr;
+    int2* d_sepPairs = nullptr;
+    int itemsCap = 0;
+    int nSepPairs = 0;
     uint8_t* d_stage = nullptr;    // staging for host-image uploads
     size_t stageBytes = 0;
     int qtMN = 0, qtSortP = 0;
@@ -184,7 +197,10 @@ static void batch_free(sd_batch* b)
     void* ptrs[] = {b->d_plan, b->d_cells, b->d_tabs, b->d_pyr, b->d_blur, b->d_cellList, b->d_cellCount, b->d_cand,
                     b->d_nodeOf, b->d_lvlCount, b->d_candCount, b->d_lvlKp, b->d_rot, b->d_kp, b->d_desc, b->d_count,
                     b->d_err, b->d_uright, b->d_depth, b->d_sad, b->d_stage, b->d_cellOf, b->d_xw, b->d_flags,
-                    b->d_pcand, b->d_pncand, b->d_match, b->d_pairs, b->d_npairs, b->d_nmatch, b->d_pose, b->d_pairIdx, b->d_sortedIdx, b->d_cellStart};
+                    b->d_pcand, b->d_pncand, b->d_match, b->d_pairs, b->d_npairs, b->d_nmatch, b->d_pose, b->d_pairIdx, b->d_sortedIdx, b->d_cellStart,
+                    b->d_fb, b->d_boxItems, b->d_kpT, b->d_descT, b->d_urT, b->d_depT, b->d_slots, b->d_HorF, b->d_sepFlag,
+                    b->d_lastIdx, b->d_lastStatus, b->d_nLast, b->d_dynStart, b->d_dynStatus, b->d_sepMatches, b->d_sepRet,
+                    b->d_sepPairs, b->d_kpD, b->d_descD, b->d_urD, b->d_depD};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& r : b->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : b->pool) (void)hipEventDestroy(e);
@@ -275,6 +291,28 @@ int sd_batch_create(sd_batch** out, sd_extractor* ex, int width, int height, int
     ALLOC(b->d_npairs, nI * 4);
     ALLOC(b->d_nmatch, nI * 4);
     ALLOC(b->d_pose, nI * 2 * 16 * 4);
+    b->itemsCap = 2 * P.kpCap;
+    ALLOC(b->d_fb, nI * sizeof(SdFrameBoxes));
+    ALLOC(b->d_boxItems, nI * b->itemsCap * 4);
+    ALLOC(b->d_kpT, nI * P.kpCap * sizeof(sd_keypoint));
+    ALLOC(b->d_descT, nI * P.kpCap * 32);
+    ALLOC(b->d_urT, nI * P.kpCap * 4);
+    ALLOC(b->d_depT, nI * P.kpCap * 4);
+    ALLOC(b->d_kpD, nI * P.kpCap * sizeof(sd_keypoint));
+    ALLOC(b->d_descD, nI * P.kpCap * 32);
+    ALLOC(b->d_urD, nI * P.kpCap * 4);
+    ALLOC(b->d_depD, nI * P.kpCap * 4);
+    ALLOC(b->d_slots, nI * 4);
+    ALLOC(b->d_HorF, nI * 9 * 4);
+    ALLOC(b->d_sepFlag, nI * 4);
+    ALLOC(b->d_lastIdx, nI * SD_MAXB * 4);
+    ALLOC(b->d_lastStatus, nI * SD_MAXB * 4);
+    ALLOC(b->d_nLast, nI * 4);
+    ALLOC(b->d_dynStart, nI * (SD_MAXB + 1) * 4);
+    ALLOC(b->d_dynStatus, nI * b->itemsCap * 4);
+    ALLOC(b->d_sepMatches, nI * b->itemsCap * 8);
+    ALLOC(b->d_sepRet, nI * 4);
+    ALLOC(b->d_sepPairs, nI * sizeof(int2));
     ALLOC(b->d_pairIdx, nI * sizeof(int2));
     b->slotValid.assign(nI, 0);
 #undef ALLOC
@@ -283,6 +321,8 @@ int sd_batch_create(sd_batch** out, sd_extractor* ex, int width, int height, int
     if (e == hipSuccess) e = hipMemcpy(b->d_cells, P.cells.data(), sizeof(SdCell) * P.cells.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(b->d_tabs, P.tabs.data(), sizeof(int16_t) * P.tabs.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(b->d_err, 0, 4);
+    if (e == hipSuccess) e = hipMemset(b->d_fb, 0, nI * sizeof(SdFrameBoxes));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_separate, hipFuncAttributeMaxDynamicSharedMemorySize, SD_BF_TCAP * 40 + 64);
     if (e == hipSuccess) e = hipMemset(b->d_count, 0, nI * 4);
     if (e == hipSuccess) e = hipMemset(b->d_lvlCount, 0, nI * P.nlevels * 4);
     if (e == hipSuccess && lds > 64 * 1024)
@@ -428,7 +468,7 @@ int sd_batch_sync(sd_batch* b)
     HIPCHK(hipMemcpy(&err, b->d_err, 4, hipMemcpyDeviceToHost));
     if (err) {
         (void)hipMemset(b->d_err, 0, 4);
-        return set_err(SD_ERR_UNSUPPORTED, "device capacity exceeded: 1|2 quadtree nodes, 4 projection candidates (flag " + std::to_string(err) + ")");
+        return set_err(SD_ERR_UNSUPPORTED, "device capacity exceeded: 1|2 quadtree nodes, 4 projection candidates, 8|16|32 box tables (flag " + std::to_string(err) + ")");
     }
     return SD_OK;
 }
@@ -851,12 +891,16 @@ int sd_batch_copy_frame(sd_batch* b, int src, int dst, void* stream_)
 #define CP(ptr, elemBytes) HIPCHK(hipMemcpyAsync((char*)(ptr) + dst * cap * (elemBytes), (const char*)(ptr) + src * cap * (elemBytes), cap * (elemBytes), hipMemcpyDeviceToDevice, s))
     CP(b->d_kp, sizeof(sd_keypoint)); CP(b->d_desc, 32); CP(b->d_uright, 4); CP(b->d_depth, 4); CP(b->d_sad, 4);
     CP(b->d_cellOf, 2); CP(b->d_xw, 12); CP(b->d_flags, 1); CP(b->d_sortedIdx, 2);
+    CP(b->d_kpD, sizeof(sd_keypoint)); CP(b->d_descD, 32); CP(b->d_urD, 4); CP(b->d_depD, 4);
 #undef CP
     HIPCHK(hipMemcpyAsync(b->d_cellStart + (size_t)dst * (SD_GRID_CELLS + 8), b->d_cellStart + (size_t)src * (SD_GRID_CELLS + 8),
                           (size_t)(SD_GRID_CELLS + 8) * 2, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(b->d_count + dst, b->d_count + src, 4, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(b->d_lvlCount + (size_t)dst * b->plan.nlevels, b->d_lvlCount + (size_t)src * b->plan.nlevels,
                           (size_t)b->plan.nlevels * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->d_fb + dst, b->d_fb + src, sizeof(SdFrameBoxes), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->d_boxItems + (size_t)dst * b->itemsCap, b->d_boxItems + (size_t)src * b->itemsCap, (size_t)b->itemsCap * 4,
+                          hipMemcpyDeviceToDevice, s));
     b->slotValid[dst] = 1;
     return SD_OK;
 }
@@ -885,6 +929,253 @@ int sd_batch_download_matches(sd_batch* b, int pair, int32_t* match, int32_t* pa
     if (pairs && np > 0) HIPCHK(hipMemcpy(pairs, b->d_pairs + (size_t)pair * b->plan.kpCap * 2, (size_t)np * 8, hipMemcpyDeviceToHost));
     if (npairs) *npairs = np;
     if (nmatches) *nmatches = nm;
+    return SD_OK;
+}
+
+
+// ---------------------------------------------------------------- dynamic-object cull
+static SdCullPtrs cull_ptrs(sd_batch* b)
+{
+    SdCullPtrs A;
+    A.kp = b->d_kp; A.desc = b->d_desc; A.uright = b->d_uright; A.depth = b->d_depth; A.count = b->d_count;
+    A.kpT = b->d_kpT; A.descT = b->d_descT; A.urT = b->d_urT; A.depT = b->d_depT;
+    A.kpD = b->d_kpD; A.descD = b->d_descD; A.urD = b->d_urD; A.depD = b->d_depD;
+    A.fb = b->d_fb; A.boxItems = b->d_boxItems; A.cap = b->plan.kpCap; A.itemsCap = b->itemsCap; A.errFlag = b->d_err;
+    return A;
+}
+
+namespace {
+struct HRect { double x, y, w, h; bool empty() const { return w <= 0 || h <= 0; } double area() const { return w * h; } };
+inline HRect hrect_and(HRect a, const HRect& b)
+{
+    const double x1 = a.x > b.x ? a.x : b.x, y1 = a.y > b.y ? a.y : b.y;
+    const double x2 = a.x + a.w < b.x + b.w ? a.x + a.w : b.x + b.w, y2 = a.y + a.h < b.y + b.h ? a.y + a.h : b.y + b.h;
+    HRect r = {x1, y1, x2 - x1, y2 - y1};
+    if (r.w <= 0 || r.h <= 0) r = HRect{0, 0, 0, 0};
+    return r;
+}
+inline HRect hrect_or(HRect a, const HRect& b)
+{
+    if (a.empty()) return b;
+    if (b.empty()) return a;
+    const double x1 = a.x < b.x ? a.x : b.x, y1 = a.y < b.y ? a.y : b.y;
+    const double x2 = a.x + a.w > b.x + b.w ? a.x + a.w : b.x + b.w, y2 = a.y + a.h > b.y + b.h ? a.y + a.h : b.y + b.h;
+    return HRect{x1, y1, x2 - x1, y2 - y1};
+}
+}  // namespace
+
+// Frame::boxTrack (src/Frame.cc:481-552) — host code: a handful of boxes per frame, f64 arithmetic.
+int sd_box_track(double* boxes, int n_box, int cap, const double* last_objects, int n_last, const int32_t* last_box_idx,
+                 const uint8_t* last_omit, const double* last_velocity, int img_cols, int img_rows, int32_t* box_idx,
+                 uint8_t* omit, double* velocity, int* n_out)
+{
+    if (!boxes || n_box < 0 || cap < n_box || n_last < 0 || !box_idx || !omit || !velocity || !n_out ||
+        (n_last > 0 && (!last_objects || !last_box_idx || !last_omit || !last_velocity)))
+        return set_err(SD_ERR_INVALID, "bad box_track arguments");
+    std::vector<HRect> bx(n_box);
+    for (int i = 0; i < n_box; i++) bx[i] = HRect{boxes[4 * i], boxes[4 * i + 1], boxes[4 * i + 2], boxes[4 * i + 3]};
+    std::vector<int> idx(n_box, -1);
+    std::vector<uint8_t> om(n_box, 0);
+    std::vector<double> vel(2 * (size_t)n_box, 0.0);
+    if (n_last > 0) {
+        std::vector<HRect> lo(n_last);
+        for (int i = 0; i < n_last; i++) lo[i] = HRect{last_objects[4 * i], last_objects[4 * i + 1], last_objects[4 * i + 2], last_objects[4 * i + 3]};
+        for (int i = 0; i < n_last; i++) {           // greedy 1 - IoU association, later previous boxes may overwrite
+            double minCost = 1;
+            int best = -1;
+            for (int j = 0; j < n_box; j++) {
+                const double cost = 1 - hrect_and(lo[i], bx[j]).area() / hrect_or(lo[i], bx[j]).area();
+                if (cost < minCost) { minCost = cost; best = j; }
+            }
+            if (best != -1 && !last_omit[i]) {
+                idx[best] = last_box_idx[i];
+                vel[2 * best] = bx[best].x + bx[best].w / 2 - lo[i].x - lo[i].w / 2;
+                vel[2 * best + 1] = bx[best].y + bx[best].h / 2 - lo[i].y - lo[i].h / 2;
+            }
+        }
+        for (int i = 0; i < n_last; i++) {           // re-inject an unmatched previous box once
+            if (last_omit[i]) continue;
+            bool found = false;
+            for (size_t k = 0; k < idx.size(); k++) found |= idx[k] == last_box_idx[i];
+            if (found) continue;
+            const float cx = (float)(lo[i].x + lo[i].w / 2 + last_velocity[2 * i]);
+            const float cy = (float)(lo[i].y + lo[i].h / 2 + last_velocity[2 * i + 1]);
+            if (0.f <= cx && cx < (float)img_cols && 0.f <= cy && cy < (float)img_rows) {
+                bx.push_back(HRect{lo[i].x + last_velocity[2 * i], lo[i].y + last_velocity[2 * i + 1], lo[i].w, lo[i].h});
+                idx.push_back(last_box_idx[i]);
+                om.push_back(1);
+                vel.push_back(last_velocity[2 * i]); vel.push_back(last_velocity[2 * i + 1]);
+            }
+        }
+        for (int i = 0; i < n_box; i++) {            // new ids for unmatched current boxes
+            if (idx[i] != -1) continue;
+            int mx = idx[0];
+            for (size_t k = 1; k < idx.size(); k++) mx = idx[k] > mx ? idx[k] : mx;
+            idx[i] = mx + 1;
+        }
+    } else {
+        for (int i = 0; i < n_box; i++) idx[i] = i;
+    }
+    const int n = (int)bx.size();
+    if (n > cap) return set_err(SD_ERR_CAPACITY, "box buffer too small for the re-injected boxes");
+    for (int i = 0; i < n; i++) {
+        boxes[4 * i] = bx[i].x; boxes[4 * i + 1] = bx[i].y; boxes[4 * i + 2] = bx[i].w; boxes[4 * i + 3] = bx[i].h;
+        box_idx[i] = idx[i]; omit[i] = om[i]; velocity[2 * i] = vel[2 * i]; velocity[2 * i + 1] = vel[2 * i + 1];
+    }
+    *n_out = n;
+    return SD_OK;
+}
+
+int sd_batch_first_separate(sd_batch* b, int n_frames, const int32_t* slots, const double* boxes, const int32_t* n_boxes,
+                            const int32_t* box_idx, void* stream_)
+{
+    if (!b || n_frames < 0 || n_frames > b->maxImages || (n_frames > 0 && (!slots || !boxes || !n_boxes || !box_idx)))
+        return set_err(SD_ERR_INVALID, "bad first_separate arguments");
+    if (b->plan.kpCap > 2048) return set_err(SD_ERR_UNSUPPORTED, "box separation supports up to 2048 keypoints per image");
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
+    b->lastStream = s;
+    if (n_frames == 0) return SD_OK;
+    std::vector<SdFrameBoxes> h(n_frames);
+    for (int f = 0; f < n_frames; f++) {
+        if (!slot_ok(b, slots[f])) return set_err(SD_ERR_STATE, "first_separate: slot holds no results");
+        if (n_boxes[f] < 0 || n_boxes[f] > SD_MAXB) return set_err(SD_ERR_CAPACITY, "more than 32 boxes in a frame");
+        memset(&h[f], 0, sizeof(SdFrameBoxes));
+        h[f].nb = n_boxes[f];
+        for (int j = 0; j < n_boxes[f]; j++) {
+            for (int k = 0; k < 4; k++) h[f].boxes[j][k] = boxes[((size_t)f * SD_MAXB + j) * 4 + k];
+            h[f].box_idx[j] = box_idx[(size_t)f * SD_MAXB + j];
+            h[f].box_status[j] = -1;
+        }
+    }
+    for (int f = 0; f < n_frames; f++)
+        HIPCHK(hipMemcpyAsync(b->d_fb + slots[f], &h[f], sizeof(SdFrameBoxes), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->d_slots, slots, (size_t)n_frames * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));        // h[] is pageable stack/heap memory about to go out of scope
+    {
+        ProfScope ps(b, s, K_BOXSEP);
+        const size_t lds = (size_t)b->plan.kpCap * 8 + 64;
+        hipLaunchKernelGGL(k_box_separate, dim3(n_frames), dim3(256), lds, s, cull_ptrs(b), b->d_slots);
+    }
+    LAUNCH_CHECK("k_box_separate");
+    return SD_OK;
+}
+
+int sd_batch_download_boxes(sd_batch* b, int slot, int* nb, double* boxes, int32_t* box_idx, int32_t* box_status, int32_t* kept_orig,
+                            int32_t* box_start, int32_t* box_items, int items_cap, int* n_all, int* n_static)
+{
+    if (!b || !slot_ok(b, slot)) return SD_ERR_INVALID;
+    int rc = sd_batch_sync(b);
+    if (rc != SD_OK) return rc;
+    SdFrameBoxes h;
+    HIPCHK(hipMemcpy(&h, b->d_fb + slot, sizeof(h), hipMemcpyDeviceToHost));
+    if (nb) *nb = h.nb;
+    if (n_all) *n_all = h.nAll;
+    if (n_static) *n_static = h.nOri;
+    for (int j = 0; j < h.nb; j++) {
+        if (boxes) for (int k = 0; k < 4; k++) boxes[4 * j + k] = h.boxes[j][k];
+        if (box_idx) box_idx[j] = h.box_idx[j];
+        if (box_status) box_status[j] = h.box_status[j];
+        if (kept_orig) kept_orig[j] = h.keptOrig[j];
+    }
+    if (box_start) for (int j = 0; j <= h.nb; j++) box_start[j] = h.boxStart[j];
+    if (box_items) {
+        const int n = h.boxStart[h.nb];
+        if (n > items_cap) return set_err(SD_ERR_CAPACITY, "box item buffer too small");
+        if (n > 0) HIPCHK(hipMemcpy(box_items, b->d_boxItems + (size_t)slot * b->itemsCap, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
+    return SD_OK;
+}
+
+int sd_batch_download_dynamic(sd_batch* b, int slot, sd_keypoint* kp, uint8_t* desc, float* uright, float* depth, int cap, int* n)
+{
+    if (!b || !slot_ok(b, slot) || !n) return SD_ERR_INVALID;
+    int rc = sd_batch_sync(b);
+    if (rc != SD_OK) return rc;
+    SdFrameBoxes h;
+    HIPCHK(hipMemcpy(&h, b->d_fb + slot, sizeof(h), hipMemcpyDeviceToHost));
+    *n = h.nDyn;
+    if (h.nDyn > cap) return set_err(SD_ERR_CAPACITY, "dynamic keypoint buffer too small");
+    const size_t off = (size_t)slot * b->plan.kpCap;
+    if (h.nDyn > 0) {
+        if (kp) HIPCHK(hipMemcpy(kp, b->d_kpD + off, (size_t)h.nDyn * sizeof(sd_keypoint), hipMemcpyDeviceToHost));
+        if (desc) HIPCHK(hipMemcpy(desc, b->d_descD + off * 32, (size_t)h.nDyn * 32, hipMemcpyDeviceToHost));
+        if (uright) HIPCHK(hipMemcpy(uright, b->d_urD + off, (size_t)h.nDyn * 4, hipMemcpyDeviceToHost));
+        if (depth) HIPCHK(hipMemcpy(depth, b->d_depD + off, (size_t)h.nDyn * 4, hipMemcpyDeviceToHost));
+    }
+    return SD_OK;
+}
+
+int sd_batch_separate(sd_batch* b, int n_pairs, const int32_t* cur_index, const int32_t* ref_index, const float* HorF,
+                      const int32_t* flag, const int32_t* last_box_idx, const int32_t* last_box_status, const int32_t* n_last,
+                      void* stream_)
+{
+    if (!b || n_pairs < 0 || n_pairs > b->maxImages ||
+        (n_pairs > 0 && (!cur_index || !ref_index || !HorF || !flag || !last_box_idx || !last_box_status || !n_last)))
+        return set_err(SD_ERR_INVALID, "bad separate arguments");
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
+    b->lastStream = s;
+    b->nSepPairs = 0;
+    if (n_pairs == 0) return SD_OK;
+    std::vector<int2> idx(n_pairs);
+    for (int p = 0; p < n_pairs; p++) {
+        if (!slot_ok(b, cur_index[p]) || !slot_ok(b, ref_index[p])) return set_err(SD_ERR_STATE, "separate: slot holds no results");
+        if (flag[p] != 1 && flag[p] != 2) return set_err(SD_ERR_INVALID, "separate: flag must be 1 (H) or 2 (F)");
+        if (n_last[p] < 0 || n_last[p] > SD_MAXB) return set_err(SD_ERR_INVALID, "separate: bad n_last");
+        idx[p] = make_int2(cur_index[p], ref_index[p]);
+    }
+    HIPCHK(hipMemcpyAsync(b->d_sepPairs, idx.data(), (size_t)n_pairs * sizeof(int2), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->d_HorF, HorF, (size_t)n_pairs * 36, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->d_sepFlag, flag, (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->d_lastIdx, last_box_idx, (size_t)n_pairs * SD_MAXB * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->d_lastStatus, last_box_status, (size_t)n_pairs * SD_MAXB * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->d_nLast, n_last, (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));        // idx[] is about to go out of scope
+    SdSepArgs G;
+    G.pairIdx = b->d_sepPairs; G.HorF = b->d_HorF; G.flag = b->d_sepFlag; G.lastIdx = b->d_lastIdx; G.lastStatus = b->d_lastStatus;
+    G.nLast = b->d_nLast; G.dynStart = b->d_dynStart; G.dynStatus = b->d_dynStatus; G.matches = b->d_sepMatches; G.ret = b->d_sepRet;
+    {
+        ProfScope ps(b, s, K_SEPARATE);
+        hipLaunchKernelGGL(k_separate, dim3(n_pairs), dim3(256), (size_t)SD_BF_TCAP * 40 + 64, s, cull_ptrs(b), G);
+    }
+    LAUNCH_CHECK("k_separate");
+    b->nSepPairs = n_pairs;
+    return SD_OK;
+}
+
+int sd_batch_download_separate(sd_batch* b, int pair, int32_t* ret, int32_t* dyn_start, int32_t* dyn_status, int32_t* matches, int cap)
+{
+    if (!b || pair < 0 || pair >= b->nSepPairs) return SD_ERR_INVALID;
+    int rc = sd_batch_sync(b);
+    if (rc != SD_OK) return rc;
+    int ds[SD_MAXB + 1];
+    HIPCHK(hipMemcpy(ds, b->d_dynStart + (size_t)pair * (SD_MAXB + 1), sizeof(ds), hipMemcpyDeviceToHost));
+    if (dyn_start) memcpy(dyn_start, ds, sizeof(ds));
+    const int n = ds[SD_MAXB];
+    if (n > cap) return set_err(SD_ERR_CAPACITY, "dynStatus buffer too small");
+    if (ret) HIPCHK(hipMemcpy(ret, b->d_sepRet + pair, 4, hipMemcpyDeviceToHost));
+    if (n > 0) {
+        if (dyn_status) HIPCHK(hipMemcpy(dyn_status, b->d_dynStatus + (size_t)pair * b->itemsCap, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (matches) HIPCHK(hipMemcpy(matches, b->d_sepMatches + (size_t)pair * b->itemsCap * 2, (size_t)n * 8, hipMemcpyDeviceToHost));
+    }
+    return SD_OK;
+}
+
+int sd_batch_update_frame(sd_batch* b, int only_if_static, void* stream_)
+{
+    if (!b) return SD_ERR_INVALID;
+    if (b->nSepPairs <= 0) return set_err(SD_ERR_STATE, "update_frame needs a preceding separate");
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
+    b->lastStream = s;
+    SdSepArgs G;
+    G.pairIdx = b->d_sepPairs; G.HorF = b->d_HorF; G.flag = b->d_sepFlag; G.lastIdx = b->d_lastIdx; G.lastStatus = b->d_lastStatus;
+    G.nLast = b->d_nLast; G.dynStart = b->d_dynStart; G.dynStatus = b->d_dynStatus; G.matches = b->d_sepMatches; G.ret = b->d_sepRet;
+    {
+        ProfScope ps(b, s, K_UPDATE);
+        const size_t lds = (size_t)b->itemsCap * 4 + (size_t)b->plan.kpCap + 64;
+        hipLaunchKernelGGL(k_update_frame, dim3(b->nSepPairs), dim3(256), lds, s, cull_ptrs(b), G,
+                           only_if_static ? (const int*)b->d_sepRet : (const int*)nullptr);
+    }
+    LAUNCH_CHECK("k_update_frame");
     return SD_OK;
 }
 

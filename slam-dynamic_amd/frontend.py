@@ -79,6 +79,13 @@ def lib():
         L.sd_batch_copy_frame.argtypes = [vp, i, i, vp]
         L.sd_batch_matches_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i)]
         L.sd_batch_download_matches.argtypes = [vp, i, vp, vp, i, C.POINTER(i), C.POINTER(i)]
+        L.sd_box_track.argtypes = [vp, i, i, vp, i, vp, vp, vp, i, i, vp, vp, vp, C.POINTER(i)]
+        L.sd_batch_first_separate.argtypes = [vp, i, vp, vp, vp, vp, vp]
+        L.sd_batch_download_boxes.argtypes = [vp, i, C.POINTER(i), vp, vp, vp, vp, vp, vp, i, C.POINTER(i), C.POINTER(i)]
+        L.sd_batch_download_dynamic.argtypes = [vp, i, vp, vp, vp, vp, i, C.POINTER(i)]
+        L.sd_batch_separate.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.sd_batch_download_separate.argtypes = [vp, i, C.POINTER(i), vp, vp, vp, i]
+        L.sd_batch_update_frame.argtypes = [vp, i, vp]
         L.sd_cvt_gray_device.argtypes = [vp, i, i, sz, sz, i, i, vp, sz, sz, i, vp]
         L.sd_depth_to_f32_device.argtypes = [vp, i, i, sz, f, vp, i, sz, vp]
         L.sd_descriptor_distance.argtypes = [vp, vp]
@@ -285,6 +292,55 @@ class Batch:
         check(lib().sd_batch_download_matches(self.h, pair, _p(match), _p(pairs), self.cap, C.byref(npairs), C.byref(nm)))
         return match, pairs[:npairs.value].copy(), nm.value
 
+    # -- dynamic-object cull: Frame::firstSeparate, Tracking::Separate, Frame::UpdateFrame
+    def first_separate(self, slots, boxes_list, box_idx_list, stream=None):
+        n = len(slots)
+        sl = np.ascontiguousarray(slots, np.int32)
+        bx = np.zeros((n, MAXB, 4), np.float64); bi = np.zeros((n, MAXB), np.int32); nb = np.zeros(n, np.int32)
+        for k in range(n):
+            m = len(boxes_list[k]); nb[k] = m
+            if m:
+                bx[k, :m] = np.asarray(boxes_list[k], np.float64).reshape(m, 4); bi[k, :m] = box_idx_list[k]
+        check(lib().sd_batch_first_separate(self.h, n, _p(sl), _p(bx), _p(nb), _p(bi), C.c_void_p(stream or 0)))
+
+    def download_boxes(self, slot):
+        nb = C.c_int(); n_all = C.c_int(); n_s = C.c_int()
+        bx = np.zeros((MAXB, 4), np.float64); bi = np.zeros(MAXB, np.int32); bs = np.zeros(MAXB, np.int32)
+        ko = np.zeros(MAXB, np.int32); st = np.zeros(MAXB + 1, np.int32); it = np.zeros(2 * self.cap, np.int32)
+        check(lib().sd_batch_download_boxes(self.h, slot, C.byref(nb), _p(bx), _p(bi), _p(bs), _p(ko), _p(st), _p(it), len(it),
+                                            C.byref(n_all), C.byref(n_s)))
+        m = nb.value
+        return dict(nb=m, boxes=bx[:m].copy(), box_idx=bi[:m].copy(), box_status=bs[:m].copy(), kept_orig=ko[:m].copy(),
+                    boxStart=st[:m + 1].copy(), boxItems=it[:st[m]].copy(), n_all=n_all.value, n_static=n_s.value)
+
+    def download_dynamic(self, slot):
+        kp = np.zeros(self.cap, KP_DTYPE); desc = np.zeros((self.cap, 32), np.uint8)
+        ur = np.zeros(self.cap, np.float32); dep = np.zeros(self.cap, np.float32)
+        n = C.c_int()
+        check(lib().sd_batch_download_dynamic(self.h, slot, _p(kp), _p(desc), _p(ur), _p(dep), self.cap, C.byref(n)))
+        m = n.value
+        return kp[:m].copy(), desc[:m].copy(), ur[:m].copy(), dep[:m].copy()
+
+    def separate(self, cur_index, ref_index, HorF, flag, last_box_idx, last_box_status, stream=None):
+        n = len(cur_index)
+        ci = np.ascontiguousarray(cur_index, np.int32); ri = np.ascontiguousarray(ref_index, np.int32)
+        M = np.ascontiguousarray(HorF, np.float32).reshape(n, 9); fl = np.ascontiguousarray(flag, np.int32)
+        li = np.zeros((n, MAXB), np.int32); ls = np.zeros((n, MAXB), np.int32); nl = np.zeros(n, np.int32)
+        for k in range(n):
+            m = len(last_box_idx[k]); nl[k] = m
+            li[k, :m] = last_box_idx[k]; ls[k, :m] = last_box_status[k]
+        check(lib().sd_batch_separate(self.h, n, _p(ci), _p(ri), _p(M), _p(fl), _p(li), _p(ls), _p(nl), C.c_void_p(stream or 0)))
+
+    def download_separate(self, pair):
+        ret = C.c_int(); ds = np.zeros(MAXB + 1, np.int32)
+        dyn = np.zeros(2 * self.cap, np.int32); mt = np.zeros((2 * self.cap, 2), np.int32)
+        check(lib().sd_batch_download_separate(self.h, pair, C.byref(ret), _p(ds), _p(dyn), _p(mt), len(dyn)))
+        n = ds[MAXB]
+        return ret.value, ds, dyn[:n].copy(), mt[:n].copy()
+
+    def update_frame(self, only_if_static=True, stream=None):
+        check(lib().sd_batch_update_frame(self.h, int(only_if_static), C.c_void_p(stream or 0)))
+
     # -- profiling
     def set_profiling(self, on):
         check(lib().sd_batch_set_profiling(self.h, int(bool(on))))
@@ -301,6 +357,24 @@ class Batch:
             check(lib().sd_batch_kernel_times(self.h, i, C.byref(name), C.byref(ms), C.byref(cnt)))
             out[name.value.decode()] = (ms.value, cnt.value)
         return out
+
+
+MAXB = 32
+
+
+def box_track(boxes, last_objects, last_box_idx, last_omit, last_velocity, img_cols, img_rows, cap=MAXB):
+    """Frame::boxTrack (src/Frame.cc:481-552) through the C ABI (host code)."""
+    n = len(boxes)
+    bx = np.zeros((cap, 4), np.float64); bx[:n] = np.asarray(boxes, np.float64).reshape(n, 4)
+    lo = np.ascontiguousarray(last_objects, np.float64).reshape(-1, 4)
+    li = np.ascontiguousarray(last_box_idx, np.int32); lm = np.ascontiguousarray(last_omit, np.uint8)
+    lv = np.ascontiguousarray(last_velocity, np.float64).reshape(-1, 2)
+    idx = np.zeros(cap, np.int32); om = np.zeros(cap, np.uint8); vel = np.zeros((cap, 2), np.float64)
+    n2 = C.c_int()
+    check(lib().sd_box_track(_p(bx), n, cap, _p(lo), len(lo), _p(li), _p(lm), _p(lv), int(img_cols), int(img_rows), _p(idx), _p(om),
+                             _p(vel), C.byref(n2)))
+    m = n2.value
+    return bx[:m].copy(), idx[:m].copy(), om[:m].copy(), vel[:m].copy()
 
 
 def make_camera(cfg):
