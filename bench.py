@@ -137,7 +137,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="frames per step per GPU")
-    ap.add_argument("--workload", choices=["rgbd", "stereo"], default="rgbd")
+    ap.add_argument("--workload", choices=["rgbd", "stereo", "rgbd-cull"], default="rgbd")
     ap.add_argument("--cpu-frames", type=int, default=96, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents")
     ap.add_argument("--streams", type=int, default=1,
@@ -170,9 +170,15 @@ def main():
     if B % S:
         raise SystemExit("--batch must be a multiple of --streams")
     Bs = B // S
+    cull = args.workload == "rgbd-cull"
+    if cull:
+        args.workload = "rgbd"
     if args.workload == "rgbd":
         cfg = synth.KITTI03_RGBD
         workload_name = "KITTI-03 RGB-D 1241x376, 2000 feat/frame, ORB extract+match, no semantic mask (BASELINE configs[1])"
+        if cull:
+            workload_name = ("RGB-D 1241x376, 2000 feat/frame, extract + match + dynamic cull with 3 given boxes/frame "
+                             "(firstSeparate, Separate vs the frame 0.2 s back, UpdateFrame); detector off (BASELINE configs[3] data path)")
         imgs_per_frame, th = 1, 15.0
     else:
         cfg = synth.KITTI_STEREO
@@ -218,6 +224,26 @@ def main():
     cur_idx = np.arange(Bs, dtype=np.int32) * imgs_per_frame
     last_idx = np.concatenate([[n_img], cur_idx[:-1]]).astype(np.int32)
     depth_factor = float(np.float32(1.0) / np.float32(cfg.get("depth_map_factor", 1.0)))
+    cull_state = None
+    if cull:
+        # detector boxes per frame: precomputed (boxTrack is host code on a per-sequence recurrence; ids are stable here)
+        bl, il = [], []
+        for t in range(B):
+            rows = synth.boxes_for_frame(seq, t, cfg)
+            bl.append(synth.rows_to_rects(rows)); il.append(np.arange(len(rows), dtype=np.int32))
+        dt = 2                                                    # reference frame = 0.2 s older at 10 fps
+        sc = 1.01 ** dt
+        Hm = np.array([[sc, 0, (3.0 * dt - cfg["cx"]) * sc + cfg["cx"]], [0, sc, -cfg["cy"] * sc + cfg["cy"]], [0, 0, 1]], np.float32)
+        cull_state = []
+        for k in range(S):
+            f0 = k * Bs
+            packed = fe.Batch.pack_boxes(bl[f0:f0 + Bs], il[f0:f0 + Bs])
+            npair = Bs - dt
+            li = np.zeros((npair, fe.MAXB), np.int32); ls = np.full((npair, fe.MAXB), -1, np.int32); nl = np.full(npair, 3, np.int32)
+            li[:, :3] = np.arange(3)
+            cull_state.append(dict(packed=packed, slots=np.arange(Bs, dtype=np.int32), cur=np.arange(dt, Bs, dtype=np.int32),
+                                   ref=np.arange(0, Bs - dt, dtype=np.int32), H=np.tile(Hm.reshape(1, 9), (npair, 1)),
+                                   flag=np.ones(npair, np.int32), last=(li, ls, nl)))
     recs = None
     if dist is not None:
         recs = []
@@ -236,12 +262,20 @@ def main():
             bt.rgbd_from_u16(d_depth[f0:].data_ptr(), W, W * H, Bs, depth_factor, cfg["bf"], st)
         else:
             bt.stereo_match(Bs, cfg["bf"], cfg["fx"], st)
+        if cull:
+            cs = cull_state[k]
+            bt.first_separate(cs["slots"], None, None, stream=st, packed=cs["packed"])
         bt.assign_grid(n_img, cam, st)
         bt.unproject(imgs_per_frame, Bs, cam, I, st)
         if first:
             bt.search_by_projection(cur_idx[1:], last_idx[1:], I[1:], I[1:], cam, th, False, True, stream=st)
         else:
             bt.search_by_projection(cur_idx, last_idx, I, I, cam, th, False, True, stream=st)
+        if cull:
+            cs = cull_state[k]
+            bt.separate(cs["cur"], cs["ref"], cs["H"], cs["flag"], None, None, stream=st, packed_last=cs["last"])
+            bt.update_frame(True, st)
+            bt.assign_grid(n_img, cam, st)                       # UpdateFeaturesToGrid
         bt.copy_frame(int(cur_idx[-1]), n_img, st)
 
     def step(first=False):

@@ -203,6 +203,19 @@ int sd_batch_download_separate(sd_batch* b, int pair, int32_t* ret, int32_t* dyn
  * sd_batch_assign_grid afterwards (UpdateFeaturesToGrid). */
 int sd_batch_update_frame(sd_batch* b, int only_if_static, void* stream);
 
+/* Reference-frame queue of the dynamic block of Tracking::Track_new (src/Tracking.cc:620-666, 952-959; q_frame,
+ * Tracking.h:109): host logic.  candidate(): oldest queued frame more than 0.2 s older than the current one
+ * that has boxes (box-less fronts are dropped), or -1; reject(): TrackHomo failed on it, pop unless last;
+ * push(): after a tracked frame, keep at most 0.3*fps frames (max_frames = Camera.fps). */
+typedef struct sd_refqueue sd_refqueue;
+int sd_refqueue_create(sd_refqueue** out);
+int sd_refqueue_destroy(sd_refqueue* q);
+int sd_refqueue_clear(sd_refqueue* q);
+int sd_refqueue_size(const sd_refqueue* q, int* n);
+int sd_refqueue_candidate(sd_refqueue* q, double cur_timestamp, int cur_has_boxes, int* slot);
+int sd_refqueue_reject(sd_refqueue* q, int* again);
+int sd_refqueue_push(sd_refqueue* q, double timestamp, int slot, int has_boxes, int max_frames, int* evicted_slot);
+
 /* ---- Tracking::GrabImage* preprocessing (src/Tracking.cc:170-343) ---- */
 /* cvtColor(RGB|BGR|RGBA|BGRA -> GRAY); rgb_order = Camera.RGB.  channels 3 or 4. */
 int sd_cvt_gray_device(const uint8_t* d_src, int width, int height, size_t src_stride, size_t src_pitch, int channels,

@@ -90,6 +90,8 @@ struct sd_batch {
     int2* d_sepPairs = nullptr;
     int itemsCap = 0;
     int nSepPairs = 0;
+    std::vector<SdFrameBoxes> hostBoxes;     // staging that must outlive the async uploads
+    std::vector<int2> hostPairs;
     uint8_t* d_stage = nullptr;    // staging for host-image uploads
     size_t stageBytes = 0;
     int qtMN = 0, qtSortP = 0;
@@ -1035,7 +1037,8 @@ int sd_batch_first_separate(sd_batch* b, int n_frames, const int32_t* slots, con
     hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
     b->lastStream = s;
     if (n_frames == 0) return SD_OK;
-    std::vector<SdFrameBoxes> h(n_frames);
+    std::vector<SdFrameBoxes>& h = b->hostBoxes;
+    h.resize(n_frames);
     for (int f = 0; f < n_frames; f++) {
         if (!slot_ok(b, slots[f])) return set_err(SD_ERR_STATE, "first_separate: slot holds no results");
         if (n_boxes[f] < 0 || n_boxes[f] > SD_MAXB) return set_err(SD_ERR_CAPACITY, "more than 32 boxes in a frame");
@@ -1050,7 +1053,6 @@ int sd_batch_first_separate(sd_batch* b, int n_frames, const int32_t* slots, con
     for (int f = 0; f < n_frames; f++)
         HIPCHK(hipMemcpyAsync(b->d_fb + slots[f], &h[f], sizeof(SdFrameBoxes), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(b->d_slots, slots, (size_t)n_frames * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));        // h[] is pageable stack/heap memory about to go out of scope
     {
         ProfScope ps(b, s, K_BOXSEP);
         const size_t lds = (size_t)b->plan.kpCap * 8 + 64;
@@ -1116,7 +1118,8 @@ int sd_batch_separate(sd_batch* b, int n_pairs, const int32_t* cur_index, const 
     b->lastStream = s;
     b->nSepPairs = 0;
     if (n_pairs == 0) return SD_OK;
-    std::vector<int2> idx(n_pairs);
+    std::vector<int2>& idx = b->hostPairs;
+    idx.resize(n_pairs);
     for (int p = 0; p < n_pairs; p++) {
         if (!slot_ok(b, cur_index[p]) || !slot_ok(b, ref_index[p])) return set_err(SD_ERR_STATE, "separate: slot holds no results");
         if (flag[p] != 1 && flag[p] != 2) return set_err(SD_ERR_INVALID, "separate: flag must be 1 (H) or 2 (F)");
@@ -1129,7 +1132,6 @@ int sd_batch_separate(sd_batch* b, int n_pairs, const int32_t* cur_index, const 
     HIPCHK(hipMemcpyAsync(b->d_lastIdx, last_box_idx, (size_t)n_pairs * SD_MAXB * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(b->d_lastStatus, last_box_status, (size_t)n_pairs * SD_MAXB * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(b->d_nLast, n_last, (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));        // idx[] is about to go out of scope
     SdSepArgs G;
     G.pairIdx = b->d_sepPairs; G.HorF = b->d_HorF; G.flag = b->d_sepFlag; G.lastIdx = b->d_lastIdx; G.lastStatus = b->d_lastStatus;
     G.nLast = b->d_nLast; G.dynStart = b->d_dynStart; G.dynStatus = b->d_dynStatus; G.matches = b->d_sepMatches; G.ret = b->d_sepRet;
@@ -1176,6 +1178,58 @@ int sd_batch_update_frame(sd_batch* b, int only_if_static, void* stream_)
                            only_if_static ? (const int*)b->d_sepRet : (const int*)nullptr);
     }
     LAUNCH_CHECK("k_update_frame");
+    return SD_OK;
+}
+
+
+// ---------------------------------------------------------------- reference-frame queue (Tracking.cc:620-666, 952-959)
+struct sd_refqueue {
+    struct E { double t; int slot; int hasBoxes; };
+    std::vector<E> q;      // front = oldest
+};
+
+int sd_refqueue_create(sd_refqueue** out) { if (!out) return SD_ERR_INVALID; *out = new sd_refqueue(); return SD_OK; }
+int sd_refqueue_destroy(sd_refqueue* q) { delete q; return SD_OK; }
+int sd_refqueue_clear(sd_refqueue* q) { if (!q) return SD_ERR_INVALID; q->q.clear(); return SD_OK; }   // :602-605
+int sd_refqueue_size(const sd_refqueue* q, int* n) { if (!q || !n) return SD_ERR_INVALID; *n = (int)q->q.size(); return SD_OK; }
+
+// The `while(mCurrentFrame.mTimeStamp - q_frame.front().mTimeStamp > 0.2f)` head of the loop (:623-631): drops
+// box-less fronts, then yields the oldest frame more than 0.2 s older than the current one, or -1.
+int sd_refqueue_candidate(sd_refqueue* q, double cur_timestamp, int cur_has_boxes, int* slot)
+{
+    if (!q || !slot) return SD_ERR_INVALID;
+    *slot = -1;
+    if (!cur_has_boxes) return SD_OK;                              // `!mCurrentFrame.objects.empty()` (:622)
+    while (!q->q.empty() && cur_timestamp - q->q.front().t > 0.2f) {
+        if (!q->q.front().hasBoxes) { q->q.erase(q->q.begin()); continue; }   // reference: no emptiness re-check (UB)
+        *slot = q->q.front().slot;
+        return SD_OK;
+    }
+    return SD_OK;
+}
+
+// TrackHomo failed on the candidate (:655-661): pop it unless it is the last element; *again = loop continues.
+int sd_refqueue_reject(sd_refqueue* q, int* again)
+{
+    if (!q || !again) return SD_ERR_INVALID;
+    *again = 0;
+    if (q->q.size() <= 1) return SD_OK;
+    q->q.erase(q->q.begin());
+    *again = 1;
+    return SD_OK;
+}
+
+// After tracking (mState == OK): `if(q_frame.size() >= mMaxFrames * 0.3) q_frame.pop(); q_frame.push(cur)` (:952-959).
+// *evicted_slot = slot of the popped frame (its batch slot can be reused) or -1.
+int sd_refqueue_push(sd_refqueue* q, double timestamp, int slot, int has_boxes, int max_frames, int* evicted_slot)
+{
+    if (!q) return SD_ERR_INVALID;
+    if (evicted_slot) *evicted_slot = -1;
+    if ((double)q->q.size() >= max_frames * 0.3 && !q->q.empty()) {
+        if (evicted_slot) *evicted_slot = q->q.front().slot;
+        q->q.erase(q->q.begin());
+    }
+    q->q.push_back({timestamp, slot, has_boxes});
     return SD_OK;
 }
 

@@ -86,6 +86,13 @@ def lib():
         L.sd_batch_separate.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp, vp]
         L.sd_batch_download_separate.argtypes = [vp, i, C.POINTER(i), vp, vp, vp, i]
         L.sd_batch_update_frame.argtypes = [vp, i, vp]
+        L.sd_refqueue_create.argtypes = [C.POINTER(vp)]
+        L.sd_refqueue_destroy.argtypes = [vp]
+        L.sd_refqueue_clear.argtypes = [vp]
+        L.sd_refqueue_size.argtypes = [vp, C.POINTER(i)]
+        L.sd_refqueue_candidate.argtypes = [vp, C.c_double, i, C.POINTER(i)]
+        L.sd_refqueue_reject.argtypes = [vp, C.POINTER(i)]
+        L.sd_refqueue_push.argtypes = [vp, C.c_double, i, i, i, C.POINTER(i)]
         L.sd_cvt_gray_device.argtypes = [vp, i, i, sz, sz, i, i, vp, sz, sz, i, vp]
         L.sd_depth_to_f32_device.argtypes = [vp, i, i, sz, f, vp, i, sz, vp]
         L.sd_descriptor_distance.argtypes = [vp, vp]
@@ -293,15 +300,20 @@ class Batch:
         return match, pairs[:npairs.value].copy(), nm.value
 
     # -- dynamic-object cull: Frame::firstSeparate, Tracking::Separate, Frame::UpdateFrame
-    def first_separate(self, slots, boxes_list, box_idx_list, stream=None):
-        n = len(slots)
-        sl = np.ascontiguousarray(slots, np.int32)
+    @staticmethod
+    def pack_boxes(boxes_list, box_idx_list):
+        n = len(boxes_list)
         bx = np.zeros((n, MAXB, 4), np.float64); bi = np.zeros((n, MAXB), np.int32); nb = np.zeros(n, np.int32)
         for k in range(n):
             m = len(boxes_list[k]); nb[k] = m
             if m:
                 bx[k, :m] = np.asarray(boxes_list[k], np.float64).reshape(m, 4); bi[k, :m] = box_idx_list[k]
-        check(lib().sd_batch_first_separate(self.h, n, _p(sl), _p(bx), _p(nb), _p(bi), C.c_void_p(stream or 0)))
+        return bx, nb, bi
+
+    def first_separate(self, slots, boxes_list, box_idx_list, stream=None, packed=None):
+        sl = np.ascontiguousarray(slots, np.int32)
+        bx, nb, bi = packed if packed is not None else self.pack_boxes(boxes_list, box_idx_list)
+        check(lib().sd_batch_first_separate(self.h, len(sl), _p(sl), _p(bx), _p(nb), _p(bi), C.c_void_p(stream or 0)))
 
     def download_boxes(self, slot):
         nb = C.c_int(); n_all = C.c_int(); n_s = C.c_int()
@@ -321,14 +333,17 @@ class Batch:
         m = n.value
         return kp[:m].copy(), desc[:m].copy(), ur[:m].copy(), dep[:m].copy()
 
-    def separate(self, cur_index, ref_index, HorF, flag, last_box_idx, last_box_status, stream=None):
+    def separate(self, cur_index, ref_index, HorF, flag, last_box_idx, last_box_status, stream=None, packed_last=None):
         n = len(cur_index)
         ci = np.ascontiguousarray(cur_index, np.int32); ri = np.ascontiguousarray(ref_index, np.int32)
         M = np.ascontiguousarray(HorF, np.float32).reshape(n, 9); fl = np.ascontiguousarray(flag, np.int32)
-        li = np.zeros((n, MAXB), np.int32); ls = np.zeros((n, MAXB), np.int32); nl = np.zeros(n, np.int32)
-        for k in range(n):
-            m = len(last_box_idx[k]); nl[k] = m
-            li[k, :m] = last_box_idx[k]; ls[k, :m] = last_box_status[k]
+        if packed_last is not None:
+            li, ls, nl = packed_last
+        else:
+            li = np.zeros((n, MAXB), np.int32); ls = np.zeros((n, MAXB), np.int32); nl = np.zeros(n, np.int32)
+            for k in range(n):
+                m = len(last_box_idx[k]); nl[k] = m
+                li[k, :m] = last_box_idx[k]; ls[k, :m] = last_box_status[k]
         check(lib().sd_batch_separate(self.h, n, _p(ci), _p(ri), _p(M), _p(fl), _p(li), _p(ls), _p(nl), C.c_void_p(stream or 0)))
 
     def download_separate(self, pair):
@@ -360,6 +375,35 @@ class Batch:
 
 
 MAXB = 32
+
+
+class RefQueue:
+    """q_frame of Tracking (Tracking.h:109) with the reference-frame choice of Track_new (Tracking.cc:620-666)."""
+
+    def __init__(self):
+        self.h = C.c_void_p()
+        check(lib().sd_refqueue_create(C.byref(self.h)))
+
+    def __del__(self):
+        try:
+            lib().sd_refqueue_destroy(self.h)
+        except Exception:
+            pass
+
+    def __len__(self):
+        n = C.c_int(); check(lib().sd_refqueue_size(self.h, C.byref(n))); return n.value
+
+    def clear(self):
+        check(lib().sd_refqueue_clear(self.h))
+
+    def candidate(self, t, has_boxes=True):
+        s = C.c_int(); check(lib().sd_refqueue_candidate(self.h, t, int(has_boxes), C.byref(s))); return s.value
+
+    def reject(self):
+        a = C.c_int(); check(lib().sd_refqueue_reject(self.h, C.byref(a))); return bool(a.value)
+
+    def push(self, t, slot, has_boxes, max_frames):
+        e = C.c_int(); check(lib().sd_refqueue_push(self.h, t, slot, int(has_boxes), max_frames, C.byref(e))); return e.value
 
 
 def box_track(boxes, last_objects, last_box_idx, last_omit, last_velocity, img_cols, img_rows, cap=MAXB):

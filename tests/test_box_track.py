@@ -39,3 +39,51 @@ def test_box_track_first_frame_and_reinjection(fe):
     # a frame later the omitted box is not injected again
     b3, idx3, om3, _ = fe.box_track(cur, b2, idx2, om2, vel2, 640, 480)
     assert idx3.tolist() == [0]
+
+
+def _py_refqueue():
+    """Literal restatement of the q_frame handling (Tracking.cc:620-666, 952-959) for comparison."""
+    class Q:
+        def __init__(self): self.q = []
+        def candidate(self, t, has):
+            if not has: return -1
+            while self.q and t - self.q[0][0] > np.float32(0.2):
+                if not self.q[0][2]:
+                    self.q.pop(0); continue
+                return self.q[0][1]
+            return -1
+        def reject(self):
+            if len(self.q) <= 1: return False
+            self.q.pop(0); return True
+        def push(self, t, slot, has, fps):
+            ev = -1
+            if len(self.q) >= fps * 0.3 and self.q:
+                ev = self.q.pop(0)[1]
+            self.q.append((t, slot, has)); return ev
+    return Q()
+
+
+def test_reference_queue(fe):
+    rng = np.random.default_rng(5)
+    for fps in (10, 30):
+        q, r = fe.RefQueue(), _py_refqueue()
+        t = 0.0
+        for k in range(300):
+            t += 1.0 / fps
+            has = bool(rng.random() < 0.8)
+            c1, c2 = q.candidate(t, has), r.candidate(t, has)
+            assert c1 == c2
+            while c1 >= 0 and rng.random() < 0.3:        # TrackHomo "fails": try the next-oldest frame
+                a1, a2 = q.reject(), r.reject()
+                assert a1 == a2
+                if not a1: break
+                c1, c2 = q.candidate(t, has), r.candidate(t, has)
+                assert c1 == c2
+            if rng.random() < 0.9:                        # mState == OK
+                assert q.push(t, k % 16, has, fps) == r.push(t, k % 16, has, fps)
+            assert len(q) == len(r.q) <= max(1, int(np.ceil(fps * 0.3)))
+    q = fe.RefQueue()
+    for k in range(5):
+        q.push(0.1 * k, k, True, 10)
+    assert len(q) == 3                                     # 0.3 * fps frames at 10 fps
+    assert q.candidate(0.55, True) == 2 and q.candidate(0.55, False) == -1
