@@ -13,6 +13,50 @@ __device__ __forceinline__ int sd_hamming256(const uint4 a0, const uint4 a1, con
            __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
+// Right-image keypoints bucketed by integer row (counting sort in LDS): rowStart[y] .. rowStart[y+1] are the
+// right keypoints with (int)y == y.  The order inside a bucket is irrelevant: the matcher takes the
+// lexicographic minimum of (distance, iR).
+__global__ void __launch_bounds__(256) k_row_sort(const sd_keypoint* __restrict__ kp, const int* __restrict__ count,
+                                                  unsigned short* __restrict__ rowIdx, int* __restrict__ rowStart,
+                                                  int cap, int H)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    int* start = (int*)smem;                 // [H + 1]
+    int* fill = start + H + 8;               // [H]
+    __shared__ int s_carry;
+    const int f = blockIdx.x, img = 2 * f + 1, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ int s_wsum[4];
+    const int N = count[img];
+    const sd_keypoint* k = kp + (size_t)img * cap;
+    for (int y = tid; y < H; y += 256) { start[y] = 0; fill[y] = 0; }
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) { int y = (int)k[i].y; y = min(max(y, 0), H - 1); atomicAdd(&start[y], 1); }
+    __syncthreads();
+    for (int y0 = 0; y0 < H; y0 += 256) {    // exclusive scan over rows, 256 at a time
+        const int y = y0 + tid;
+        const int v = y < H ? start[y] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) s_wsum[wv] = incl;
+        __syncthreads();
+        int base = s_carry;
+        for (int w = 0; w < wv; w++) base += s_wsum[w];
+        if (y < H) start[y] = base + incl - v;
+        __syncthreads();
+        if (tid == 255) s_carry = base + incl;
+        __syncthreads();
+    }
+    if (tid == 0) start[H] = s_carry;
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) {
+        int y = (int)k[i].y; y = min(max(y, 0), H - 1);
+        rowIdx[(size_t)f * cap + start[y] + atomicAdd(&fill[y], 1)] = (unsigned short)i;
+    }
+    for (int y = tid; y <= H; y += 256) rowStart[(size_t)f * (H + 8) + y] = start[y];
+}
+
 // One wave per left keypoint.  Row-band membership (the reference's vRowIndices table, Frame.cc:884-900)
 // is evaluated directly per (left, right) pair: right keypoint iR is a candidate of row yi iff
 // floor(kpY - r) <= yi <= ceil(kpY + r), r = 2*scale[octave]; candidates are visited in increasing iR
@@ -21,6 +65,8 @@ __global__ void __launch_bounds__(256) k_stereo_match(const sd_keypoint* __restr
                                                       const uint8_t* __restrict__ desc, const int* __restrict__ count,
                                                       const uint8_t* __restrict__ pyr, float* __restrict__ uRight,
                                                       float* __restrict__ depthOut, int* __restrict__ sadOut,
+                                                      const unsigned short* __restrict__ rowIdx,
+                                                      const int* __restrict__ rowStart, int bandR,
                                                       const SdDevPlan* __restrict__ PP, float mbf, float fx)
 {
     const SdDevPlan& P = *PP;
@@ -45,7 +91,13 @@ __global__ void __launch_bounds__(256) k_stereo_match(const sd_keypoint* __restr
     const sd_keypoint* kR = kp + (size_t)imgR * P.kpCap;
     const uint8_t* dR = desc + (size_t)imgR * P.kpCap * 32;
     if (!(maxU < 0)) {
-        for (int iR = lane; iR < Nr; iR += 64) {
+        // only right keypoints whose integer row lies within bandR (>= 2*scale_max + 1) rows can contain yi
+        const int H0 = P.lv[0].H;
+        const int* rs = rowStart + (size_t)f * (H0 + 8);
+        const unsigned short* ridx = rowIdx + (size_t)f * P.kpCap;
+        const int p0 = rs[max(yi - bandR, 0)], p1 = rs[min(yi + bandR, H0 - 1) + 1];
+        for (int p = p0 + lane; p < p1; p += 64) {
+            const int iR = ridx[p];
             const sd_keypoint k = kR[iR];
             const float r = 2.0f * P.lv[k.octave].scale;
             const int maxr = (int)ceilf(k.y + r), minr = (int)floorf(k.y - r);

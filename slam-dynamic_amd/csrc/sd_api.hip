@@ -65,6 +65,8 @@ struct sd_batch {
     float* d_uright = nullptr;
     float* d_depth = nullptr;
     int* d_sad = nullptr;
+    unsigned short* d_rowIdx = nullptr;   // right keypoints bucketed by row (stereo)
+    int* d_rowStart = nullptr;
     short* d_cellOf = nullptr;      // grid cell of every keypoint
     unsigned short* d_sortedIdx = nullptr;   // keypoint indices sorted by (cell, index)
     unsigned short* d_cellStart = nullptr;   // [maxImages][3072 + 8]
@@ -202,7 +204,7 @@ static void batch_free(sd_batch* b)
                     b->d_pcand, b->d_pncand, b->d_match, b->d_pairs, b->d_npairs, b->d_nmatch, b->d_pose, b->d_pairIdx, b->d_sortedIdx, b->d_cellStart,
                     b->d_fb, b->d_boxItems, b->d_kpT, b->d_descT, b->d_urT, b->d_depT, b->d_slots, b->d_HorF, b->d_sepFlag,
                     b->d_lastIdx, b->d_lastStatus, b->d_nLast, b->d_dynStart, b->d_dynStatus, b->d_sepMatches, b->d_sepRet,
-                    b->d_sepPairs, b->d_kpD, b->d_descD, b->d_urD, b->d_depD};
+                    b->d_sepPairs, b->d_kpD, b->d_descD, b->d_urD, b->d_depD, b->d_rowIdx, b->d_rowStart};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& r : b->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : b->pool) (void)hipEventDestroy(e);
@@ -280,6 +282,8 @@ int sd_batch_create(sd_batch** out, sd_extractor* ex, int width, int height, int
     ALLOC(b->d_uright, nI * P.kpCap * 4);
     ALLOC(b->d_depth, nI * P.kpCap * 4);
     ALLOC(b->d_sad, nI * P.kpCap * 4);
+    ALLOC(b->d_rowIdx, nI * P.kpCap * 2);
+    ALLOC(b->d_rowStart, nI * (size_t)(P.lv[0].H + 8) * 4);
     ALLOC(b->d_cellOf, nI * P.kpCap * 2);
     ALLOC(b->d_sortedIdx, nI * P.kpCap * 2);
     ALLOC(b->d_cellStart, nI * (SD_GRID_CELLS + 8) * 2);
@@ -590,11 +594,21 @@ int sd_batch_stereo_match(sd_batch* b, int n_frames, float mbf, float fx, void* 
     hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
     b->lastStream = s;
     if (n_frames == 0) return SD_OK;
+    const int H0 = b->plan.lv[0].H;
+    // a right keypoint's band is floor(y - r) .. ceil(y + r), r = 2*scale[octave]: +2 covers floor/ceil and (int)y
+    const int bandR = (int)ceilf(2.0f * b->plan.lv[b->plan.nlevels - 1].scale) + 2;
+    {
+        ProfScope ps(b, s, K_STEREO);
+        const size_t lds = (size_t)(2 * H0 + 16) * 4;
+        hipLaunchKernelGGL(k_row_sort, dim3(n_frames), dim3(256), lds, s, b->d_kp, b->d_count, b->d_rowIdx, b->d_rowStart,
+                           b->plan.kpCap, H0);
+    }
+    LAUNCH_CHECK("k_row_sort");
     {
         ProfScope ps(b, s, K_STEREO);
         dim3 grd((b->plan.kpCap + 3) / 4, n_frames);
         hipLaunchKernelGGL(k_stereo_match, grd, dim3(256), 0, s, b->d_kp, b->d_desc, b->d_count, b->d_pyr, b->d_uright,
-                           b->d_depth, b->d_sad, b->d_plan, mbf, fx);
+                           b->d_depth, b->d_sad, b->d_rowIdx, b->d_rowStart, bandR, b->d_plan, mbf, fx);
     }
     LAUNCH_CHECK("k_stereo_match");
     {
