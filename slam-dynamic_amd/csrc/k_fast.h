@@ -34,187 +34,200 @@ __device__ __forceinline__ int sd_wave_append(bool pred, int* counter)
     return pred ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
 }
 
-__global__ void __launch_bounds__(256) k_fast_cells_staged(const uint8_t* __restrict__ pyr,
-                                                           const SdCell* __restrict__ cells,
-                                                           uint32_t* __restrict__ cellList, int* __restrict__ cellCount,
-                                                           const SdDevPlan* __restrict__ PP)
+// One workgroup of NT threads per cell.  The cost of a cell is dominated by latencies (window fetch, LDS
+// round trips between the short phases), so small workgroups with a small LDS footprint (lists sized by the
+// plan's largest scan area) are used to keep many independent cells in flight per CU.
+template <int NT>
+__global__ void __launch_bounds__(NT) k_fast_cells_staged(const uint8_t* __restrict__ pyr,
+                                                          const SdCell* __restrict__ cells,
+                                                          uint32_t* __restrict__ cellList, int* __restrict__ cellCount,
+                                                          const SdDevPlan* __restrict__ PP, int listCap)
 {
     const SdDevPlan& P = *PP;
     __shared__ __align__(16) uint8_t tile[SD_FS_MAXWIN * SD_FS_TW];
     __shared__ __align__(16) uint8_t score[SD_FS_SW * SD_FS_SW];
-    __shared__ unsigned short list1[SD_FS_MAXSCAN];
-    __shared__ unsigned short list2[SD_FS_MAXSCAN];
-    __shared__ int s_cnt1, s_cnt2, s_any, s_wsum[4];
-    const int img = blockIdx.y;
-    const SdCell c = cells[blockIdx.x];
-    const SdLevel& g = P.lv[c.level];
-    const int ww = c.x1 - c.x0, wh = c.y1 - c.y0;
-    const int sw = ww - 6, sh = wh - 6;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (sw <= 0 || sh <= 0) { if (tid == 0) cellCount[(size_t)img * P.cellTotal + blockIdx.x] = 0; return; }
-    if (tid == 0) { s_cnt1 = 0; s_cnt2 = 0; s_any = 0; }
-    // ---- phase 0
-    const uint8_t* src = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)(SD_EDGE + c.y0) * g.stride +
-                         SD_XOFF + c.x0 - 1;
-    uint32_t* tileW = (uint32_t*)tile;
-    for (int i = tid; i < wh * 14; i += 256) {
-        const int y = i / 14, wd = i - y * 14;
-        tileW[i] = *(const sd_u32_unaligned*)(src + (size_t)y * g.stride + 4 * wd);
-    }
-    uint32_t* scoreW = (uint32_t*)score;
-    for (int i = tid; i < SD_FS_SW * SD_FS_SW / 4; i += 256) scoreW[i] = 0;
-    __syncthreads();
+    extern __shared__ __align__(16) unsigned char dyn_smem[];
+    unsigned short* list1 = (unsigned short*)dyn_smem;              // [listCap]
+    unsigned short* list2 = list1 + listCap;                        // [listCap]
+    unsigned* kept = (unsigned*)(list2 + listCap);                  // [listCap / 4 + 4] NMS maxima: (sy<<16)|(sx<<8)|score
+    __shared__ int s_cnt1, s_cnt2, s_cnt3, s_any;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int cellTotal = P.cellTotal;
     const int T = P.minTh;
-    // ---- phase 1: compass quick test, 4 px per thread
-    const int ng = (sw + 3) >> 2;
-    const int nitems = sh * ng;
-    for (int it0 = 0; it0 < nitems; it0 += 256) {
-        const int it = it0 + tid;
-        const bool live = it < nitems;
-        int sy = 0, gq = 0;
-        uint32_t C = 0, E = 0, Wst = 0, N = 0, S = 0;
-        if (live) {
-            sy = it / ng; gq = it - sy * ng;
-            const uint32_t* row = tileW + (sy + 3) * 14 + gq;
-            const uint32_t w0 = row[0], w1 = row[1], w2 = row[2];
-            C = w1;
-            E = __builtin_amdgcn_alignbyte(w2, w1, 3);
-            Wst = __builtin_amdgcn_alignbyte(w1, w0, 1);
-            N = tileW[sy * 14 + gq + 1];
-            S = tileW[(sy + 6) * 14 + gq + 1];
+    const uint32_t T2 = (uint32_t)T | ((uint32_t)T << 16);
+    uint32_t* tileW = (uint32_t*)tile;
+    uint32_t* scoreW = (uint32_t*)score;
+    {
+        const int img = blockIdx.y, ci = blockIdx.x;
+        const SdCell c = cells[ci];
+        const SdLevel& g = P.lv[c.level];
+        const int ww = c.x1 - c.x0, wh = c.y1 - c.y0;
+        const int sw = ww - 6, sh = wh - 6;
+        if (sw <= 0 || sh <= 0) { if (tid == 0) cellCount[(size_t)img * cellTotal + ci] = 0; return; }
+        {
+            const uint8_t* src = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)(SD_EDGE + c.y0) * g.stride +
+                                 SD_XOFF + c.x0 - 1;
+            const int wd = tid & 15;
+            for (int y = tid >> 4; y < wh; y += NT / 16)
+                if (wd < 14) tileW[y * 14 + wd] = *(const sd_u32_unaligned*)(src + (size_t)y * g.stride + 4 * wd);
         }
+        // only the frame and the scanned rows of the score tile are ever read: rows 0 .. sh+1
+        for (int i = tid; i < (sh + 2) * (SD_FS_SW / 4); i += NT) scoreW[i] = 0;
+        if (tid == 0) { s_cnt1 = 0; s_cnt2 = 0; s_cnt3 = 0; s_any = 0; }
+        __syncthreads();
+        // ---- phase 1: compass quick test, 4 px per thread, packed 2 x i16 arithmetic.
+        // With sign words dX = (X - lo) [sign set <=> X darker than v-T] the adjacent-pair test over the cycle
+        // S-E-N-W collapses to (dS|dN) & (dE|dW); same for the brighter side with (hi - X).
+        const int ng = (sw + 3) >> 2;
+        const int shift = ng <= 8 ? 3 : 4;                 // items per scan row = 1 << shift (no division)
+        const int nitems = sh << shift;
+        for (int it0 = 0; it0 < nitems; it0 += NT) {
+            const int it = it0 + tid;
+            const int sy = it >> shift, gq = it & ((1 << shift) - 1);
+            const bool live = it < nitems && gq < ng;
+            unsigned pmask = 0;
+            if (live) {
+                const uint32_t* row = tileW + (sy + 3) * 14 + gq;
+                const uint32_t w0 = row[0], w1 = row[1], w2 = row[2];
+                const uint32_t C = w1;
+                const uint32_t E = __builtin_amdgcn_alignbyte(w2, w1, 3);
+                const uint32_t Wst = __builtin_amdgcn_alignbyte(w1, w0, 1);
+                const uint32_t N = tileW[sy * 14 + gq + 1];
+                const uint32_t S = tileW[(sy + 6) * 14 + gq + 1];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int cc = (C >> (8 * j)) & 255;
-            const int lo = cc - T, hi = cc + T;
-            const int e = (E >> (8 * j)) & 255, w = (Wst >> (8 * j)) & 255, n = (N >> (8 * j)) & 255, s = (S >> (8 * j)) & 255;
-            // ring order S(0), E(4), N(8), W(12)
-            const unsigned dk = (unsigned)(s < lo) | ((unsigned)(e < lo) << 1) | ((unsigned)(n < lo) << 2) | ((unsigned)(w < lo) << 3);
-            const unsigned br = (unsigned)(s > hi) | ((unsigned)(e > hi) << 1) | ((unsigned)(n > hi) << 2) | ((unsigned)(w > hi) << 3);
-            const unsigned dr = dk | (dk << 4), bq = br | (br << 4);
-            const bool pass = live && (4 * gq + j < sw) && ((((dr & (dr >> 1)) | (bq & (bq >> 1))) & 0xF) != 0);
-            const int slot = sd_wave_append(pass, &s_cnt1);
-            if (pass) list1[slot] = (unsigned short)((sy << 8) | (4 * gq + j));
+                for (int half = 0; half < 2; half++) {
+                    const uint32_t sel = half ? 0x0C030C02u : 0x0C010C00u;   // bytes (0,1) or (2,3) -> 2 x u16
+                    const uint32_t c2 = __builtin_amdgcn_perm(0u, C, sel), e2 = __builtin_amdgcn_perm(0u, E, sel);
+                    const uint32_t w2_ = __builtin_amdgcn_perm(0u, Wst, sel), n2 = __builtin_amdgcn_perm(0u, N, sel);
+                    const uint32_t s2 = __builtin_amdgcn_perm(0u, S, sel);
+                    typedef short v2s __attribute__((ext_vector_type(2)));
+                    const v2s lo = __builtin_bit_cast(v2s, c2) - __builtin_bit_cast(v2s, T2);
+                    const v2s hi = __builtin_bit_cast(v2s, c2) + __builtin_bit_cast(v2s, T2);
+                    const v2s vs = __builtin_bit_cast(v2s, s2), vn = __builtin_bit_cast(v2s, n2);
+                    const v2s ve = __builtin_bit_cast(v2s, e2), vw = __builtin_bit_cast(v2s, w2_);
+                    const uint32_t dV = __builtin_bit_cast(uint32_t, vs - lo) | __builtin_bit_cast(uint32_t, vn - lo);
+                    const uint32_t dH = __builtin_bit_cast(uint32_t, ve - lo) | __builtin_bit_cast(uint32_t, vw - lo);
+                    const uint32_t bV = __builtin_bit_cast(uint32_t, hi - vs) | __builtin_bit_cast(uint32_t, hi - vn);
+                    const uint32_t bH = __builtin_bit_cast(uint32_t, hi - ve) | __builtin_bit_cast(uint32_t, hi - vw);
+                    const uint32_t ps = (dV & dH) | (bV & bH);               // sign bits 15 / 31
+                    pmask |= (((ps >> 15) & 1u) | ((ps >> 30) & 2u)) << (2 * half);
+                }
+                const int nvalid = sw - 4 * gq;                               // pixels of this group inside the scan
+                if (nvalid < 4) pmask &= (1u << nvalid) - 1u;
+            }
+            // one slot reservation per wave: exclusive scan of the per-lane counts, then up to 4 writes
+            const int cnt = __popc(pmask);
+            int incl = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            const int wtot = __shfl(incl, 63, 64);
+            int base = 0;
+            if (wtot) {
+                if (lane == 63) base = atomicAdd(&s_cnt1, wtot);
+                base = __shfl(base, 63, 64);
+            }
+            int slot = base + incl - cnt;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (pmask & (1u << j)) list1[slot++] = (unsigned short)((sy << 8) | (4 * gq + j));
         }
-    }
-    __syncthreads();
-    // ---- phase 2: exact ring test on the survivors
-    const int n1 = s_cnt1;
-    for (int i0 = 0; i0 < n1; i0 += 256) {
-        const int i = i0 + tid;
-        bool corner = false;
-        unsigned short ent = 0;
-        if (i < n1) {
-            ent = list1[i];
-            const int sx = ent & 255, sy = ent >> 8;
-            const uint8_t* p = tile + (sy + 3) * SD_FS_TW + sx + 4;
-            const int v = p[0];
-            const int a = T - v, b = v + T;      // sign(r + a) -> darker ; sign(b - r) -> brighter
-            unsigned dark = 0, bright = 0;
-            const int S = SD_FS_TW;
+        __syncthreads();
+        // ---- phase 2: exact ring test on the survivors
+        const int n1 = s_cnt1;
+        for (int i0 = 0; i0 < n1; i0 += NT) {
+            const int i = i0 + tid;
+            bool corner = false;
+            unsigned short ent = 0;
+            if (i < n1) {
+                ent = list1[i];
+                const int sx = ent & 255, sy = ent >> 8;
+                const uint8_t* p = tile + (sy + 3) * SD_FS_TW + sx + 4;
+                const int v = p[0];
+                const int a = T - v, b = v + T;      // sign(r + a) -> darker ; sign(b - r) -> brighter
+                unsigned dark = 0, bright = 0;
+                const int S = SD_FS_TW;
 #define SD_RING(off) { const int r = p[off]; dark = __builtin_amdgcn_alignbit(dark, (unsigned)(r + a), 31); \
                        bright = __builtin_amdgcn_alignbit(bright, (unsigned)(b - r), 31); }
-            SD_RING(3 * S) SD_RING(3 * S + 1) SD_RING(2 * S + 2) SD_RING(S + 3) SD_RING(3) SD_RING(-S + 3)
-            SD_RING(-2 * S + 2) SD_RING(-3 * S + 1) SD_RING(-3 * S) SD_RING(-3 * S - 1) SD_RING(-2 * S - 2)
-            SD_RING(-S - 3) SD_RING(-3) SD_RING(S - 3) SD_RING(2 * S - 2) SD_RING(3 * S - 1)
+                SD_RING(3 * S) SD_RING(3 * S + 1) SD_RING(2 * S + 2) SD_RING(S + 3) SD_RING(3) SD_RING(-S + 3)
+                SD_RING(-2 * S + 2) SD_RING(-3 * S + 1) SD_RING(-3 * S) SD_RING(-3 * S - 1) SD_RING(-2 * S - 2)
+                SD_RING(-S - 3) SD_RING(-3) SD_RING(S - 3) SD_RING(2 * S - 2) SD_RING(3 * S - 1)
 #undef SD_RING
-            corner = sd_has9(dark & 0xFFFFu) || sd_has9(bright & 0xFFFFu);
+                corner = sd_has9(dark & 0xFFFFu) || sd_has9(bright & 0xFFFFu);
+            }
+            const int slot = sd_wave_append(corner, &s_cnt2);
+            if (corner) list2[slot] = ent;
         }
-        const int slot = sd_wave_append(corner, &s_cnt2);
-        if (corner) list2[slot] = ent;
-    }
-    __syncthreads();
-    // ---- phase 3: corner score into the score tile
-    const int n2 = s_cnt2;
-    for (int i = tid; i < n2; i += 256) {
-        const unsigned short ent = list2[i];
-        const int sx = ent & 255, sy = ent >> 8;
-        const uint8_t* p = tile + (sy + 3) * SD_FS_TW + sx + 4;
-        const int S = SD_FS_TW;
-        const int v = p[0];
-        int d[16];
-        d[0] = v - p[3 * S];       d[1] = v - p[3 * S + 1];   d[2] = v - p[2 * S + 2];   d[3] = v - p[S + 3];
-        d[4] = v - p[3];           d[5] = v - p[-S + 3];      d[6] = v - p[-2 * S + 2];  d[7] = v - p[-3 * S + 1];
-        d[8] = v - p[-3 * S];      d[9] = v - p[-3 * S - 1];  d[10] = v - p[-2 * S - 2]; d[11] = v - p[-S - 3];
-        d[12] = v - p[-3];         d[13] = v - p[S - 3];      d[14] = v - p[2 * S - 2];  d[15] = v - p[3 * S - 1];
-        int mn2[16], mx2[16], mn4[16], mx4[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-        for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
-        int A = -1000, B = 1000;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            A = max(A, min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]));
-            B = min(B, max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]));
-        }
-        const int s = max(A, -B) - 1;                       // >= T for a corner at T
-        score[(sy + 1) * SD_FS_SW + sx + 1] = (uint8_t)s;
-    }
-    __syncthreads();
-    // ---- phase 4: 3x3 NMS over the corner list (zero frame = pixels outside the scanned area)
-    unsigned supp = 0;
-    int any = 0;
-    {
-        int k = 0;
-        for (int i = tid; i < n2; i += 256, k++) {
+        __syncthreads();
+        // ---- phase 3: corner score into the score tile
+        const int n2 = s_cnt2;
+        for (int i = tid; i < n2; i += NT) {
             const unsigned short ent = list2[i];
-            const uint8_t* q = score + ((ent >> 8) + 1) * SD_FS_SW + (ent & 255) + 1;
-            const int s = q[0];
-            const bool ok = s > q[-SD_FS_SW - 1] && s > q[-SD_FS_SW] && s > q[-SD_FS_SW + 1] && s > q[-1] && s > q[1] &&
-                            s > q[SD_FS_SW - 1] && s > q[SD_FS_SW] && s > q[SD_FS_SW + 1];
-            if (!ok) supp |= 1u << k;
-            any |= (ok && s >= P.iniTh);
+            const int sx = ent & 255, sy = ent >> 8;
+            const uint8_t* p = tile + (sy + 3) * SD_FS_TW + sx + 4;
+            const int S = SD_FS_TW;
+            const int v = p[0];
+            int d[16];
+            d[0] = v - p[3 * S];       d[1] = v - p[3 * S + 1];   d[2] = v - p[2 * S + 2];   d[3] = v - p[S + 3];
+            d[4] = v - p[3];           d[5] = v - p[-S + 3];      d[6] = v - p[-2 * S + 2];  d[7] = v - p[-3 * S + 1];
+            d[8] = v - p[-3 * S];      d[9] = v - p[-3 * S - 1];  d[10] = v - p[-2 * S - 2]; d[11] = v - p[-S - 3];
+            d[12] = v - p[-3];         d[13] = v - p[S - 3];      d[14] = v - p[2 * S - 2];  d[15] = v - p[3 * S - 1];
+            int mn2[16], mx2[16], mn4[16], mx4[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+            for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+            int A = -1000, B = 1000;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                A = max(A, min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]));
+                B = min(B, max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]));
+            }
+            score[(sy + 1) * SD_FS_SW + sx + 1] = (uint8_t)(max(A, -B) - 1);      // >= T for a corner at T
         }
-    }
-    if (any) s_any = 1;
-    __syncthreads();
-    {
-        int k = 0;
-        for (int i = tid; i < n2; i += 256, k++)
-            if (supp & (1u << k)) { const unsigned short ent = list2[i]; score[((ent >> 8) + 1) * SD_FS_SW + (ent & 255) + 1] = 0; }
-    }
-    __syncthreads();
-    const int Tc = s_any ? P.iniTh : P.minTh;
-    // ---- phase 5: ordered emission; word index = sy*12 + wd over rows 1..sh of the score tile
-    const int nwords = sh * 12;
-    const int chunk = (nwords + 255) / 256;
-    const int beg = min(tid * chunk, nwords), end = min(beg + chunk, nwords);
-    int cnt = 0;
-    for (int i = beg; i < end; i++) {
-        const int sy = i / 12, wd = i - sy * 12;
-        const uint32_t w = scoreW[(sy + 1) * 12 + wd];
-#pragma unroll
-        for (int k = 0; k < 4; k++) cnt += (int)((w >> (8 * k)) & 255) >= Tc;
-    }
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-    }
-    if (lane == 63) s_wsum[wv] = incl;
-    __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wv; w++) base += s_wsum[w];
-    const int total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-    int pos = base + incl - cnt;
-    uint32_t* out = cellList + (size_t)img * P.cellListCap + c.listOffset;
-    for (int i = beg; i < end; i++) {
-        const int sy = i / 12, wd = i - sy * 12;
-        const uint32_t w = scoreW[(sy + 1) * 12 + wd];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int s = (w >> (8 * k)) & 255;
-            if (s >= Tc) {
-                const int sx = 4 * wd + k - 1;
+        __syncthreads();
+        // ---- phase 4: 3x3 strict-maximum NMS over the corner list (zero frame = outside the scanned area);
+        //      survivors go to a compact list; the cell threshold is iniTh iff one of them reaches it
+        for (int i0 = 0; i0 < n2; i0 += NT) {
+            const int i = i0 + tid;
+            bool ok = false;
+            unsigned key = 0;
+            if (i < n2) {
+                const unsigned short ent = list2[i];
+                const uint8_t* q = score + ((ent >> 8) + 1) * SD_FS_SW + (ent & 255) + 1;
+                const int s = q[0];
+                ok = s > q[-SD_FS_SW - 1] && s > q[-SD_FS_SW] && s > q[-SD_FS_SW + 1] && s > q[-1] && s > q[1] &&
+                     s > q[SD_FS_SW - 1] && s > q[SD_FS_SW] && s > q[SD_FS_SW + 1];
+                key = ((unsigned)ent << 8) | (unsigned)s;
+                if (ok && s >= P.iniTh) s_any = 1;
+            }
+            const int slot = sd_wave_append(ok, &s_cnt3);
+            if (ok) kept[slot] = key;
+        }
+        __syncthreads();
+        // ---- phase 5: row-major emission: rank of a survivor = number of survivors (>= threshold) before it
+        const int n3 = s_cnt3;
+        const int Tc = s_any ? P.iniTh : P.minTh;
+        uint32_t* out = cellList + (size_t)img * P.cellListCap + c.listOffset;
+        int total = 0;
+        for (int i = tid; i < n3; i += NT) {
+            const unsigned key = kept[i];
+            if ((int)(key & 255u) >= Tc) {
+                int rank = 0;
+                for (int j = 0; j < n3; j++) { const unsigned kj = kept[j]; rank += ((int)(kj & 255u) >= Tc) && ((kj >> 8) < (key >> 8)); }
+                const int sx = (key >> 8) & 255, sy = key >> 16;
                 const uint32_t px = (uint32_t)(sx + 3 + c.jw), py = (uint32_t)(sy + 3 + c.ih);
-                if (pos < c.cap) out[pos] = px | (py << 12) | ((uint32_t)s << 24);
-                pos++;
+                if (rank < c.cap) out[rank] = px | (py << 12) | ((key & 255u) << 24);
             }
         }
+        if (tid < 64) {                                     // count of emitted keypoints (first wave)
+            int cnt = 0;
+            for (int j = lane; j < n3; j += 64) cnt += (int)(kept[j] & 255u) >= Tc;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+            total = cnt;
+            if (tid == 0) cellCount[(size_t)img * cellTotal + ci] = min(total, c.cap);
+        }
     }
-    if (tid == 0) cellCount[(size_t)img * P.cellTotal + blockIdx.x] = min(total, c.cap);
 }
 
 // ------------------------------------------------------------------ Gaussian blur 7x7, wide-access version
