@@ -375,14 +375,21 @@ __device__ __forceinline__ void sd_qt_body(const SdQtLds S, const SdLevel& g, ui
                                            int* __restrict__ errFlag, int& nOutRef)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    constexpr int R = CPT > 0 ? CPT : 1;
+    constexpr int R = CPT > 0 ? CPT : 2;
     uint32_t cv[R];
-    int nd[R];
+    unsigned nd2[R / 2];          // node ids (< 65536), two per register: keeps the kernel under 128 VGPRs
 #define SD_FOR_CAND(BODY)                                                                      \
     if constexpr (CPT > 0) {                                                                   \
         _Pragma("unroll") for (int k_ = 0; k_ < CPT; k_++) {                                   \
             const int c = tid + 256 * k_;                                                      \
-            if (c < M) { const uint32_t V = cv[k_]; int& ND = nd[k_]; BODY }                   \
+            if (c < M) {                                                                       \
+                const uint32_t V = cv[k_];                                                     \
+                int ND = (int)((nd2[k_ >> 1] >> (16 * (k_ & 1))) & 0xFFFFu);                   \
+                BODY                                                                           \
+                nd2[k_ >> 1] = (k_ & 1) ? ((nd2[k_ >> 1] & 0x0000FFFFu) | ((unsigned)ND << 16))  \
+                                        : ((nd2[k_ >> 1] & 0xFFFF0000u) | (unsigned)ND);       \
+            }                                                                                  \
+            if ((k_ & 7) == 7) __builtin_amdgcn_sched_barrier(0);   /* bound the live ranges */ \
         }                                                                                      \
     } else {                                                                                   \
         for (int c = tid; c < M; c += 256) {                                                   \
@@ -391,7 +398,9 @@ __device__ __forceinline__ void sd_qt_body(const SdQtLds S, const SdLevel& g, ui
     }
     if constexpr (CPT > 0) {
 #pragma unroll
-        for (int k = 0; k < CPT; k++) { const int c = tid + 256 * k; cv[k] = c < M ? myCand[c] : 0u; nd[k] = 0; }
+        for (int k = 0; k < CPT; k++) { const int c = tid + 256 * k; cv[k] = c < M ? myCand[c] : 0u; }
+#pragma unroll
+        for (int k = 0; k < CPT / 2; k++) nd2[k] = 0;
     }
     // ---- initial nodes (ORBextractor.cc:543-588)
     const int N = g.quota, nIni = g.nIni;
@@ -434,19 +443,15 @@ __device__ __forceinline__ void sd_qt_body(const SdQtLds S, const SdLevel& g, ui
         if (!sortedPhase) {
             for (int i = tid; i < n; i += 256) if (cc[i] > 1) S.order[S.tmp[i]] = (short)i;
         } else {
-            for (int k = 2; k <= sortP; k <<= 1)        // bitonic sort, descending
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int i = tid; i < sortP; i += 256) {
-                        const int ixj = i ^ j;
-                        if (ixj > i) {
-                            const unsigned long long a = S.keys[i], b = S.keys[ixj];
-                            const bool desc = ((i & k) == 0);
-                            if (desc ? (a < b) : (a > b)) { S.keys[i] = b; S.keys[ixj] = a; }
-                        }
-                    }
-                    __syncthreads();
+            // descending order by rank counting (m <= quota: a few hundred keys; one LDS sweep per key, no barriers)
+            for (int i = tid; i < n; i += 256) {
+                const unsigned long long k = S.keys[i];
+                if (k) {
+                    int rank = 0;
+                    for (int j = 0; j < n; j++) rank += S.keys[j] > k;
+                    S.order[rank] = (short)i;
                 }
-            for (int i = tid; i < m; i += 256) S.order[i] = (short)(0xFFFF - (unsigned)(S.keys[i] & 0xFFFFu));
+            }
         }
         for (int i = tid; i < 4 * m; i += 256) S.child[i] = 0;
         __syncthreads();
@@ -526,7 +531,7 @@ __device__ __forceinline__ void sd_qt_body(const SdQtLds S, const SdLevel& g, ui
 #undef SD_FOR_CAND
 }
 
-__global__ void __launch_bounds__(256) k_quadtree(const uint32_t* __restrict__ cellList,
+__global__ void __launch_bounds__(256, 4) k_quadtree(const uint32_t* __restrict__ cellList,
                                                   const int* __restrict__ cellCount, const SdCell* __restrict__ cells,
                                                   uint32_t* __restrict__ cand, uint16_t* __restrict__ nodeOf,
                                                   int* __restrict__ lvlCount, int* __restrict__ candCount,
