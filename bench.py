@@ -18,7 +18,7 @@ i.e. per frame (reference call stack SURVEY 3.2, 3-argument TrackRGBD):
 Multi-GPU (driver launches one rank per GPU through torch.distributed.run): independent frames are
 sharded, every rank runs the same per-GPU batch (weak scaling), there is no data-path collective.
 Start-up: RCCL broadcast of the packed ORB vocabulary (synthetic k=10, L=6 tree, ~45 MB) from rank 0.
-Per step: all_gather of the fixed-stride per-frame result records.  value = frames of ALL ranks / max
+Per step: asynchronous gather (to rank 0) of the fixed-stride per-frame result records, overlapped with the next step.  value = frames of ALL ranks / max
 rank time.
 
 Prints ONE JSON line on rank 0.
@@ -83,7 +83,7 @@ def max_over_ranks(dist, seconds, device):
 
 
 def gather_records(dist, local, world):
-    """all_gather of one rank's fixed-stride result block (uint8 tensor) -> [world, nbytes]."""
+    """all_gather of one rank's fixed-stride result block (uint8 tensor) -> [world, nbytes] (kept for tests / small runs)."""
     import torch
     if dist is None or world == 1:
         return local.unsqueeze(0)
@@ -91,6 +91,37 @@ def gather_records(dist, local, world):
     out = torch.empty((world * flat.numel(),), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, flat)
     return out.view((world,) + tuple(local.shape))
+
+
+class ResultGather:
+    """Per-rank result gather to rank 0 (north star: "per-rank result gather"), overlapped with the next step.
+
+    The records (keypoints + descriptors, fixed stride) are first copied into a staging tensor on the compute
+    stream, then `dist.gather(..., dst=0, async_op=True)` moves them while the next step computes.  A gather to one
+    root uses the 7 direct xGMI links into rank 0 in parallel; an all_gather would move 7x the bytes into every
+    rank (57 GB/s per GPU at 59k frames/s) for no consumer."""
+
+    def __init__(self, dist, world, rank, nbytes, device):
+        import torch
+        self.dist, self.world, self.rank = dist, world, rank
+        self.stage = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        self.recv = [torch.empty((nbytes,), dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
+        self.work = None
+
+    def submit(self, parts):
+        if self.work is not None:
+            self.work.wait()                     # previous gather must have drained the staging tensor
+        off = 0
+        for p in parts:
+            n = p.numel()
+            self.stage[off:off + n].copy_(p, non_blocking=True)
+            off += n
+        self.work = self.dist.gather(self.stage, gather_list=self.recv, dst=0, async_op=True)
+
+    def finish(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
 
 
 # --------------------------------------------------------------------------- CPU baseline (oracle; rank 0, N=1 only)
@@ -151,13 +182,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    if os.environ.get("SD_BENCH_SINGLE_DEVICE"):     # rehearsal only: several ranks share cuda:0 (gloo backend)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("SD_BENCH_BACKEND", "nccl")            # "gloo" only for single-GPU rehearsal
+        if backend == "nccl":
+            dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist_mod.init_process_group(backend, rank=rank, world_size=world)
         dist = dist_mod
 
     pkg = graft.load_package()
@@ -244,12 +281,13 @@ def main():
             cull_state.append(dict(packed=packed, slots=np.arange(Bs, dtype=np.int32), cur=np.arange(dt, Bs, dtype=np.int32),
                                    ref=np.arange(0, Bs - dt, dtype=np.int32), H=np.tile(Hm.reshape(1, 9), (npair, 1)),
                                    flag=np.ones(npair, np.int32), last=(li, ls, nl)))
-    recs = None
+    recs, gatherer = None, None
     if dist is not None:
         recs = []
         for bt in batches:
             kp_p, desc_p, cnt_p, cap = bt.results_device()
-            recs.append(dict(kp=fe.as_torch_u8(kp_p, n_img * cap * 28), desc=fe.as_torch_u8(desc_p, n_img * cap * 32)))
+            recs += [fe.as_torch_u8(kp_p, n_img * cap * 28), fe.as_torch_u8(desc_p, n_img * cap * 32)]
+        gatherer = ResultGather(dist, world, rank, sum(r.numel() for r in recs), dev)
 
     def run_stream(k, first):
         bt, st = batches[k], streams[k].cuda_stream
@@ -285,9 +323,7 @@ def main():
             for k in range(1, S):
                 main_stream.wait_stream(streams[k])
         if dist is not None:
-            for r in recs:
-                gather_records(dist, r["kp"], world)
-                gather_records(dist, r["desc"], world)
+            gatherer.submit(recs)
         if S > 1:                                   # next step's side-stream work must not overtake the gather
             for k in range(1, S):
                 streams[k].wait_stream(main_stream)
@@ -308,6 +344,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if gatherer is not None:
+        gatherer.finish()                          # the last step's gather is inside the timed region
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -366,7 +404,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload_name, "frames_per_step_per_gpu": B, "images_per_frame": imgs_per_frame,
                        "features_per_image": int(np.mean(counts)), "projection_matches_last_pair": int(nm),
-                       "sharding": "independent frame batches per rank, no data-path collective; per-step all_gather of results"
+                       "sharding": "independent frame batches per rank, no data-path collective; per-step async gather of results to rank 0"
                        if world > 1 else "single GPU"},
             "roofline": roof, "cpu_baseline": cpu,
         }

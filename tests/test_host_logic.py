@@ -51,6 +51,12 @@ def _gloo_worker(rank, world, port, q):
     local = torch.full((5, 7), rank + 1, dtype=torch.uint8)
     g = bench.gather_records(dist, local, world)
     t = bench.max_over_ranks(dist, 1.0 + rank, torch.device("cpu"))
+    rg = bench.ResultGather(dist, world, rank, 35, torch.device("cpu"))
+    for step in range(3):                      # async gather to rank 0, re-submitted while the previous one may be in flight
+        rg.submit([torch.full((5, 7), 10 * step + rank, dtype=torch.uint8).reshape(-1)])
+    rg.finish()
+    if rank == 0:
+        assert [int(r[0]) for r in rg.recv] == [20, 21]
     voc = torch.arange(100, dtype=torch.uint8) if rank == 0 else torch.zeros(100, dtype=torch.uint8)
     dist.broadcast(voc, src=0)
     q.put((rank, g.shape, [int(g[r].float().mean()) for r in range(world)], t, int(voc.sum())))
