@@ -760,6 +760,18 @@ int sd_hamming_matrix_device(const uint8_t* d_a, int na, const uint8_t* d_b, int
 
 
 // ---------------------------------------------------------------- grid / unproject / projection matcher
+struct SdCopySegs { const char* src[24]; char* dst[24]; unsigned bytes[24]; int n; };
+__global__ void __launch_bounds__(256) k_copy_segments(SdCopySegs S)
+{
+    const int seg = blockIdx.y;
+    const unsigned n = S.bytes[seg];
+    const char* s = S.src[seg]; char* d = S.dst[seg];
+    const bool aligned = ((((size_t)s) | ((size_t)d)) & 3) == 0;
+    const unsigned words = aligned ? n >> 2 : 0;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < words; i += gridDim.x * 256) ((uint32_t*)d)[i] = ((const uint32_t*)s)[i];
+    for (unsigned i = (words << 2) + blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) d[i] = s[i];
+}
+
 static int cam_ok(const sd_camera* c)
 {
     return c && c->fx > 0 && c->fy > 0 && c->mnMaxX > c->mnMinX && c->mnMaxY > c->mnMinY;
@@ -914,19 +926,23 @@ int sd_batch_copy_frame(sd_batch* b, int src, int dst, void* stream_)
     hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
     b->lastStream = s;
     const size_t cap = b->plan.kpCap;
-#define CP(ptr, elemBytes) HIPCHK(hipMemcpyAsync((char*)(ptr) + dst * cap * (elemBytes), (const char*)(ptr) + src * cap * (elemBytes), cap * (elemBytes), hipMemcpyDeviceToDevice, s))
+#define CP(ptr, elemBytes) do { if (nseg < 24) { segs.src[nseg] = (const char*)(ptr) + src * cap * (elemBytes); segs.dst[nseg] = (char*)(ptr) + dst * cap * (elemBytes); segs.bytes[nseg] = (unsigned)(cap * (elemBytes)); nseg++; } } while (0)
+    SdCopySegs segs;
+    int nseg = 0;
     CP(b->d_kp, sizeof(sd_keypoint)); CP(b->d_desc, 32); CP(b->d_uright, 4); CP(b->d_depth, 4); CP(b->d_sad, 4);
     CP(b->d_cellOf, 2); CP(b->d_xw, 12); CP(b->d_flags, 1); CP(b->d_sortedIdx, 2);
     CP(b->d_kpD, sizeof(sd_keypoint)); CP(b->d_descD, 32); CP(b->d_urD, 4); CP(b->d_depD, 4);
 #undef CP
-    HIPCHK(hipMemcpyAsync(b->d_cellStart + (size_t)dst * (SD_GRID_CELLS + 8), b->d_cellStart + (size_t)src * (SD_GRID_CELLS + 8),
-                          (size_t)(SD_GRID_CELLS + 8) * 2, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(b->d_count + dst, b->d_count + src, 4, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(b->d_lvlCount + (size_t)dst * b->plan.nlevels, b->d_lvlCount + (size_t)src * b->plan.nlevels,
-                          (size_t)b->plan.nlevels * 4, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(b->d_fb + dst, b->d_fb + src, sizeof(SdFrameBoxes), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(b->d_boxItems + (size_t)dst * b->itemsCap, b->d_boxItems + (size_t)src * b->itemsCap, (size_t)b->itemsCap * 4,
-                          hipMemcpyDeviceToDevice, s));
+#define CPX(ptr, elems, elemBytes) do { if (nseg < 24) { segs.src[nseg] = (const char*)((ptr) + (size_t)src * (elems)); segs.dst[nseg] = (char*)((ptr) + (size_t)dst * (elems)); segs.bytes[nseg] = (unsigned)((elems) * (elemBytes)); nseg++; } } while (0)
+    CPX(b->d_cellStart, SD_GRID_CELLS + 8, 2);
+    CPX(b->d_count, 1, 4);
+    CPX(b->d_lvlCount, b->plan.nlevels, 4);
+    CPX(b->d_fb, 1, sizeof(SdFrameBoxes));
+    CPX(b->d_boxItems, b->itemsCap, 4);
+#undef CPX
+    segs.n = nseg;
+    hipLaunchKernelGGL(k_copy_segments, dim3(32, nseg), dim3(256), 0, s, segs);      // one launch instead of 19 small copies
+    LAUNCH_CHECK("k_copy_segments");
     b->slotValid[dst] = 1;
     return SD_OK;
 }
