@@ -216,6 +216,46 @@ int sd_refqueue_candidate(sd_refqueue* q, double cur_timestamp, int cur_has_boxe
 int sd_refqueue_reject(sd_refqueue* q, int* again);
 int sd_refqueue_push(sd_refqueue* q, double timestamp, int slot, int has_boxes, int max_frames, int* evicted_slot);
 
+/* ---- detector: yolov3Segment (include/yolo.h:22-48, src/yolo.cc, src/yolo/yolov3.cfg) ----
+ * cv::dnn's Darknet importer + Net::forward + the reference's post-processing, on MFMA (f16 operands, f32
+ * accumulation).  The network is given as a layer list (the five layer types of yolov3.cfg); weights are the
+ * payload of a Darknet .weights file (floats after the header; per convolutional layer: biases, [scales, rolling
+ * mean, rolling variance], weights [filters][c][size][size]), i.e. what readNetFromDarknet (yolo.cc:27) consumes. */
+#define SD_YOLO_CONV 0
+#define SD_YOLO_SHORTCUT 1
+#define SD_YOLO_ROUTE 2
+#define SD_YOLO_UPSAMPLE 3
+#define SD_YOLO_YOLO 4
+typedef struct sd_yolo_layer {
+    int32_t type;
+    int32_t filters, size, stride, batch_normalize, leaky; /* [convolutional]; leaky 0 = linear; pad = size/2 */
+    int32_t from[2], nfrom;                                /* [shortcut] from / [route] layers (negative = relative) */
+    int32_t mask[3];                                       /* [yolo] anchor indices */
+} sd_yolo_layer;
+typedef struct sd_yolo sd_yolo;
+/* The 107 layers and 9 anchors of src/yolo/yolov3.cfg. */
+int sd_yolo_v3_layers(sd_yolo_layer* layers, int cap, int* n, float anchors[18]);
+/* yolov3Segment::yolov3Segment (yolo.cc:15-31); net_w x net_h = inpWidth x inpHeight (yolo.h:26-27). */
+int sd_yolo_create(sd_yolo** out, const sd_yolo_layer* layers, int n_layers, const float anchors[18], int classes, int net_w,
+                   int net_h, int max_batch);
+int sd_yolo_destroy(sd_yolo* y);
+int sd_yolo_weight_count(const sd_yolo* y, size_t* n_floats);
+int sd_yolo_load_darknet_weights(sd_yolo* y, const float* payload, size_t n_floats);
+int sd_yolo_layer_shape(const sd_yolo* y, int layer, int* h, int* w, int* c);
+int sd_yolo_flops(const sd_yolo* y, double* flops_per_image);
+/* blobFromImage + net.forward + the confidence filter (yolo.cc:63-68,163-183) for n 8-bit 3-channel images in HBM
+ * (channel order as cv::imread delivers it, i.e. BGR; swapRB is applied as in the reference). */
+int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int height, size_t stride, size_t image_pitch, int n,
+                           float conf_threshold, void* stream);
+/* Test access: layer output (f16, NHWC, dense) of one image; region-layer rows [total_rows][5 + classes] of image 0
+ * (only after a forward with n == 1). */
+int sd_yolo_download_layer(sd_yolo* y, int layer, int image, uint16_t* f16_nhwc_out);
+int sd_yolo_download_region(sd_yolo* y, float* rows, int* total_rows);
+/* yolov3Segment::Segmentation_ result for one image (yolo.cc:151-206): NMSBoxes(conf, nms), class filter
+ * {person, car, bicycle, bus, truck}, box width -20 % / height +60 % about the centre.  boxes: [cap][4] x,y,w,h. */
+int sd_yolo_boxes(sd_yolo* y, int image, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold, double* boxes,
+                  int32_t* class_ids, float* confidences, int cap, int* n);
+
 /* ---- Tracking::GrabImage* preprocessing (src/Tracking.cc:170-343) ---- */
 /* cvtColor(RGB|BGR|RGBA|BGRA -> GRAY); rgb_order = Camera.RGB.  channels 3 or 4. */
 int sd_cvt_gray_device(const uint8_t* d_src, int width, int height, size_t src_stride, size_t src_pitch, int channels,

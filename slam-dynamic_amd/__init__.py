@@ -7,3 +7,4 @@ which registers it as module `slam_dynamic_amd`.
 """
 from . import synth  # noqa: F401
 from . import frontend  # noqa: F401
+from . import yolo  # noqa: F401

@@ -1,0 +1,232 @@
+// HIP kernels of the detector (YOLOv3 / Darknet-53 at 640x480, src/yolo.cc:60-77, src/yolo/yolov3.cfg):
+// the only GEMM-shaped work on the hot path, so the only place MFMA is used.
+//   k_blob_from_image   blobFromImage(1/255, 640x480, swapRB, no crop)            yolo.cc:63
+//   k_conv_mfma         convolution (+ folded batch-norm + leaky ReLU + shortcut) as implicit GEMM on
+//                       v_mfma_f32_32x32x16_f16: D[cout][pixel] = W[cout][k] * X[k][pixel], f32 accumulate
+//   k_upsample_concat   [upsample] x2 nearest + [route] channel concatenation
+//   k_region_decode     the [yolo] region layer of cv::dnn + the confidence filter of postprocess_ (yolo.cc:163-183)
+// Activations are NHWC f16 (channels innermost: one im2col K-step of 32 channels of one filter tap is 64
+// contiguous bytes per pixel); weights are [cout][kh][kw][cin] f16 with batch-norm folded in.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+typedef _Float16 sd_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sd_h4 __attribute__((ext_vector_type(4)));
+typedef float sd_f16v __attribute__((ext_vector_type(16)));
+
+struct SdConvArgs {
+    const _Float16* in;      // [N][H][W][cinStride]
+    const _Float16* wgt;     // [coutPad][taps][cin]
+    const float* bias;       // [coutPad]
+    const _Float16* res;     // shortcut source, same geometry as out (or null)
+    _Float16* out;           // [N][Ho][Wo][outStride] written at channel offset outOff
+    int N, H, W, cin, cinStride;
+    int Ho, Wo, cout, coutPad, outStride, outOff, resStride;
+    int ksize, stride, pad, leaky;
+};
+
+#define SD_CV_BM 64          // couts per workgroup
+#define SD_CV_BN 256         // pixels per workgroup
+#define SD_CV_BK 32          // K step (two MFMA k-steps of 16)
+#define SD_CV_LD 40          // LDS row length in halfs (32 + 8 pad: ds_read_b128 rows 80 B apart)
+
+// 4 waves, each 64 couts x 64 pixels = 2 x 2 MFMA tiles of 32 x 32.
+__global__ void __launch_bounds__(256) k_conv_mfma(SdConvArgs A)
+{
+    __shared__ __align__(16) _Float16 sW[SD_CV_BM * SD_CV_LD];     //  5 KB
+    __shared__ __align__(16) _Float16 sX[SD_CV_BN * SD_CV_LD];     // 20 KB
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int pix0 = blockIdx.x * SD_CV_BN, co0 = blockIdx.y * SD_CV_BM;
+    const int npix = A.N * A.Ho * A.Wo;
+    // the 4 activation chunks (16 B = 8 channels) this thread stages per K step: chunk = tid + 256*i
+    int pyi[4], pxi[4];
+    size_t pbase[4];
+    bool pok[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int chunk = tid + 256 * i;
+        const int p = pix0 + (chunk >> 2);
+        pok[i] = p < npix;
+        const int pp = pok[i] ? p : 0;
+        const int n = pp / (A.Ho * A.Wo), r = pp - n * (A.Ho * A.Wo);
+        const int yo = r / A.Wo, xo = r - yo * A.Wo;
+        pyi[i] = yo * A.stride - A.pad; pxi[i] = xo * A.stride - A.pad;
+        pbase[i] = (size_t)n * A.H * A.W;
+    }
+    const int wrow = tid >> 2, wq = tid & 3;                      // weight chunk: cout row, 8-channel quarter
+    const int taps = A.ksize * A.ksize;
+    const int ksteps = taps * (A.cin / SD_CV_BK);
+    const int cchunks = A.cin / SD_CV_BK;
+    sd_f16v acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+    const int r32 = lane & 31, h = lane >> 5;
+    for (int ks = 0; ks < ksteps; ks++) {
+        const int t = ks / cchunks, c0 = (ks - t * cchunks) * SD_CV_BK;
+        const int kh = t / A.ksize, kw = t - kh * A.ksize;
+        // ---- stage W tile [64][32] and X tile [256][32]
+        {
+            const uint4 wv4 = *(const uint4*)(A.wgt + ((size_t)(co0 + wrow) * taps + t) * A.cin + c0 + 8 * wq);
+            *(uint4*)(sW + wrow * SD_CV_LD + 8 * wq) = wv4;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int chunk = tid + 256 * i;
+            const int yi = pyi[i] + kh, xi = pxi[i] + kw;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (pok[i] && yi >= 0 && yi < A.H && xi >= 0 && xi < A.W)
+                v = *(const uint4*)(A.in + (pbase[i] + (size_t)yi * A.W + xi) * A.cinStride + c0 + 8 * (chunk & 3));
+            *(uint4*)(sX + (chunk >> 2) * SD_CV_LD + 8 * (chunk & 3)) = v;
+        }
+        __syncthreads();
+        // ---- fragments: A = W[row r32][k = 8h + j], B = X[k = 8h + j][col r32]; two k-steps of 16
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            sd_h8 a[2], b[2];
+#pragma unroll
+            for (int m = 0; m < 2; m++) a[m] = *(const sd_h8*)(sW + (32 * m + r32) * SD_CV_LD + 16 * kk + 8 * h);
+#pragma unroll
+            for (int n = 0; n < 2; n++) b[n] = *(const sd_h8*)(sX + (64 * wv + 32 * n + r32) * SD_CV_LD + 16 * kk + 8 * h);
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int n = 0; n < 2; n++)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: D col = pixel (lane & 31), row = cout (reg&3) + 8*(reg>>2) + 4*(lane>>5): 4 consecutive couts per group
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+        const int p = pix0 + 64 * wv + 32 * n + r32;
+        if (p >= npix) continue;
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int co = co0 + 32 * m + 8 * g + 4 * h;
+                if (co >= A.cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float x = acc[m][n][4 * g + e] + A.bias[co + e];
+                    if (A.leaky) x = x > 0.f ? x : 0.1f * x;
+                    v[e] = x;
+                }
+                if (A.res) {
+                    const sd_h4 rr = *(const sd_h4*)(A.res + (size_t)p * A.resStride + co);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] += (float)rr[e];
+                }
+                sd_h4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = (_Float16)v[e];
+                _Float16* dst = A.out + (size_t)p * A.outStride + A.outOff + co;
+                if (co + 3 < A.cout) *(sd_h4*)dst = o;
+                else for (int e = 0; e < 4 && co + e < A.cout; e++) dst[e] = o[e];
+            }
+    }
+}
+
+// blobFromImage(image, 1/255, Size(640,480), Scalar(0,0,0), swapRB = true, crop = false): bilinear resize of
+// the 8-bit image (OpenCV resize INTER_LINEAR fixed-point path, per channel), swap R and B, scale to [0,1].
+// Output NHWC f16 with the 3 channels padded to 32 (zeros) so the first convolution runs on the MFMA path.
+__global__ void __launch_bounds__(256) k_blob_from_image(const uint8_t* __restrict__ src, int sw, int sh, size_t sstride,
+                                                         size_t spitch, const short4* __restrict__ ct,
+                                                         const short4* __restrict__ rt, _Float16* __restrict__ dst,
+                                                         int dw, int dh, int swapRB)
+{
+    const int img = blockIdx.z;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= dw || y >= dh) return;
+    const short4 ce = ct[x], re = rt[y];
+    const int sx = ce.x, sx1 = min(sx + 1, sw - 1);
+    const int r0 = min(max((int)re.x, 0), sh - 1), r1 = min(max((int)re.x + 1, 0), sh - 1);
+    const uint8_t* S0 = src + (size_t)img * spitch + (size_t)r0 * sstride;
+    const uint8_t* S1 = src + (size_t)img * spitch + (size_t)r1 * sstride;
+    float ch[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int h0 = S0[3 * sx + c] * ce.y + S0[3 * sx1 + c] * ce.z;
+        const int h1 = S1[3 * sx + c] * ce.y + S1[3 * sx1 + c] * ce.z;
+        const int v = ((((int)re.y * (h0 >> 4)) >> 16) + (((int)re.z * (h1 >> 4)) >> 16) + 2) >> 2;
+        ch[c] = (float)(v & 255) * (float)(1 / 255.0);
+    }
+    _Float16* o = dst + ((size_t)img * dh * dw + (size_t)y * dw + x) * 32;
+    o[0] = (_Float16)(swapRB ? ch[2] : ch[0]); o[1] = (_Float16)ch[1]; o[2] = (_Float16)(swapRB ? ch[0] : ch[2]);
+#pragma unroll
+    for (int c = 3; c < 32; c++) o[c] = (_Float16)0.f;
+}
+
+// [upsample] stride 2 (nearest) of `a` (C1 channels, h x w) into channels [0, C1) of `out` (2h x 2w, C1 + C2
+// channels), and [route] concatenation of `b` (C2 channels, 2h x 2w) into channels [C1, C1 + C2).
+__global__ void __launch_bounds__(256) k_upsample_concat(const _Float16* __restrict__ a, int C1, int h, int w,
+                                                         const _Float16* __restrict__ b, int C2,
+                                                         _Float16* __restrict__ out, int N)
+{
+    const int Ct = C1 + C2, H2 = 2 * h, W2 = 2 * w;
+    const size_t total = (size_t)N * H2 * W2 * (Ct / 8);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c8 = (int)(i % (Ct / 8));
+        const size_t p = i / (Ct / 8);
+        const int x = (int)(p % W2);
+        const size_t q = p / W2;
+        const int y = (int)(q % H2), n = (int)(q / H2);
+        uint4 v;
+        if (c8 * 8 < C1) v = *(const uint4*)(a + (((size_t)n * h + (y >> 1)) * w + (x >> 1)) * C1 + c8 * 8);
+        else v = *(const uint4*)(b + (((size_t)n * H2 + y) * W2 + x) * C2 + (c8 * 8 - C1));
+        *(uint4*)(out + p * Ct + c8 * 8) = v;
+    }
+}
+
+// cv::dnn RegionLayer for YOLOv3 (logistic activations, classes scaled by objectness, thresh 0.001 default) fused
+// with the confidence filter of yolov3Segment::postprocess_ (yolo.cc:163-183): one thread per (cell, anchor) row.
+// Rows are numbered as cv::dnn emits them: head by head, then (y, x, anchor).  Surviving rows are appended to a
+// compact list; their order is restored on the host before NMSBoxes (it needs the original row order for ties).
+struct SdDet { int row; int cls; float conf; float cx, cy, w, h; };   // 28 B
+__global__ void __launch_bounds__(256) k_region_decode(const _Float16* __restrict__ head, int hs /*channel stride*/,
+                                                       int gh, int gw, int N, float aw0, float ah0, float aw1,
+                                                       float ah1, float aw2, float ah2, int netW, int netH,
+                                                       float confThreshold, int rowBase, SdDet* __restrict__ dets,
+                                                       int* __restrict__ ndet, int detCap, float* __restrict__ rawOut)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int perImg = gh * gw * 3;
+    if (i >= N * perImg) return;
+    const int n = i / perImg, r = i - n * perImg;
+    const int a = r % 3, cell = r / 3;
+    const int y = cell / gw, x = cell - y * gw;
+    const _Float16* t = head + ((size_t)n * gh * gw + cell) * hs + a * 85;
+    const float aw = a == 0 ? aw0 : a == 1 ? aw1 : aw2, ah = a == 0 ? ah0 : a == 1 ? ah1 : ah2;
+    auto sig = [](float v) { return 1.f / (1.f + expf(-v)); };
+    const float cx = (sig((float)t[0]) + (float)x) / (float)gw;
+    const float cy = (sig((float)t[1]) + (float)y) / (float)gh;
+    const float bw = expf((float)t[2]) * aw / (float)netW;
+    const float bh = expf((float)t[3]) * ah / (float)netH;
+    const float obj = sig((float)t[4]);
+    float best = 0.f;
+    int bc = 0;
+    for (int c = 0; c < 80; c++) {
+        float p = obj * sig((float)t[5 + c]);
+        if (!(p > 0.001f)) p = 0.f;                 // region layer `thresh`
+        if (p > best) { best = p; bc = c; }         // minMaxLoc: first maximum
+        if (rawOut) rawOut[(size_t)(rowBase + r) * 85 + 5 + c] = p;          // only requested for single-image runs
+    }
+    if (rawOut) {
+        float* o = rawOut + (size_t)(rowBase + r) * 85;
+        o[0] = cx; o[1] = cy; o[2] = bw; o[3] = bh; o[4] = obj;
+    }
+    if (best > confThreshold) {
+        const int slot = atomicAdd(&ndet[n], 1);
+        if (slot < detCap) {
+            SdDet d; d.row = rowBase + r; d.cls = bc; d.conf = best; d.cx = cx; d.cy = cy; d.w = bw; d.h = bh;
+            dets[(size_t)n * detCap + slot] = d;
+        }
+    }
+}

@@ -11,6 +11,7 @@
 #include "k_frame.h"
 #include "k_fast.h"
 #include "k_cull.h"
+#include "sd_yolo.h"
 
 static thread_local std::string g_err;
 static int set_err(int code, const std::string& msg) { g_err = msg; return code; }
@@ -1270,6 +1271,346 @@ int sd_refqueue_push(sd_refqueue* q, double timestamp, int slot, int has_boxes, 
         q->q.erase(q->q.begin());
     }
     q->q.push_back({timestamp, slot, has_boxes});
+    return SD_OK;
+}
+
+
+// ---------------------------------------------------------------- detector (YOLOv3 on MFMA)
+int sd_yolo_v3_layers(sd_yolo_layer* layers, int cap, int* n, float anchors[18])
+{
+    if (!n) return SD_ERR_INVALID;
+    std::vector<sd_yolo_layer> L;
+    yolo_v3_layers(L);
+    *n = (int)L.size();
+    if (anchors) memcpy(anchors, kYoloV3Anchors, sizeof(kYoloV3Anchors));
+    if (layers) {
+        if (cap < (int)L.size()) return set_err(SD_ERR_CAPACITY, "layer buffer too small");
+        memcpy(layers, L.data(), L.size() * sizeof(sd_yolo_layer));
+    }
+    return SD_OK;
+}
+
+static void yolo_free(sd_yolo* y)
+{
+    if (!y) return;
+    for (void* p : y->owned) if (p) (void)hipFree(p);
+    if (y->stream) (void)hipStreamDestroy(y->stream);
+    delete y;
+}
+
+int sd_yolo_create(sd_yolo** out, const sd_yolo_layer* layers, int n_layers, const float anchors[18], int classes, int net_w,
+                   int net_h, int max_batch)
+{
+    if (!out) return SD_ERR_INVALID;
+    *out = nullptr;
+    if (!layers || n_layers < 1 || !anchors || classes != 80 || net_w < 32 || net_h < 32 || (net_w % 32) || (net_h % 32) || max_batch < 1)
+        return set_err(SD_ERR_INVALID, "bad detector arguments (classes must be 80, net size a multiple of 32)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(SD_ERR_NO_DEVICE, "no HIP device: the detector has no CPU fallback");
+    sd_yolo* y = new sd_yolo();
+    y->L.assign(layers, layers + n_layers);
+    y->R.resize(n_layers);
+    y->netW = net_w; y->netH = net_h; y->classes = classes; y->maxBatch = max_batch;
+    memcpy(y->anchors, anchors, sizeof(y->anchors));
+    // ---- shapes
+    int H = net_h, W = net_w, C = 32;      // blob: 3 channels padded to 32
+    size_t wOff = 0, bOff = 0;
+    for (int i = 0; i < n_layers; i++) {
+        const sd_yolo_layer& l = y->L[i];
+        sd_yolo::Rt& r = y->R[i];
+        if (l.type == SD_YOLO_CONV) {
+            if ((l.size != 1 && l.size != 3) || (l.stride != 1 && l.stride != 2) || l.filters < 1) { delete y; return set_err(SD_ERR_UNSUPPORTED, "convolution size/stride not supported"); }
+            const int cinReal = i == 0 ? 3 : C;
+            r.cinPad = i == 0 ? 32 : C;
+            if (r.cinPad % 32) { delete y; return set_err(SD_ERR_UNSUPPORTED, "input channels must be a multiple of 32"); }
+            const int pad = l.size / 2;
+            r.H = (H + 2 * pad - l.size) / l.stride + 1; r.W = (W + 2 * pad - l.size) / l.stride + 1; r.C = l.filters;
+            r.outC = (l.filters + 31) / 32 * 32;            // stored channel count (255 -> 256)
+            r.coutPad = (l.filters + SD_CV_BM - 1) / SD_CV_BM * SD_CV_BM;
+            r.wOff = wOff; r.bOff = bOff;
+            wOff += (size_t)r.coutPad * l.size * l.size * r.cinPad;
+            bOff += r.coutPad;
+            y->convFlops += 2.0 * r.H * r.W * (double)l.filters * l.size * l.size * cinReal;
+            y->nconv++;
+        } else if (l.type == SD_YOLO_SHORTCUT) {
+            const int f = yolo_resolve(i, l.from[0]);
+            if (f < 0 || f >= i || y->R[f].H != H || y->R[f].W != W || y->R[f].C != C) { delete y; return set_err(SD_ERR_INVALID, "bad shortcut"); }
+            r.H = H; r.W = W; r.C = C; r.outC = C;
+        } else if (l.type == SD_YOLO_ROUTE) {
+            const int f0 = yolo_resolve(i, l.from[0]);
+            if (f0 < 0 || f0 >= i) { delete y; return set_err(SD_ERR_INVALID, "bad route"); }
+            r.H = y->R[f0].H; r.W = y->R[f0].W; r.C = y->R[f0].C;
+            if (l.nfrom == 2) {
+                const int f1 = yolo_resolve(i, l.from[1]);
+                if (f1 < 0 || f1 >= i || y->R[f1].H != r.H || y->R[f1].W != r.W) { delete y; return set_err(SD_ERR_INVALID, "bad route"); }
+                r.C += y->R[f1].C;
+            }
+            r.outC = r.C;
+        } else if (l.type == SD_YOLO_UPSAMPLE) {
+            r.H = 2 * H; r.W = 2 * W; r.C = C; r.outC = C;
+        } else if (l.type == SD_YOLO_YOLO) {
+            if (C != 3 * (5 + classes)) { delete y; return set_err(SD_ERR_INVALID, "[yolo] input must have 3*(5+classes) channels"); }
+            r.H = H; r.W = W; r.C = C; r.outC = C;
+            y->totalRows += H * W * 3;
+        } else { delete y; return set_err(SD_ERR_INVALID, "unknown layer type"); }
+        H = r.H; W = r.W; C = r.C;
+        if ((l.type == SD_YOLO_CONV) && (r.C % 4) && r.C != 3 * (5 + classes)) { delete y; return set_err(SD_ERR_UNSUPPORTED, "filters must be a multiple of 4"); }
+    }
+    y->wTotal = wOff; y->bTotal = bOff;
+    y->detCap = 8192;
+    // ---- device memory
+    auto alloc = [&](void** p, size_t bytes) -> bool {
+        if (hipMalloc(p, bytes) != hipSuccess) return false;
+        y->owned.push_back(*p);
+        return true;
+    };
+    bool ok = true;
+    const size_t nB = (size_t)max_batch;
+    ok = ok && alloc((void**)&y->d_blob, nB * net_h * net_w * 32 * 2);
+    ok = ok && alloc((void**)&y->d_wgt, wOff * 2 + 64);
+    ok = ok && alloc((void**)&y->d_bias, bOff * 4 + 64);
+    ok = ok && alloc((void**)&y->d_dets, nB * y->detCap * sizeof(SdDet));
+    ok = ok && alloc((void**)&y->d_ndet, nB * 4);
+    ok = ok && alloc((void**)&y->d_raw, (size_t)y->totalRows * (5 + classes) * 4 + 64);
+    ok = ok && alloc((void**)&y->d_ct, 8 * 8192);
+    ok = ok && alloc((void**)&y->d_rt, 8 * 8192);
+    for (int i = 0; ok && i < n_layers; i++) {
+        const sd_yolo_layer& l = y->L[i];
+        sd_yolo::Rt& r = y->R[i];
+        if (l.type == SD_YOLO_CONV) {
+            ok = alloc((void**)&r.out, nB * r.H * r.W * r.outC * 2 + 64);
+            if (ok && r.outC != r.C) ok = hipMemset(r.out, 0, nB * r.H * r.W * r.outC * 2) == hipSuccess;
+        } else if (l.type == SD_YOLO_SHORTCUT) {
+            // fused into the preceding convolution's epilogue when that output has no other consumer
+            bool fuse = i > 0 && y->L[i - 1].type == SD_YOLO_CONV && yolo_resolve(i, l.from[0]) != i - 1;
+            for (int j = 0; fuse && j < n_layers; j++) {
+                if (j == i) continue;
+                const sd_yolo_layer& o = y->L[j];
+                if (o.type == SD_YOLO_SHORTCUT || o.type == SD_YOLO_ROUTE)
+                    for (int k = 0; k < o.nfrom; k++) if (yolo_resolve(j, o.from[k]) == i - 1) fuse = false;
+            }
+            if (fuse) { r.out = y->R[i - 1].out; r.alias = true; }
+            else ok = alloc((void**)&r.out, nB * r.H * r.W * r.outC * 2 + 64);
+        } else if (l.type == SD_YOLO_ROUTE && l.nfrom == 1) {
+            r.out = y->R[yolo_resolve(i, l.from[0])].out; r.alias = true; r.outC = y->R[yolo_resolve(i, l.from[0])].outC;
+        } else if (l.type == SD_YOLO_ROUTE) {
+            ok = alloc((void**)&r.out, nB * r.H * r.W * r.outC * 2 + 64);
+        } else if (l.type == SD_YOLO_UPSAMPLE) {
+            // materialised only inside the following 2-input route (k_upsample_concat); stand-alone upsample unsupported
+            if (!(i + 1 < n_layers && y->L[i + 1].type == SD_YOLO_ROUTE && y->L[i + 1].nfrom == 2 && yolo_resolve(i + 1, y->L[i + 1].from[0]) == i)) {
+                yolo_free(y); return set_err(SD_ERR_UNSUPPORTED, "[upsample] must feed a 2-input [route] as its first input");
+            }
+        } else if (l.type == SD_YOLO_YOLO) {
+            r.out = y->R[i - 1].out; r.alias = true; r.outC = y->R[i - 1].outC;
+        }
+    }
+    if (ok) ok = hipStreamCreateWithFlags(&y->stream, hipStreamNonBlocking) == hipSuccess;
+    if (!ok) { yolo_free(y); return set_err(SD_ERR_HIP, "detector allocation failed"); }
+    *out = y;
+    return SD_OK;
+}
+
+int sd_yolo_destroy(sd_yolo* y) { if (y) { (void)hipDeviceSynchronize(); yolo_free(y); } return SD_OK; }
+
+int sd_yolo_weight_count(const sd_yolo* y, size_t* n_floats)
+{
+    if (!y || !n_floats) return SD_ERR_INVALID;
+    size_t n = 0;
+    int C = 3;
+    for (size_t i = 0; i < y->L.size(); i++) {
+        const sd_yolo_layer& l = y->L[i];
+        if (l.type == SD_YOLO_CONV) {
+            const int cin = i == 0 ? 3 : (int)y->R[i].cinPad;
+            n += (size_t)l.filters * (l.batch_normalize ? 4 : 1) + (size_t)l.filters * cin * l.size * l.size;
+        }
+        (void)C;
+    }
+    *n_floats = n;
+    return SD_OK;
+}
+
+int sd_yolo_load_darknet_weights(sd_yolo* y, const float* p, size_t n_floats)
+{
+    if (!y || !p) return SD_ERR_INVALID;
+    size_t need = 0;
+    sd_yolo_weight_count(y, &need);
+    if (n_floats != need) return set_err(SD_ERR_INVALID, "weight payload has " + std::to_string(n_floats) + " floats, the network needs " + std::to_string(need));
+    std::vector<_Float16> w(y->wTotal, (_Float16)0.f);
+    std::vector<float> b(y->bTotal, 0.f);
+    for (size_t i = 0; i < y->L.size(); i++) {
+        const sd_yolo_layer& l = y->L[i];
+        if (l.type != SD_YOLO_CONV) continue;
+        const sd_yolo::Rt& r = y->R[i];
+        const int cin = i == 0 ? 3 : r.cinPad, F = l.filters, taps = l.size * l.size;
+        const float* biases = p; p += F;
+        const float *scales = nullptr, *mean = nullptr, *var = nullptr;
+        if (l.batch_normalize) { scales = p; p += F; mean = p; p += F; var = p; p += F; }
+        const float* wt = p; p += (size_t)F * cin * taps;
+        for (int f = 0; f < F; f++) {
+            // batch-norm folding as cv::dnn's Darknet importer applies it: y = (x - mean) * scale / sqrt(var + 1e-6) + beta
+            float s = 1.f, bias = biases[f];
+            if (l.batch_normalize) { s = scales[f] / sqrtf(var[f] + 0.000001f); bias = biases[f] - mean[f] * s; }
+            b[r.bOff + f] = bias;
+            for (int c = 0; c < cin; c++)
+                for (int t = 0; t < taps; t++)
+                    w[r.wOff + ((size_t)f * taps + t) * r.cinPad + c] = (_Float16)(wt[((size_t)f * cin + c) * taps + t] * s);
+        }
+    }
+    HIPCHK(hipMemcpy(y->d_wgt, w.data(), y->wTotal * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(y->d_bias, b.data(), y->bTotal * 4, hipMemcpyHostToDevice));
+    y->weightsLoaded = true;
+    return SD_OK;
+}
+
+int sd_yolo_layer_shape(const sd_yolo* y, int layer, int* h, int* w, int* c)
+{
+    if (!y || layer < 0 || layer >= (int)y->L.size()) return SD_ERR_INVALID;
+    if (h) *h = y->R[layer].H;
+    if (w) *w = y->R[layer].W;
+    if (c) *c = y->R[layer].C;
+    return SD_OK;
+}
+
+int sd_yolo_flops(const sd_yolo* y, double* flops_per_image)
+{
+    if (!y || !flops_per_image) return SD_ERR_INVALID;
+    *flops_per_image = y->convFlops;
+    return SD_OK;
+}
+
+int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int height, size_t stride, size_t image_pitch, int n,
+                           float conf_threshold, void* stream_)
+{
+    if (!y || !d_bgr || width < 2 || height < 2 || n < 1 || n > y->maxBatch || width > 8192 || height > 8192) return set_err(SD_ERR_INVALID, "bad forward arguments");
+    if (!y->weightsLoaded) return set_err(SD_ERR_STATE, "detector weights not loaded");
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : y->stream;
+    if (y->tabW != width || y->tabH != height) {
+        std::vector<int16_t> ct, rt;
+        yolo_resize_tables(width, height, y->netW, y->netH, ct, rt);
+        HIPCHK(hipMemcpy(y->d_ct, ct.data(), ct.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(y->d_rt, rt.data(), rt.size() * 2, hipMemcpyHostToDevice));
+        y->tabW = width; y->tabH = height;
+    }
+    {
+        dim3 blk(64, 4), grd((y->netW + 63) / 64, (y->netH + 3) / 4, n);
+        hipLaunchKernelGGL(k_blob_from_image, grd, blk, 0, s, d_bgr, width, height, stride, image_pitch, y->d_ct, y->d_rt, y->d_blob,
+                           y->netW, y->netH, 1);
+    }
+    LAUNCH_CHECK("k_blob_from_image");
+    HIPCHK(hipMemsetAsync(y->d_ndet, 0, (size_t)n * 4, s));
+    const _Float16* cur = y->d_blob;
+    int H = y->netH, W = y->netW, Cs = 32;
+    int rowBase = 0;
+    for (size_t i = 0; i < y->L.size(); i++) {
+        const sd_yolo_layer& l = y->L[i];
+        const sd_yolo::Rt& r = y->R[i];
+        if (l.type == SD_YOLO_CONV) {
+            SdConvArgs A;
+            A.in = cur; A.wgt = y->d_wgt + r.wOff; A.bias = y->d_bias + r.bOff; A.res = nullptr; A.out = r.out;
+            A.N = n; A.H = H; A.W = W; A.cin = r.cinPad; A.cinStride = Cs;
+            A.Ho = r.H; A.Wo = r.W; A.cout = l.filters; A.coutPad = r.coutPad; A.outStride = r.outC; A.outOff = 0; A.resStride = 0;
+            A.ksize = l.size; A.stride = l.stride; A.pad = l.size / 2; A.leaky = l.leaky;
+            if (i + 1 < y->L.size() && y->L[i + 1].type == SD_YOLO_SHORTCUT && y->R[i + 1].alias) {
+                const int f = yolo_resolve((int)i + 1, y->L[i + 1].from[0]);
+                A.res = y->R[f].out; A.resStride = y->R[f].outC;
+            }
+            const int npix = n * r.H * r.W;
+            dim3 grd((npix + SD_CV_BN - 1) / SD_CV_BN, r.coutPad / SD_CV_BM);
+            hipLaunchKernelGGL(k_conv_mfma, grd, dim3(256), 0, s, A);
+            LAUNCH_CHECK("k_conv_mfma");
+        } else if (l.type == SD_YOLO_SHORTCUT) {
+            if (!r.alias) return set_err(SD_ERR_UNSUPPORTED, "unfused [shortcut] is not implemented");
+        } else if (l.type == SD_YOLO_ROUTE && l.nfrom == 2) {
+            const int fa = yolo_resolve((int)i, l.from[0]), fb = yolo_resolve((int)i, l.from[1]);
+            const int src = yolo_resolve(fa, -1);          // the layer the [upsample] reads
+            const sd_yolo::Rt& ra = y->R[src]; const sd_yolo::Rt& rb = y->R[fb];
+            if (ra.outC != ra.C || rb.outC != rb.C || (ra.C % 8) || (rb.C % 8)) return set_err(SD_ERR_UNSUPPORTED, "route inputs must be dense, channels % 8 == 0");
+            hipLaunchKernelGGL(k_upsample_concat, dim3(2048), dim3(256), 0, s, ra.out, ra.C, ra.H, ra.W, rb.out, rb.C, r.out, n);
+            LAUNCH_CHECK("k_upsample_concat");
+        } else if (l.type == SD_YOLO_YOLO) {
+            const float* an = y->anchors;
+            const int rows = n * r.H * r.W * 3;
+            hipLaunchKernelGGL(k_region_decode, dim3((rows + 255) / 256), dim3(256), 0, s, r.out, r.outC, r.H, r.W, n, an[2 * l.mask[0]],
+                               an[2 * l.mask[0] + 1], an[2 * l.mask[1]], an[2 * l.mask[1] + 1], an[2 * l.mask[2]], an[2 * l.mask[2] + 1],
+                               y->netW, y->netH, conf_threshold, rowBase, y->d_dets, y->d_ndet, y->detCap, n == 1 ? y->d_raw : nullptr);
+            LAUNCH_CHECK("k_region_decode");
+            rowBase += r.H * r.W * 3;
+        }
+        // the input of the next layer
+        if (l.type != SD_YOLO_YOLO && l.type != SD_YOLO_UPSAMPLE) { cur = r.out; H = r.H; W = r.W; Cs = r.outC; }
+        if (l.type == SD_YOLO_YOLO) { cur = r.out; }
+    }
+    y->lastN = n;
+    if (!stream_) HIPCHK(hipStreamSynchronize(s));
+    return SD_OK;
+}
+
+int sd_yolo_download_layer(sd_yolo* y, int layer, int image, uint16_t* out)
+{
+    if (!y || !out || layer < 0 || layer >= (int)y->L.size() || image < 0 || image >= y->lastN) return SD_ERR_INVALID;
+    const sd_yolo::Rt& r = y->R[layer];
+    if (!r.out) return set_err(SD_ERR_INVALID, "layer has no materialised output");
+    HIPCHK(hipDeviceSynchronize());
+    const size_t pix = (size_t)r.H * r.W;
+    if (r.outC == r.C) {
+        HIPCHK(hipMemcpy(out, r.out + (size_t)image * pix * r.outC, pix * r.C * 2, hipMemcpyDeviceToHost));
+    } else {
+        HIPCHK(hipMemcpy2D(out, (size_t)r.C * 2, r.out + (size_t)image * pix * r.outC, (size_t)r.outC * 2, (size_t)r.C * 2, pix, hipMemcpyDeviceToHost));
+    }
+    return SD_OK;
+}
+
+int sd_yolo_download_region(sd_yolo* y, float* rows, int* total_rows)
+{
+    if (!y || !rows || y->lastN != 1) return set_err(SD_ERR_STATE, "region rows are kept only after a forward with n == 1");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(rows, y->d_raw, (size_t)y->totalRows * (5 + y->classes) * 4, hipMemcpyDeviceToHost));
+    if (total_rows) *total_rows = y->totalRows;
+    return SD_OK;
+}
+
+int sd_yolo_boxes(sd_yolo* y, int image, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold, double* boxes,
+                  int32_t* class_ids, float* confidences, int cap, int* n_out)
+{
+    if (!y || !n_out || image < 0 || image >= y->lastN || frame_cols < 1 || frame_rows < 1) return SD_ERR_INVALID;
+    HIPCHK(hipDeviceSynchronize());
+    int nd = 0;
+    HIPCHK(hipMemcpy(&nd, y->d_ndet + image, 4, hipMemcpyDeviceToHost));
+    if (nd > y->detCap) return set_err(SD_ERR_CAPACITY, "more than 8192 rows above the confidence threshold");
+    std::vector<SdDet> d(nd);
+    if (nd) HIPCHK(hipMemcpy(d.data(), y->d_dets + (size_t)image * y->detCap, (size_t)nd * sizeof(SdDet), hipMemcpyDeviceToHost));
+    std::sort(d.begin(), d.end(), [](const SdDet& a, const SdDet& b) { return a.row < b.row; });   // cv::dnn row order
+    std::vector<YRect> rects(nd);
+    for (int i = 0; i < nd; i++) {
+        if (!(d[i].conf > conf_threshold)) { rects[i] = YRect{0, 0, 0, 0}; continue; }
+        const int centerX = (int)(d[i].cx * frame_cols), centerY = (int)(d[i].cy * frame_rows);
+        const int width = (int)(d[i].w * frame_cols), height = (int)(d[i].h * frame_rows);
+        rects[i] = YRect{centerX - width / 2, centerY - height / 2, width, height};
+    }
+    // cv::dnn::NMSBoxes(boxes, confidences, score_threshold, nms_threshold): stable sort by score, greedy keep
+    std::vector<int> order;
+    for (int i = 0; i < nd; i++) if (d[i].conf > conf_threshold) order.push_back(i);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return d[a].conf > d[b].conf; });
+    std::vector<int> keep;
+    for (int idx : order) {
+        bool k = true;
+        for (size_t j = 0; j < keep.size() && k; j++) k = yolo_overlap(rects[idx], rects[keep[j]]) <= nms_threshold;
+        if (k) keep.push_back(idx);
+    }
+    int n = 0;
+    for (int idx : keep) {
+        const int c = d[idx].cls;     // coco.names: 0 person, 1 bicycle, 2 car, 3 motorbike ("motorcycle" never matches), 5 bus, 7 truck
+        if (!(c == 0 || c == 1 || c == 2 || c == 5 || c == 7)) continue;
+        if (n >= cap) return set_err(SD_ERR_CAPACITY, "box buffer too small");
+        const YRect& r = rects[idx];
+        // rectCenterScale(box, Size2d(-0.2 w, 0.6 h)): rect += size; rect -= size / 2
+        const double sw = -0.2 * (double)r.w, sh = 0.6 * (double)r.h;
+        if (boxes) { boxes[4 * n] = (double)r.x - sw / 2.0; boxes[4 * n + 1] = (double)r.y - sh / 2.0; boxes[4 * n + 2] = (double)r.w + sw; boxes[4 * n + 3] = (double)r.h + sh; }
+        if (class_ids) class_ids[n] = c;
+        if (confidences) confidences[n] = d[idx].conf;
+        n++;
+    }
+    *n_out = n;
     return SD_OK;
 }
 
