@@ -1,0 +1,28 @@
+"""Developer timing of the detector (images/s, achieved TFLOP/s vs the f16 MFMA dense peak)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import __graft_entry__ as g
+pkg = g.load_package(); synth = pkg.synth
+import torch
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+layers, anchors = pkg.yolo.v3_layers()
+payload, _ = pkg.yolo.synth_weights(layers, seed=3)
+d = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=B)
+d.load_weights(payload)
+cfg = synth.KITTI03_RGBD
+imgs = np.stack([np.ascontiguousarray(synth.rgbd_frame(6, t % 4, cfg)[0][:, :, ::-1]) for t in range(B)])
+dev = torch.from_numpy(imgs).cuda()
+H, W = imgs.shape[1:3]
+st = torch.cuda.current_stream().cuda_stream
+for _ in range(2):
+    d.forward_device(dev.data_ptr(), W, H, W * 3, W * H * 3, B, 0.5, st)
+torch.cuda.synchronize()
+K = 5
+t = time.time()
+for _ in range(K):
+    d.forward_device(dev.data_ptr(), W, H, W * 3, W * H * 3, B, 0.5, st)
+torch.cuda.synchronize()
+dt = (time.time() - t) / K
+fl = d.flops()
+print("batch %d: %.2f ms/batch, %.1f images/s, %.1f TFLOP/s (%.1f%% of 2500 dense f16)" % (B, dt * 1e3, B / dt, fl * B / dt / 1e12, fl * B / dt / 2.5e15 * 100))
