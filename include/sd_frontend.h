@@ -253,6 +253,10 @@ int sd_yolo_download_layer(sd_yolo* y, int layer, int image, uint16_t* f16_nhwc_
 int sd_yolo_download_region(sd_yolo* y, float* rows, int* total_rows);
 /* yolov3Segment::Segmentation_ result for one image (yolo.cc:151-206): NMSBoxes(conf, nms), class filter
  * {person, car, bicycle, bus, truck}, box width -20 % / height +60 % about the centre.  boxes: [cap][4] x,y,w,h. */
+/* yolov3Segment::Segmentation (yolo.cc:34-58, postprocess :80-137): d_mask (frame_rows x frame_cols u8 in HBM) = 1 except
+ * inside the 31x31-ellipse dilation of the kept boxes' central halves; all ones and *no_target = 1 when none is kept. */
+int sd_yolo_mask_device(sd_yolo* y, int image, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold,
+                        uint8_t* d_mask, size_t stride, int* no_target, void* stream);
 int sd_yolo_boxes(sd_yolo* y, int image, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold, double* boxes,
                   int32_t* class_ids, float* confidences, int cap, int* n);
 

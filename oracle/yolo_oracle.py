@@ -107,3 +107,59 @@ def postprocess(rows, frame_cols, frame_rows, conf_thr=0.5, nms_thr=0.4):
             sw, sh = -0.2 * w, 0.6 * h
             out.append((x - sw / 2.0, y - sh / 2.0, w + sw, h + sh)); oc.append(cls[i]); of.append(confs[i])
     return np.array(out, np.float64).reshape(-1, 4), np.array(oc, np.int32), np.array(of, np.float32)
+
+
+def ellipse_element(ksize=31):
+    """cv::getStructuringElement(MORPH_ELLIPSE, Size(k, k)) [OpenCV-recall]."""
+    r = c = ksize // 2
+    inv_r2 = 1.0 / (r * r)
+    el = np.zeros((ksize, ksize), np.uint8)
+    for i in range(ksize):
+        dy = i - r
+        dx = int(np.rint(c * np.sqrt((r * r - dy * dy) * inv_r2)))
+        el[i, max(c - dx, 0):min(c + dx + 1, ksize)] = 1
+    return el
+
+
+def segmentation_mask(rows, frame_cols, frame_rows, conf_thr=0.5, nms_thr=0.4):
+    """yolov3Segment::Segmentation (yolo.cc:34-58) from region rows: (mask u8, noTarget)."""
+    boxes, confs, cls = [], [], []
+    for r in rows:
+        sc = r[5:]
+        c = int(np.argmax(sc)); confidence = float(sc[c])
+        if confidence > np.float32(conf_thr):
+            cx = int(np.float32(r[0]) * np.float32(frame_cols)); cy = int(np.float32(r[1]) * np.float32(frame_rows))
+            w = int(np.float32(r[2]) * np.float32(frame_cols)); h = int(np.float32(r[3]) * np.float32(frame_rows))
+            boxes.append((cx - int(w / 2), cy - int(h / 2), w, h)); confs.append(np.float32(confidence)); cls.append(c)
+    order = sorted(range(len(boxes)), key=lambda i: -confs[i])
+
+    def overlap(a, b):
+        Aa, Ab = a[2] * a[3], b[2] * b[3]
+        if Aa + Ab <= 2.220446049250313e-16:
+            return np.float32(1)
+        x1, y1 = max(a[0], b[0]), max(a[1], b[1]); x2, y2 = min(a[0] + a[2], b[0] + b[2]), min(a[1] + a[3], b[1] + b[3])
+        Aab = (x2 - x1) * (y2 - y1) if (x2 > x1 and y2 > y1) else 0
+        return np.float32(1. - (1. - Aab / (Aa + Ab - Aab)))
+    keep = []
+    for i in order:
+        if all(overlap(boxes[i], boxes[j]) <= np.float32(nms_thr) for j in keep):
+            keep.append(i)
+    m = np.zeros((frame_rows, frame_cols), np.uint8)
+    no_target = True
+    for i in keep:
+        if cls[i] in KEEP_CLASSES:
+            x, y, w, h = boxes[i]
+            x0, x1 = max(0, x + int(w / 4)), min(x + int(3 * w / 4), frame_cols)     # C++ int division of non-negative values
+            y0, y1 = max(0, y), min(y + h, frame_rows)
+            if x1 > x0 and y1 > y0:
+                m[y0:y1, x0:x1] = 1
+            no_target = False
+    if no_target:
+        return np.ones((frame_rows, frame_cols), np.uint8), True
+    el = ellipse_element(31)
+    dil = np.zeros_like(m)
+    ys, xs = np.nonzero(el)
+    pad = np.pad(m, 15)
+    for dy, dx in zip(ys - 15, xs - 15):
+        dil |= pad[15 + dy:15 + dy + frame_rows, 15 + dx:15 + dx + frame_cols]
+    return (1 - dil).astype(np.uint8), False

@@ -230,3 +230,39 @@ __global__ void __launch_bounds__(256) k_region_decode(const _Float16* __restric
         }
     }
 }
+
+
+// yolov3Segment::Segmentation (yolo.cc:34-58) after NMS: rasterise the central half-width of every kept box
+// (postprocess, yolo.cc:128-131), dilate with cv::getStructuringElement(MORPH_ELLIPSE, 31x31) and return
+// 1 - dilated.  One 16x16 pixel tile per workgroup; the rasterised mask of the tile + 15-px halo lives in LDS;
+// span[dy] = half-width of the ellipse row (dx such that columns c-dx .. c+dx are set).
+struct SdMaskRects { int n; int x0[32], y0[32], x1[32], y1[32]; };   // filled region [x0,x1) x [y0,y1)
+__global__ void __launch_bounds__(256) k_mask_dilate(SdMaskRects R, int cols, int rows, uint8_t* __restrict__ mask, size_t stride)
+{
+    __shared__ uint8_t t[46][48];
+    __shared__ int span[31];
+    const int bx = blockIdx.x * 16, by = blockIdx.y * 16, tid = threadIdx.x;
+    if (tid < 31) {
+        const int r = 15, c = 15, dy = tid - r;
+        const double inv_r2 = 1.0 / ((double)r * r);
+        span[tid] = (int)lrint(c * sqrt((double)(r * r - dy * dy) * inv_r2));     // saturate_cast<int>(double) = cvRound
+    }
+    for (int i = tid; i < 46 * 46; i += 256) {
+        const int ty = i / 46, tx = i - ty * 46;
+        const int x = bx + tx - 15, y = by + ty - 15;
+        uint8_t v = 0;
+        if (x >= 0 && x < cols && y >= 0 && y < rows)
+            for (int k = 0; k < R.n; k++) v |= (x >= R.x0[k] && x < R.x1[k] && y >= R.y0[k] && y < R.y1[k]);
+        t[ty][tx] = v;
+    }
+    __syncthreads();
+    const int lx = tid & 15, ly = tid >> 4;
+    const int x = bx + lx, y = by + ly;
+    if (x >= cols || y >= rows) return;
+    int hit = 0;
+    for (int dy = -15; dy <= 15 && !hit; dy++) {
+        const int dx = span[dy + 15];
+        for (int k = -dx; k <= dx; k++) hit |= t[ly + 15 + dy][lx + 15 + k];
+    }
+    mask[(size_t)y * stride + x] = (uint8_t)(1 - (hit ? 1 : 0));
+}

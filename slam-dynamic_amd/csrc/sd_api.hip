@@ -1569,25 +1569,24 @@ int sd_yolo_download_region(sd_yolo* y, float* rows, int* total_rows)
     return SD_OK;
 }
 
-int sd_yolo_boxes(sd_yolo* y, int image, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold, double* boxes,
-                  int32_t* class_ids, float* confidences, int cap, int* n_out)
+// shared by Segmentation_ / Segmentation: rows above the threshold -> int boxes -> NMSBoxes -> kept (class-filtered) indices
+static int yolo_nms(sd_yolo* y, int image, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold,
+                    std::vector<SdDet>& d, std::vector<YRect>& rects, std::vector<int>& kept)
 {
-    if (!y || !n_out || image < 0 || image >= y->lastN || frame_cols < 1 || frame_rows < 1) return SD_ERR_INVALID;
     HIPCHK(hipDeviceSynchronize());
     int nd = 0;
     HIPCHK(hipMemcpy(&nd, y->d_ndet + image, 4, hipMemcpyDeviceToHost));
     if (nd > y->detCap) return set_err(SD_ERR_CAPACITY, "more than 8192 rows above the confidence threshold");
-    std::vector<SdDet> d(nd);
+    d.resize(nd);
     if (nd) HIPCHK(hipMemcpy(d.data(), y->d_dets + (size_t)image * y->detCap, (size_t)nd * sizeof(SdDet), hipMemcpyDeviceToHost));
     std::sort(d.begin(), d.end(), [](const SdDet& a, const SdDet& b) { return a.row < b.row; });   // cv::dnn row order
-    std::vector<YRect> rects(nd);
+    rects.assign(nd, YRect{0, 0, 0, 0});
     for (int i = 0; i < nd; i++) {
-        if (!(d[i].conf > conf_threshold)) { rects[i] = YRect{0, 0, 0, 0}; continue; }
+        if (!(d[i].conf > conf_threshold)) continue;
         const int centerX = (int)(d[i].cx * frame_cols), centerY = (int)(d[i].cy * frame_rows);
         const int width = (int)(d[i].w * frame_cols), height = (int)(d[i].h * frame_rows);
         rects[i] = YRect{centerX - width / 2, centerY - height / 2, width, height};
     }
-    // cv::dnn::NMSBoxes(boxes, confidences, score_threshold, nms_threshold): stable sort by score, greedy keep
     std::vector<int> order;
     for (int i = 0; i < nd; i++) if (d[i].conf > conf_threshold) order.push_back(i);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return d[a].conf > d[b].conf; });
@@ -1597,21 +1596,61 @@ int sd_yolo_boxes(sd_yolo* y, int image, int frame_cols, int frame_rows, float c
         for (size_t j = 0; j < keep.size() && k; j++) k = yolo_overlap(rects[idx], rects[keep[j]]) <= nms_threshold;
         if (k) keep.push_back(idx);
     }
-    int n = 0;
+    kept.clear();
     for (int idx : keep) {
         const int c = d[idx].cls;     // coco.names: 0 person, 1 bicycle, 2 car, 3 motorbike ("motorcycle" never matches), 5 bus, 7 truck
-        if (!(c == 0 || c == 1 || c == 2 || c == 5 || c == 7)) continue;
-        if (n >= cap) return set_err(SD_ERR_CAPACITY, "box buffer too small");
-        const YRect& r = rects[idx];
-        // rectCenterScale(box, Size2d(-0.2 w, 0.6 h)): rect += size; rect -= size / 2
-        const double sw = -0.2 * (double)r.w, sh = 0.6 * (double)r.h;
-        if (boxes) { boxes[4 * n] = (double)r.x - sw / 2.0; boxes[4 * n + 1] = (double)r.y - sh / 2.0; boxes[4 * n + 2] = (double)r.w + sw; boxes[4 * n + 3] = (double)r.h + sh; }
-        if (class_ids) class_ids[n] = c;
-        if (confidences) confidences[n] = d[idx].conf;
-        n++;
+        if (c == 0 || c == 1 || c == 2 || c == 5 || c == 7) kept.push_back(idx);
     }
-    *n_out = n;
     return SD_OK;
+}
+
+// yolov3Segment::Segmentation (yolo.cc:34-58): mask = 1 outside the dilated central halves of the kept boxes; all ones
+// (and *no_target = 1) when nothing is kept.  d_mask: frame_rows x frame_cols u8 in HBM.
+int sd_yolo_mask_device(sd_yolo* y, int image, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold,
+                        uint8_t* d_mask, size_t stride, int* no_target, void* stream_)
+{
+    if (!y || !d_mask || image < 0 || image >= y->lastN || frame_cols < 1 || frame_rows < 1 || stride < (size_t)frame_cols) return SD_ERR_INVALID;
+    std::vector<SdDet> d; std::vector<YRect> rects; std::vector<int> kept;
+    int rc = yolo_nms(y, image, frame_cols, frame_rows, conf_threshold, nms_threshold, d, rects, kept);
+    if (rc != SD_OK) return rc;
+    if (kept.size() > 32) return set_err(SD_ERR_CAPACITY, "more than 32 kept boxes");
+    if (no_target) *no_target = kept.empty();
+    SdMaskRects R;
+    R.n = (int)kept.size();
+    for (int k = 0; k < R.n; k++) {
+        const YRect& b = rects[kept[k]];
+        R.x0[k] = std::max(0, b.x + b.w / 4); R.x1[k] = std::min(b.x + 3 * b.w / 4, frame_cols);
+        R.y0[k] = std::max(0, b.y); R.y1[k] = std::min(b.y + b.h, frame_rows);
+    }
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : y->stream;
+    hipLaunchKernelGGL(k_mask_dilate, dim3((frame_cols + 15) / 16, (frame_rows + 15) / 16), dim3(256), 0, s, R, frame_cols, frame_rows, d_mask, stride);
+    LAUNCH_CHECK("k_mask_dilate");
+    if (!stream_) HIPCHK(hipStreamSynchronize(s));
+    return SD_OK;
+}
+
+int sd_yolo_boxes(sd_yolo* y, int image, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold, double* boxes,
+                  int32_t* class_ids, float* confidences, int cap, int* n_out)
+{
+    if (!y || !n_out || image < 0 || image >= y->lastN || frame_cols < 1 || frame_rows < 1) return SD_ERR_INVALID;
+    {
+        std::vector<SdDet> d; std::vector<YRect> rects; std::vector<int> kept;
+        int rc = yolo_nms(y, image, frame_cols, frame_rows, conf_threshold, nms_threshold, d, rects, kept);
+        if (rc != SD_OK) return rc;
+        int n = 0;
+        for (int idx : kept) {
+            if (n >= cap) return set_err(SD_ERR_CAPACITY, "box buffer too small");
+            const YRect& r = rects[idx];
+            // rectCenterScale(box, Size2d(-0.2 w, 0.6 h)): rect += size; rect -= size / 2
+            const double sw = -0.2 * (double)r.w, sh = 0.6 * (double)r.h;
+            if (boxes) { boxes[4 * n] = (double)r.x - sw / 2.0; boxes[4 * n + 1] = (double)r.y - sh / 2.0; boxes[4 * n + 2] = (double)r.w + sw; boxes[4 * n + 3] = (double)r.h + sh; }
+            if (class_ids) class_ids[n] = d[idx].cls;
+            if (confidences) confidences[n] = d[idx].conf;
+            n++;
+        }
+        *n_out = n;
+        return SD_OK;
+    }
 }
 
 // ---------------------------------------------------------------- profiling

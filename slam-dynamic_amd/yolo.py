@@ -127,6 +127,7 @@ class Detector:
         L.sd_yolo_download_layer.argtypes = [vp, i, i, vp]
         L.sd_yolo_download_region.argtypes = [vp, vp, C.POINTER(i)]
         L.sd_yolo_boxes.argtypes = [vp, i, i, i, f, f, vp, vp, vp, i, C.POINTER(i)]
+        L.sd_yolo_mask_device.argtypes = [vp, i, i, i, f, f, vp, sz, C.POINTER(i), vp]
         fe.check(L.sd_yolo_create(C.byref(self.h), fe._p(self.layers), len(self.layers), fe._p(self.anchors), 80, net_w, net_h, max_batch))
 
     def close(self):
@@ -175,3 +176,9 @@ class Detector:
         n = C.c_int()
         fe.check(fe.lib().sd_yolo_boxes(self.h, image, frame_cols, frame_rows, conf, nms, fe._p(b), fe._p(cid), fe._p(cf), cap, C.byref(n)))
         return b[:n.value].copy(), cid[:n.value].copy(), cf[:n.value].copy()
+
+    def mask_device(self, image, frame_cols, frame_rows, d_mask_ptr, stride, conf=0.5, nms=0.4, stream=None):
+        nt = C.c_int()
+        fe.check(fe.lib().sd_yolo_mask_device(self.h, image, frame_cols, frame_rows, conf, nms, C.c_void_p(d_mask_ptr), stride,
+                                              C.byref(nt), C.c_void_p(stream or 0)))
+        return bool(nt.value)

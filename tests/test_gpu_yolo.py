@@ -96,3 +96,17 @@ def test_batch_of_two_images(det):
     assert np.array_equal(a0[0], b0) and np.array_equal(a0[1], c0)          # image 0 unchanged by batching
     assert not np.array_equal(a1[0], b0) or len(b0) == 0                     # the flipped image gives other boxes
     d.forward_device(dev.data_ptr(), W, H, W * 3, W * H * 3, 1, 0.5)         # restore single-image state
+
+
+def test_segmentation_mask(det):
+    """yolov3Segment::Segmentation: rasterised central halves, 31x31 ellipse dilation, 1 - mask; exact given the GPU's rows."""
+    import torch
+    d, yo, W, H = det["d"], det["yo"], det["W"], det["H"]
+    m = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+    nt = d.mask_device(0, W, H, m.data_ptr(), W)
+    torch.cuda.synchronize()
+    em, ent = yo.segmentation_mask(d.region_rows(), W, H)
+    assert nt == ent and not nt
+    got = m.cpu().numpy()
+    assert set(np.unique(got).tolist()) == {0, 1}
+    assert np.array_equal(got, em)
