@@ -29,25 +29,31 @@ struct SdConvArgs {
 
 #define SD_CV_BM 64          // couts per workgroup
 #define SD_CV_BN 256         // pixels per workgroup
-#define SD_CV_BK 32          // K step (two MFMA k-steps of 16)
-#define SD_CV_LD 40          // LDS row length in halfs (32 + 8 pad: ds_read_b128 rows 80 B apart)
 
-// 4 waves, each 64 couts x 64 pixels = 2 x 2 MFMA tiles of 32 x 32.
+// 4 waves, each 64 couts x 64 pixels = 2 x 2 MFMA tiles of 32 x 32.  K is walked in steps of BK channels of one
+// filter tap; the global loads of step k+1 are issued into registers before the MFMAs of step k and written to
+// LDS after them (one LDS buffer, two barriers per step), so the L2/HBM latency of the im2col gather overlaps
+// the matrix work.  BK = 64 when the input channel count allows it, else 32.
+template <int BK>
 __global__ void __launch_bounds__(256) k_conv_mfma(SdConvArgs A)
 {
-    __shared__ __align__(16) _Float16 sW[SD_CV_BM * SD_CV_LD];     //  5 KB
-    __shared__ __align__(16) _Float16 sX[SD_CV_BN * SD_CV_LD];     // 20 KB
+    constexpr int LD = BK + 8;                 // LDS row length in halfs (pad: ds_read_b128 rows 16 B off the bank period)
+    constexpr int CPR = BK / 8;                // 16-B chunks per row
+    constexpr int XC = SD_CV_BN * CPR / 256;   // activation chunks per thread per step
+    constexpr int WC = SD_CV_BM * CPR / 256;   // weight chunks per thread per step
+    __shared__ __align__(16) _Float16 sW[SD_CV_BM * LD];
+    __shared__ __align__(16) _Float16 sX[SD_CV_BN * LD];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int pix0 = blockIdx.x * SD_CV_BN, co0 = blockIdx.y * SD_CV_BM;
     const int npix = A.N * A.Ho * A.Wo;
-    // the 4 activation chunks (16 B = 8 channels) this thread stages per K step: chunk = tid + 256*i
-    int pyi[4], pxi[4];
-    size_t pbase[4];
-    bool pok[4];
+    // the activation chunks this thread stages per step: chunk = tid + 256*i -> pixel chunk / CPR, quarter chunk % CPR
+    int pyi[XC], pxi[XC];
+    size_t pbase[XC];
+    bool pok[XC];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < XC; i++) {
         const int chunk = tid + 256 * i;
-        const int p = pix0 + (chunk >> 2);
+        const int p = pix0 + chunk / CPR;
         pok[i] = p < npix;
         const int pp = pok[i] ? p : 0;
         const int n = pp / (A.Ho * A.Wo), r = pp - n * (A.Ho * A.Wo);
@@ -55,10 +61,9 @@ __global__ void __launch_bounds__(256) k_conv_mfma(SdConvArgs A)
         pyi[i] = yo * A.stride - A.pad; pxi[i] = xo * A.stride - A.pad;
         pbase[i] = (size_t)n * A.H * A.W;
     }
-    const int wrow = tid >> 2, wq = tid & 3;                      // weight chunk: cout row, 8-channel quarter
     const int taps = A.ksize * A.ksize;
-    const int ksteps = taps * (A.cin / SD_CV_BK);
-    const int cchunks = A.cin / SD_CV_BK;
+    const int cchunks = A.cin / BK;
+    const int ksteps = taps * cchunks;
     sd_f16v acc[2][2];
 #pragma unroll
     for (int m = 0; m < 2; m++)
@@ -67,32 +72,41 @@ __global__ void __launch_bounds__(256) k_conv_mfma(SdConvArgs A)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
     const int r32 = lane & 31, h = lane >> 5;
-    for (int ks = 0; ks < ksteps; ks++) {
-        const int t = ks / cchunks, c0 = (ks - t * cchunks) * SD_CV_BK;
-        const int kh = t / A.ksize, kw = t - kh * A.ksize;
-        // ---- stage W tile [64][32] and X tile [256][32]
-        {
-            const uint4 wv4 = *(const uint4*)(A.wgt + ((size_t)(co0 + wrow) * taps + t) * A.cin + c0 + 8 * wq);
-            *(uint4*)(sW + wrow * SD_CV_LD + 8 * wq) = wv4;
+    uint4 xr[XC], wr[WC];
+    int t = 0, c0 = 0, kh = 0, kw = 0;         // (tap, channel offset) of the step being fetched
+    auto fetch = [&]() {
+#pragma unroll
+        for (int i = 0; i < WC; i++) {
+            const int chunk = tid + 256 * i;
+            wr[i] = *(const uint4*)(A.wgt + ((size_t)(co0 + chunk / CPR) * taps + t) * A.cin + c0 + 8 * (chunk % CPR));
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < XC; i++) {
             const int chunk = tid + 256 * i;
             const int yi = pyi[i] + kh, xi = pxi[i] + kw;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            xr[i] = make_uint4(0u, 0u, 0u, 0u);
             if (pok[i] && yi >= 0 && yi < A.H && xi >= 0 && xi < A.W)
-                v = *(const uint4*)(A.in + (pbase[i] + (size_t)yi * A.W + xi) * A.cinStride + c0 + 8 * (chunk & 3));
-            *(uint4*)(sX + (chunk >> 2) * SD_CV_LD + 8 * (chunk & 3)) = v;
+                xr[i] = *(const uint4*)(A.in + (pbase[i] + (size_t)yi * A.W + xi) * A.cinStride + c0 + 8 * (chunk % CPR));
         }
-        __syncthreads();
-        // ---- fragments: A = W[row r32][k = 8h + j], B = X[k = 8h + j][col r32]; two k-steps of 16
+        c0 += BK;
+        if (c0 == A.cin) { c0 = 0; t++; kw++; if (kw == A.ksize) { kw = 0; kh++; } }
+    };
+    fetch();
+    for (int ks = 0; ks < ksteps; ks++) {
 #pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
+        for (int i = 0; i < WC; i++) { const int chunk = tid + 256 * i; *(uint4*)(sW + (chunk / CPR) * LD + 8 * (chunk % CPR)) = wr[i]; }
+#pragma unroll
+        for (int i = 0; i < XC; i++) { const int chunk = tid + 256 * i; *(uint4*)(sX + (chunk / CPR) * LD + 8 * (chunk % CPR)) = xr[i]; }
+        __syncthreads();
+        if (ks + 1 < ksteps) fetch();          // in flight during the MFMAs below
+        // fragments: A = W[row r32][k = 8h + j], B = X[k = 8h + j][col r32]; BK/16 k-steps of 16
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; kk++) {
             sd_h8 a[2], b[2];
 #pragma unroll
-            for (int m = 0; m < 2; m++) a[m] = *(const sd_h8*)(sW + (32 * m + r32) * SD_CV_LD + 16 * kk + 8 * h);
+            for (int m = 0; m < 2; m++) a[m] = *(const sd_h8*)(sW + (32 * m + r32) * LD + 16 * kk + 8 * h);
 #pragma unroll
-            for (int n = 0; n < 2; n++) b[n] = *(const sd_h8*)(sX + (64 * wv + 32 * n + r32) * SD_CV_LD + 16 * kk + 8 * h);
+            for (int n = 0; n < 2; n++) b[n] = *(const sd_h8*)(sX + (64 * wv + 32 * n + r32) * LD + 16 * kk + 8 * h);
 #pragma unroll
             for (int m = 0; m < 2; m++)
 #pragma unroll
@@ -136,7 +150,7 @@ __global__ void __launch_bounds__(256) k_conv_mfma(SdConvArgs A)
 
 // blobFromImage(image, 1/255, Size(640,480), Scalar(0,0,0), swapRB = true, crop = false): bilinear resize of
 // the 8-bit image (OpenCV resize INTER_LINEAR fixed-point path, per channel), swap R and B, scale to [0,1].
-// Output NHWC f16 with the 3 channels padded to 32 (zeros) so the first convolution runs on the MFMA path.
+// Output NHWC f16, 4 channels (3 + a zero); read directly by k_conv_first.
 __global__ void __launch_bounds__(256) k_blob_from_image(const uint8_t* __restrict__ src, int sw, int sh, size_t sstride,
                                                          size_t spitch, const short4* __restrict__ ct,
                                                          const short4* __restrict__ rt, _Float16* __restrict__ dst,
@@ -158,10 +172,67 @@ __global__ void __launch_bounds__(256) k_blob_from_image(const uint8_t* __restri
         const int v = ((((int)re.y * (h0 >> 4)) >> 16) + (((int)re.z * (h1 >> 4)) >> 16) + 2) >> 2;
         ch[c] = (float)(v & 255) * (float)(1 / 255.0);
     }
-    _Float16* o = dst + ((size_t)img * dh * dw + (size_t)y * dw + x) * 32;
-    o[0] = (_Float16)(swapRB ? ch[2] : ch[0]); o[1] = (_Float16)ch[1]; o[2] = (_Float16)(swapRB ? ch[0] : ch[2]);
+    sd_h4 o;
+    o[0] = (_Float16)(swapRB ? ch[2] : ch[0]); o[1] = (_Float16)ch[1]; o[2] = (_Float16)(swapRB ? ch[0] : ch[2]); o[3] = (_Float16)0.f;
+    *(sd_h4*)(dst + ((size_t)img * dh * dw + (size_t)y * dw + x) * 4) = o;
+}
+
+// First convolution (3 input channels, 3x3, stride 1, pad 1, <= 32 filters) straight from the 4-channel blob: the GEMM K
+// axis is k = tap*4 + c (9 taps -> 36, padded to 48 = 3 MFMA k-steps).  With the 32x32x16 fragment layout a lane's 8
+// B-operand halfs are exactly two taps of its own pixel, so the im2col gather is two 8-byte loads per k-step and needs no
+// LDS; the 32 x 48 weight tile lives in registers.  One wave = 64 pixels x 32 filters.
+__global__ void __launch_bounds__(256) k_conv_first(const _Float16* __restrict__ blob4, const _Float16* __restrict__ wgt,
+                                                    const float* __restrict__ bias, _Float16* __restrict__ out, int N, int H, int W,
+                                                    int cout, int outStride, int leaky)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r32 = lane & 31, h = lane >> 5;
+    const size_t npix = (size_t)N * H * W;
+    sd_h8 a[3];
 #pragma unroll
-    for (int c = 3; c < 32; c++) o[c] = (_Float16)0.f;
+    for (int kk = 0; kk < 3; kk++) a[kk] = *(const sd_h8*)(wgt + r32 * 48 + 16 * kk + 8 * h);
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+        const size_t p = (size_t)blockIdx.x * 256 + 64 * wv + 32 * n + r32;
+        const bool ok = p < npix;
+        const size_t pp = ok ? p : 0;
+        const int x = (int)(pp % W);
+        const size_t q = pp / W;
+        const int y = (int)(q % H);
+        const _Float16* img = blob4 + (q / H) * (size_t)H * W * 4;
+        sd_f16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) {
+            sd_h8 b;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int tp = 4 * kk + 2 * h + e;
+                const int ky = (tp * 11) >> 5, kx = tp - 3 * ky;          // tp / 3, tp % 3 for tp < 12
+                const int yy = y + ky - 1, xx = x + kx - 1;
+                sd_h4 v = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                if (ok && tp < 9 && yy >= 0 && yy < H && xx >= 0 && xx < W) v = *(const sd_h4*)(img + ((size_t)yy * W + xx) * 4);
+                b[4 * e] = v[0]; b[4 * e + 1] = v[1]; b[4 * e + 2] = v[2]; b[4 * e + 3] = v[3];
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kk], b, acc, 0, 0, 0);
+        }
+        if (!ok) continue;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int co = 8 * g + 4 * h;
+            if (co >= cout) continue;
+            sd_h4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float v = acc[4 * g + e] + bias[co + e];
+                if (leaky) v = v > 0.f ? v : 0.1f * v;
+                o[e] = (_Float16)v;
+            }
+            _Float16* dst = out + p * outStride + co;
+            if (co + 3 < cout) *(sd_h4*)dst = o;
+            else for (int e = 0; e < 4 && co + e < cout; e++) dst[e] = o[e];
+        }
+    }
 }
 
 // [upsample] stride 2 (nearest) of `a` (C1 channels, h x w) into channels [0, C1) of `out` (2h x 2w, C1 + C2
@@ -205,6 +276,9 @@ __global__ void __launch_bounds__(256) k_region_decode(const _Float16* __restric
     const _Float16* t = head + ((size_t)n * gh * gw + cell) * hs + a * 85;
     const float aw = a == 0 ? aw0 : a == 1 ? aw1 : aw2, ah = a == 0 ? ah0 : a == 1 ? ah1 : ah2;
     auto sig = [](float v) { return 1.f / (1.f + expf(-v)); };
+    // class scores are obj * sigmoid(.) <= obj (a product with a factor <= 1 never rounds above obj), so a row whose
+    // objectness is not above the threshold cannot pass the filter: skip its 80 class loads unless raw rows are wanted
+    if (!rawOut && !(sig((float)t[4]) > confThreshold)) return;
     const float cx = (sig((float)t[0]) + (float)x) / (float)gw;
     const float cy = (sig((float)t[1]) + (float)y) / (float)gh;
     const float bw = expf((float)t[2]) * aw / (float)netW;

@@ -1320,6 +1320,7 @@ int sd_yolo_create(sd_yolo** out, const sd_yolo_layer* layers, int n_layers, con
         sd_yolo::Rt& r = y->R[i];
         if (l.type == SD_YOLO_CONV) {
             if ((l.size != 1 && l.size != 3) || (l.stride != 1 && l.stride != 2) || l.filters < 1) { delete y; return set_err(SD_ERR_UNSUPPORTED, "convolution size/stride not supported"); }
+            if (i == 0 && (l.size != 3 || l.stride != 1 || l.filters > 32)) { delete y; return set_err(SD_ERR_UNSUPPORTED, "first convolution must be 3x3, stride 1, <= 32 filters"); }
             const int cinReal = i == 0 ? 3 : C;
             r.cinPad = i == 0 ? 32 : C;
             if (r.cinPad % 32) { delete y; return set_err(SD_ERR_UNSUPPORTED, "input channels must be a multiple of 32"); }
@@ -1366,7 +1367,8 @@ int sd_yolo_create(sd_yolo** out, const sd_yolo_layer* layers, int n_layers, con
     };
     bool ok = true;
     const size_t nB = (size_t)max_batch;
-    ok = ok && alloc((void**)&y->d_blob, nB * net_h * net_w * 32 * 2);
+    ok = ok && alloc((void**)&y->d_blob4, nB * net_h * net_w * 4 * 2);
+
     ok = ok && alloc((void**)&y->d_wgt, wOff * 2 + 64);
     ok = ok && alloc((void**)&y->d_bias, bOff * 4 + 64);
     ok = ok && alloc((void**)&y->d_dets, nB * y->detCap * sizeof(SdDet));
@@ -1453,7 +1455,12 @@ int sd_yolo_load_darknet_weights(sd_yolo* y, const float* p, size_t n_floats)
             b[r.bOff + f] = bias;
             for (int c = 0; c < cin; c++)
                 for (int t = 0; t < taps; t++)
-                    w[r.wOff + ((size_t)f * taps + t) * r.cinPad + c] = (_Float16)(wt[((size_t)f * cin + c) * taps + t] * s);
+                {
+                    if (i == 0)                        // k_conv_first: one 48-wide K row per filter, k = tap*4 + c
+                        w[r.wOff + (size_t)f * 48 + (size_t)t * 4 + c] = (_Float16)(wt[((size_t)f * cin + c) * taps + t] * s);
+                    else
+                        w[r.wOff + ((size_t)f * taps + t) * r.cinPad + c] = (_Float16)(wt[((size_t)f * cin + c) * taps + t] * s);
+                }
         }
     }
     HIPCHK(hipMemcpy(y->d_wgt, w.data(), y->wTotal * 2, hipMemcpyHostToDevice));
@@ -1493,18 +1500,23 @@ int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int heig
     }
     {
         dim3 blk(64, 4), grd((y->netW + 63) / 64, (y->netH + 3) / 4, n);
-        hipLaunchKernelGGL(k_blob_from_image, grd, blk, 0, s, d_bgr, width, height, stride, image_pitch, y->d_ct, y->d_rt, y->d_blob,
+        hipLaunchKernelGGL(k_blob_from_image, grd, blk, 0, s, d_bgr, width, height, stride, image_pitch, y->d_ct, y->d_rt, y->d_blob4,
                            y->netW, y->netH, 1);
     }
     LAUNCH_CHECK("k_blob_from_image");
     HIPCHK(hipMemsetAsync(y->d_ndet, 0, (size_t)n * 4, s));
-    const _Float16* cur = y->d_blob;
+    const _Float16* cur = y->d_blob4;
     int H = y->netH, W = y->netW, Cs = 32;
     int rowBase = 0;
     for (size_t i = 0; i < y->L.size(); i++) {
         const sd_yolo_layer& l = y->L[i];
         const sd_yolo::Rt& r = y->R[i];
-        if (l.type == SD_YOLO_CONV) {
+        if (l.type == SD_YOLO_CONV && i == 0) {
+            const size_t npix0 = (size_t)n * r.H * r.W;
+            hipLaunchKernelGGL(k_conv_first, dim3((unsigned)((npix0 + 255) / 256)), dim3(256), 0, s, y->d_blob4, y->d_wgt + r.wOff,
+                               y->d_bias + r.bOff, r.out, n, r.H, r.W, l.filters, r.outC, l.leaky);
+            LAUNCH_CHECK("k_conv_first");
+        } else if (l.type == SD_YOLO_CONV) {
             SdConvArgs A;
             A.in = cur; A.wgt = y->d_wgt + r.wOff; A.bias = y->d_bias + r.bOff; A.res = nullptr; A.out = r.out;
             A.N = n; A.H = H; A.W = W; A.cin = r.cinPad; A.cinStride = Cs;
@@ -1516,7 +1528,8 @@ int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int heig
             }
             const int npix = n * r.H * r.W;
             dim3 grd((npix + SD_CV_BN - 1) / SD_CV_BN, r.coutPad / SD_CV_BM);
-            hipLaunchKernelGGL(k_conv_mfma, grd, dim3(256), 0, s, A);
+            if (r.cinPad % 64 == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_mfma<64>), grd, dim3(256), 0, s, A);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_mfma<32>), grd, dim3(256), 0, s, A);
             LAUNCH_CHECK("k_conv_mfma");
         } else if (l.type == SD_YOLO_SHORTCUT) {
             if (!r.alias) return set_err(SD_ERR_UNSUPPORTED, "unfused [shortcut] is not implemented");

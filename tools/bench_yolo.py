@@ -18,7 +18,7 @@ st = torch.cuda.current_stream().cuda_stream
 for _ in range(2):
     d.forward_device(dev.data_ptr(), W, H, W * 3, W * H * 3, B, 0.5, st)
 torch.cuda.synchronize()
-K = 5
+K = 20
 t = time.time()
 for _ in range(K):
     d.forward_device(dev.data_ptr(), W, H, W * 3, W * H * 3, B, 0.5, st)
