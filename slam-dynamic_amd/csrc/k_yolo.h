@@ -148,6 +148,293 @@ __global__ void __launch_bounds__(256) k_conv_mfma(SdConvArgs A)
     }
 }
 
+// 3x3 / stride 1 / pad 1 convolution for feature maps up to SD_C3_MAXW wide: the im2col of k_conv_mfma re-reads every
+// activation nine times (once per tap) and once more per 64-filter tile, which makes those layers L2-bound.  Here a
+// workgroup owns 256 CONSECUTIVE pixels of the flattened [N][H][W] index and 128 filters.  For one 32-channel chunk the
+// flattened range [p0 - W - 1, p0 + 256 + W] (every tap's source pixel of every tile pixel) is staged in LDS ONCE and all
+// nine taps read their B fragments from it at row offsets kh*W + kw; out-of-image taps read a zero row.  Only the
+// 128 x 32 weight tile changes per tap (double-buffered, prefetched through registers, one barrier per tap).
+// Wave tile: 128 filters x 64 pixels = 4 x 2 MFMA 32x32x16 tiles.
+#define SD_C3_BM 128
+#define SD_C3_BN 256
+#define SD_C3_BK 32
+#define SD_C3_LD 40          // LDS row length in halfs (80 B: conflict-free ds_read_b128 over consecutive rows)
+#define SD_C3_MAXW 80
+#define SD_C3_XROWS (SD_C3_BN + 2 * SD_C3_MAXW + 2)
+#define SD_C3_XCH ((SD_C3_XROWS * 4 + 255) / 256)      // 16-B activation chunks per thread per channel chunk
+__global__ void __launch_bounds__(256, 2) k_conv3x3_flat(SdConvArgs A)
+{
+    __shared__ __align__(16) _Float16 sX[(SD_C3_XROWS + 1) * SD_C3_LD];
+    __shared__ __align__(16) _Float16 sW[2][SD_C3_BM * SD_C3_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r32 = lane & 31, h = lane >> 5;
+    const int W = A.W, H = A.H;
+    const int npix = A.N * H * W;
+    const int p0 = blockIdx.x * SD_C3_BN, co0 = blockIdx.y * SD_C3_BM;
+    const int xrows = SD_C3_BN + 2 * W + 2, ZR = xrows;          // ZR: the all-zero row
+    if (tid < 5) *(uint4*)(sX + ZR * SD_C3_LD + 8 * tid) = make_uint4(0u, 0u, 0u, 0u);
+    // B-fragment rows of this lane's two pixels
+    int jy[2], jx[2], jrow[2];
+    bool jok[2];
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+        const int j = 64 * wv + 32 * n + r32, p = p0 + j;
+        jok[n] = p < npix;
+        const int q = (jok[n] ? p : 0) / W;
+        jx[n] = (jok[n] ? p : 0) - q * W; jy[n] = q % H; jrow[n] = j;
+    }
+    sd_f16v acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+    const int nchunks = A.cin / SD_C3_BK;
+    uint4 xr[SD_C3_XCH], wr[2];
+    auto fetchX = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < SD_C3_XCH; i++) {
+            const int chunk = tid + 256 * i, r = chunk >> 2;
+            const int g = p0 - W - 1 + r;
+            xr[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (r < xrows && g >= 0 && g < npix) xr[i] = *(const uint4*)(A.in + (size_t)g * A.cinStride + c0 + 8 * (chunk & 3));
+        }
+    };
+    auto storeX = [&]() {
+#pragma unroll
+        for (int i = 0; i < SD_C3_XCH; i++) {
+            const int chunk = tid + 256 * i, r = chunk >> 2;
+            if (r < xrows) *(uint4*)(sX + r * SD_C3_LD + 8 * (chunk & 3)) = xr[i];
+        }
+    };
+    auto fetchW = [&](int tap, int c0) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int chunk = tid + 256 * i;
+            wr[i] = *(const uint4*)(A.wgt + ((size_t)(co0 + (chunk >> 2)) * 9 + tap) * A.cin + c0 + 8 * (chunk & 3));
+        }
+    };
+    auto storeW = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) { const int chunk = tid + 256 * i; *(uint4*)(sW[buf] + (chunk >> 2) * SD_C3_LD + 8 * (chunk & 3)) = wr[i]; }
+    };
+    fetchX(0); fetchW(0, 0);
+    storeX(); storeW(0);
+    __syncthreads();
+    int step = 0;
+    for (int ch = 0; ch < nchunks; ch++) {
+        const bool moreX = ch + 1 < nchunks;
+        if (moreX) fetchX((ch + 1) * SD_C3_BK);            // lands while the nine taps run
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++, step++) {
+            const int buf = step & 1;
+            const bool moreW = tap < 8 || moreX;
+            if (moreW) fetchW(tap < 8 ? tap + 1 : 0, (tap < 8 ? ch : ch + 1) * SD_C3_BK);
+            const int kh = tap / 3, kw = tap % 3;
+            int brow[2];
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                const int yy = jy[n] + kh - 1, xx = jx[n] + kw - 1;
+                brow[n] = (jok[n] && yy >= 0 && yy < H && xx >= 0 && xx < W) ? jrow[n] + kh * W + kw : ZR;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                sd_h8 a[4], b[2];
+#pragma unroll
+                for (int m = 0; m < 4; m++) a[m] = *(const sd_h8*)(sW[buf] + (32 * m + r32) * SD_C3_LD + 16 * kk + 8 * h);
+#pragma unroll
+                for (int n = 0; n < 2; n++) b[n] = *(const sd_h8*)(sX + brow[n] * SD_C3_LD + 16 * kk + 8 * h);
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+#pragma unroll
+                    for (int n = 0; n < 2; n++)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[n], acc[m][n], 0, 0, 0);
+            }
+            if (moreW) storeW(buf ^ 1);                    // the other buffer: its readers finished before the last barrier
+            if (tap == 8 && moreX) { __syncthreads(); storeX(); }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+        const int p = p0 + 64 * wv + 32 * n + r32;
+        if (p >= npix) continue;
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int co = co0 + 32 * m + 8 * g + 4 * h;
+                if (co >= A.cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float x = acc[m][n][4 * g + e] + A.bias[co + e];
+                    if (A.leaky) x = x > 0.f ? x : 0.1f * x;
+                    v[e] = x;
+                }
+                if (A.res) {
+                    const sd_h4 rr = *(const sd_h4*)(A.res + (size_t)p * A.resStride + co);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] += (float)rr[e];
+                }
+                sd_h4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = (_Float16)v[e];
+                _Float16* dst = A.out + (size_t)p * A.outStride + A.outOff + co;
+                if (co + 3 < A.cout) *(sd_h4*)dst = o;
+                else for (int e = 0; e < 4 && co + e < A.cout; e++) dst[e] = o[e];
+            }
+    }
+}
+
+// The same flattened 3x3 scheme with every staging copy done by LDS-DMA (global_load_lds_dwordx4), so no VGPR holds
+// prefetched tiles and the copies stay in flight across barriers:
+//   * 512 threads = 8 waves, tile 128 filters x 512 consecutive pixels, wave tile 128 x 64 (4 x 2 MFMA 32x32x16);
+//   * X (activations of one 32-channel chunk, flattened range + halo) is double-buffered: chunk c+1 is requested at tap 1
+//     of chunk c and has eight taps to land;
+//   * W (128 x 32 weights of one tap) goes through a 5-slot ring, requested three taps ahead; one raw s_barrier per tap,
+//     preceded by a COUNTED s_waitcnt vmcnt(N) that only retires the tile about to be read;
+//   * an LDS-DMA wave-instruction writes 1 KiB linearly (16 rows x 64 B), so rows cannot be padded: the 16-byte slot a
+//     lane fills holds channel group q ^ ((row >> 2) & 3) (swizzle applied on the SOURCE address) and fragment reads apply
+//     the same XOR, which keeps every ds_read_b128 lane group on 16 distinct bank quads.
+#define SD_G3_BM 128
+#define SD_G3_BN 512
+#define SD_G3_ZROW 688                      // (512 + 2*80 + 2 = 674 rows) rounded up to 16; row 688 is all zero
+#define SD_G3_XBYTES 44288                  // 692 rows x 64 B (a multiple of 256 B so both buffers bank alike)
+#define SD_G3_NW 5
+#define SD_G3_WBYTES (SD_G3_BM * 64)
+#define SD_G3_LDS (2 * SD_G3_XBYTES + SD_G3_NW * SD_G3_WBYTES)
+#define SD_G3_XPIECES 6                     // LDS-DMA instructions per wave per X chunk (43 groups of 16 rows over 8 waves)
+typedef __attribute__((address_space(3))) void sd_lds_void;
+typedef const __attribute__((address_space(1))) void sd_glb_void;
+#define SD_GLDS16(gsrc, ldst) __builtin_amdgcn_global_load_lds((sd_glb_void*)(gsrc), (sd_lds_void*)(ldst), 16, 0, 0)
+
+__global__ void __launch_bounds__(512, 1) k_conv3x3_glds(SdConvArgs A)
+{
+    extern __shared__ __align__(1024) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r32 = lane & 31, h = lane >> 5;
+    const int W = A.W, H = A.H;
+    const int npix = A.N * H * W;
+    const int p0 = blockIdx.x * SD_G3_BN, co0 = blockIdx.y * SD_G3_BM;
+    const int xrows = SD_G3_BN + 2 * W + 2, ngroups = (xrows + 15) >> 4;
+    if (tid < 8) *(uint4*)(smem + (tid >> 2) * SD_G3_XBYTES + SD_G3_ZROW * 64 + 16 * (tid & 3)) = make_uint4(0u, 0u, 0u, 0u);
+    // ---- LDS-DMA sources of this lane: slot (row = lane>>2, q' = lane&3) of a 16-row group holds channel group q' ^ sw
+    const int qsrc = (lane & 3) ^ ((lane >> 4) & 3);
+    const _Float16* xsrc[SD_G3_XPIECES];
+    int xdst[SD_G3_XPIECES];
+#pragma unroll
+    for (int i = 0; i < SD_G3_XPIECES; i++) {
+        int g = wv + 8 * i;
+        if (g >= ngroups) g -= 8;                       // surplus piece: rewrite this wave's previous group with the same bytes
+        const int r = 16 * g + (lane >> 2);
+        int gp = p0 - W - 1 + r;                        // rows outside [0, npix) are only ever addressed by masked taps
+        gp = gp < 0 ? 0 : (gp >= npix ? npix - 1 : gp);
+        xsrc[i] = A.in + (size_t)gp * A.cinStride + 8 * qsrc;
+        xdst[i] = 1024 * g;
+    }
+    const _Float16* wsrc = A.wgt + (size_t)(co0 + 16 * wv + (lane >> 2)) * 9 * A.cin + 8 * qsrc;
+    unsigned char* const wring = smem + 2 * SD_G3_XBYTES;
+    const int nchunks = A.cin / 32;
+    auto issueX = [&](int ch) {
+        unsigned char* xb = smem + (ch & 1) * SD_G3_XBYTES;
+#pragma unroll
+        for (int i = 0; i < SD_G3_XPIECES; i++) SD_GLDS16(xsrc[i] + ch * 32, xb + xdst[i]);
+    };
+    int wtap = 0, wch = 0, wslot = 0;                   // the next weight stage to request
+    auto issueW = [&]() {
+        SD_GLDS16(wsrc + (size_t)wtap * A.cin + wch * 32, wring + wslot * SD_G3_WBYTES + 1024 * wv);
+        wslot = wslot == SD_G3_NW - 1 ? 0 : wslot + 1;
+        if (!(wtap == 8 && wch == nchunks - 1)) { wtap++; if (wtap == 9) { wtap = 0; wch++; } }     // saturate: surplus requests re-fetch the last stage
+    };
+    // ---- fragment addressing
+    int jy[2], jx[2], jrow[2];
+    bool jok[2];
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+        const int j = 64 * wv + 32 * n + r32, p = p0 + j;
+        jok[n] = p < npix;
+        const int q = (jok[n] ? p : 0) / W;
+        jx[n] = (jok[n] ? p : 0) - q * W; jy[n] = q % H; jrow[n] = j;
+    }
+    const int aoff = r32 * 64 + ((h ^ ((r32 >> 2) & 3)) << 4);
+    sd_f16v acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+    __syncthreads();                                    // zero rows written
+    issueX(0); issueW(); issueW(); issueW();
+    int rslot = 0;
+    for (int ch = 0; ch < nchunks; ch++) {
+        const unsigned char* xb = smem + (ch & 1) * SD_G3_XBYTES;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            issueW();                                    // stage s+3 -> the slot read at step s-2
+            if (tap == 1) issueX(ch + 1 < nchunks ? ch + 1 : ch);
+            // retire W(s) (and X(ch) at tap 0): everything requested after it may stay in flight
+            if (tap >= 1 && tap <= 4) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const unsigned char* wb = wring + rslot * SD_G3_WBYTES;
+            rslot = rslot == SD_G3_NW - 1 ? 0 : rslot + 1;
+            const int kh = tap / 3, kw = tap % 3;
+            int boff[2];
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                const int yy = jy[n] + kh - 1, xx = jx[n] + kw - 1;
+                const int row = (jok[n] && yy >= 0 && yy < H && xx >= 0 && xx < W) ? jrow[n] + kh * W + kw : SD_G3_ZROW;
+                boff[n] = row * 64 + ((h ^ ((row >> 2) & 3)) << 4);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                sd_h8 a[4], b[2];
+#pragma unroll
+                for (int m = 0; m < 4; m++) a[m] = *(const sd_h8*)(wb + ((aoff ^ (32 * kk)) + 2048 * m));
+#pragma unroll
+                for (int n = 0; n < 2; n++) b[n] = *(const sd_h8*)(xb + (boff[n] ^ (32 * kk)));
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+#pragma unroll
+                    for (int n = 0; n < 2; n++)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[n], acc[m][n], 0, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // surplus LDS-DMA must not outlive the workgroup's LDS
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+        const int p = p0 + 64 * wv + 32 * n + r32;
+        if (p >= npix) continue;
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int co = co0 + 32 * m + 8 * g + 4 * h;
+                if (co >= A.cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float x = acc[m][n][4 * g + e] + A.bias[co + e];
+                    if (A.leaky) x = x > 0.f ? x : 0.1f * x;
+                    v[e] = x;
+                }
+                if (A.res) {
+                    const sd_h4 rr = *(const sd_h4*)(A.res + (size_t)p * A.resStride + co);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] += (float)rr[e];
+                }
+                sd_h4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = (_Float16)v[e];
+                _Float16* dst = A.out + (size_t)p * A.outStride + A.outOff + co;
+                if (co + 3 < A.cout) *(sd_h4*)dst = o;
+                else for (int e = 0; e < 4 && co + e < A.cout; e++) dst[e] = o[e];
+            }
+    }
+}
+
 // blobFromImage(image, 1/255, Size(640,480), Scalar(0,0,0), swapRB = true, crop = false): bilinear resize of
 // the 8-bit image (OpenCV resize INTER_LINEAR fixed-point path, per channel), swap R and B, scale to [0,1].
 // Output NHWC f16, 4 channels (3 + a zero); read directly by k_conv_first.

@@ -1528,7 +1528,13 @@ int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int heig
             }
             const int npix = n * r.H * r.W;
             dim3 grd((npix + SD_CV_BN - 1) / SD_CV_BN, r.coutPad / SD_CV_BM);
-            if (r.cinPad % 64 == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_mfma<64>), grd, dim3(256), 0, s, A);
+            if (l.size == 3 && l.stride == 1 && W <= SD_C3_MAXW && l.filters % SD_G3_BM == 0 && r.cinPad % 32 == 0 && npix >= SD_G3_BN) {
+                static bool attr = false;
+                if (!attr) { HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_glds, hipFuncAttributeMaxDynamicSharedMemorySize, SD_G3_LDS)); attr = true; }
+                hipLaunchKernelGGL(k_conv3x3_glds, dim3((npix + SD_G3_BN - 1) / SD_G3_BN, l.filters / SD_G3_BM), dim3(512), SD_G3_LDS, s, A);
+            } else if (l.size == 3 && l.stride == 1 && W <= SD_C3_MAXW && l.filters % SD_C3_BM == 0 && r.cinPad % SD_C3_BK == 0)
+                hipLaunchKernelGGL(k_conv3x3_flat, dim3((npix + SD_C3_BN - 1) / SD_C3_BN, l.filters / SD_C3_BM), dim3(256), 0, s, A);
+            else if (r.cinPad % 64 == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_mfma<64>), grd, dim3(256), 0, s, A);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_mfma<32>), grd, dim3(256), 0, s, A);
             LAUNCH_CHECK("k_conv_mfma");
         } else if (l.type == SD_YOLO_SHORTCUT) {
