@@ -435,6 +435,115 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_glds(SdConvArgs A)
     }
 }
 
+// Epilogue shared by the LDS-DMA kernels: wave tile 128 filters x 64 pixels held as acc[4][2] (D layout of
+// v_mfma_f32_32x32x16: column = pixel lane&31, rows = filters (reg&3) + 8*(reg>>2) + 4*(lane>>5)).
+__device__ __forceinline__ void sd_conv_epilogue(const SdConvArgs& A, sd_f16v (&acc)[4][2], int pbase, int co0, int npix, int r32, int h)
+{
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+        const int p = pbase + 32 * n + r32;
+        if (p >= npix) continue;
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int co = co0 + 32 * m + 8 * g + 4 * h;
+                if (co >= A.cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float x = acc[m][n][4 * g + e] + A.bias[co + e];
+                    if (A.leaky) x = x > 0.f ? x : 0.1f * x;
+                    v[e] = x;
+                }
+                if (A.res) {
+                    const sd_h4 rr = *(const sd_h4*)(A.res + (size_t)p * A.resStride + co);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] += (float)rr[e];
+                }
+                sd_h4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = (_Float16)v[e];
+                _Float16* dst = A.out + (size_t)p * A.outStride + A.outOff + co;
+                if (co + 3 < A.cout) *(sd_h4*)dst = o;
+                else for (int e = 0; e < 4 && co + e < A.cout; e++) dst[e] = o[e];
+            }
+    }
+}
+
+// 1x1 convolution (a plain GEMM over pixels) with LDS-DMA staging: NWAVES waves, tile 128 filters x 64*NWAVES pixels,
+// three-stage ring of {X: pixels x 32 channels, W: 128 x 32}; stage s+2 is requested right after the barrier of step s
+// (every wave has then finished reading the slot it overwrites), and the counted vmcnt before the next barrier leaves
+// exactly that one stage in flight.  These layers move cin + cout halfs per pixel for 2*cin*cout flops: they are bound by
+// the activation stream, which this kernel reads once per 128-filter tile in full 64-byte pieces.
+template <int NWAVES>
+__global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 1 : 2) k_conv1x1_glds(SdConvArgs A)
+{
+    constexpr int BN = 64 * NWAVES;
+    constexpr int XB = BN * 64, STAGE = XB + SD_G3_WBYTES;
+    constexpr int WP = 8 / NWAVES;                    // weight pieces per wave per stage
+    extern __shared__ __align__(1024) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r32 = lane & 31, h = lane >> 5;
+    const int npix = A.N * A.Ho * A.Wo;
+    const int p0 = blockIdx.x * BN, co0 = blockIdx.y * SD_G3_BM;
+    const int qsrc = (lane & 3) ^ ((lane >> 4) & 3);
+    const _Float16* xsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int gp = p0 + 16 * (wv + NWAVES * i) + (lane >> 2);
+        gp = gp >= npix ? npix - 1 : gp;
+        xsrc[i] = A.in + (size_t)gp * A.cinStride + 8 * qsrc;
+    }
+    const _Float16* wsrc[WP];
+#pragma unroll
+    for (int i = 0; i < WP; i++) wsrc[i] = A.wgt + (size_t)(co0 + 16 * (wv + NWAVES * i) + (lane >> 2)) * A.cin + 8 * qsrc;
+    const int nsteps = A.cin / 32;
+    auto issue = [&](int st, int slot) {
+        const int c0 = (st < nsteps ? st : nsteps - 1) * 32;                  // surplus requests re-fetch the last stage
+        unsigned char* sb = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; i++) SD_GLDS16(xsrc[i] + c0, sb + 1024 * (wv + NWAVES * i));
+#pragma unroll
+        for (int i = 0; i < WP; i++) SD_GLDS16(wsrc[i] + c0, sb + XB + 1024 * (wv + NWAVES * i));
+    };
+    const int aoff = r32 * 64 + ((h ^ ((r32 >> 2) & 3)) << 4);
+    int boff[2];
+#pragma unroll
+    for (int n = 0; n < 2; n++) { const int row = 64 * wv + 32 * n + r32; boff[n] = row * 64 + ((h ^ ((row >> 2) & 3)) << 4); }
+    sd_f16v acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+    issue(0, 0); issue(1, 1);
+    int slot = 0;
+    for (int s = 0; s < nsteps; s++) {
+        if (NWAVES == 8) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(s + 2, slot == 0 ? 2 : slot - 1);                                // (s + 2) % 3
+        const unsigned char* xb = smem + slot * STAGE;
+        const unsigned char* wb = xb + XB;
+        slot = slot == 2 ? 0 : slot + 1;
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            sd_h8 a[4], b[2];
+#pragma unroll
+            for (int m = 0; m < 4; m++) a[m] = *(const sd_h8*)(wb + ((aoff ^ (32 * kk)) + 2048 * m));
+#pragma unroll
+            for (int n = 0; n < 2; n++) b[n] = *(const sd_h8*)(xb + (boff[n] ^ (32 * kk)));
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int n = 0; n < 2; n++)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // surplus LDS-DMA must not outlive the workgroup's LDS
+    sd_conv_epilogue(A, acc, p0 + 64 * wv, co0, npix, r32, h);
+}
+
 // blobFromImage(image, 1/255, Size(640,480), Scalar(0,0,0), swapRB = true, crop = false): bilinear resize of
 // the 8-bit image (OpenCV resize INTER_LINEAR fixed-point path, per channel), swap R and B, scale to [0,1].
 // Output NHWC f16, 4 channels (3 + a zero); read directly by k_conv_first.
@@ -556,29 +665,54 @@ __global__ void __launch_bounds__(256) k_region_decode(const _Float16* __restric
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int perImg = gh * gw * 3;
-    if (i >= N * perImg) return;
-    const int n = i / perImg, r = i - n * perImg;
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < N * perImg;
+    const int ii = valid ? i : 0;
+    const int n = ii / perImg, r = ii - n * perImg;
     const int a = r % 3, cell = r / 3;
     const int y = cell / gw, x = cell - y * gw;
     const _Float16* t = head + ((size_t)n * gh * gw + cell) * hs + a * 85;
-    const float aw = a == 0 ? aw0 : a == 1 ? aw1 : aw2, ah = a == 0 ? ah0 : a == 1 ? ah1 : ah2;
     auto sig = [](float v) { return 1.f / (1.f + expf(-v)); };
+    const float obj = valid ? sig((float)t[4]) : 0.f;
     // class scores are obj * sigmoid(.) <= obj (a product with a factor <= 1 never rounds above obj), so a row whose
-    // objectness is not above the threshold cannot pass the filter: skip its 80 class loads unless raw rows are wanted
-    if (!rawOut && !(sig((float)t[4]) > confThreshold)) return;
+    // objectness is not above the threshold cannot pass the filter; only the other rows (all rows when the raw
+    // tensor is requested) have their 80 classes scored, and those are scored by the whole wave: lane c takes
+    // classes c and c + 64 (one coalesced 160-byte read), then a butterfly keeps the first maximum as minMaxLoc does.
+    const bool want = valid && (rawOut != nullptr || obj > confThreshold);
+    float best = 0.f;
+    int bc = 0;
+    unsigned long long todo = __ballot(want);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int si = __shfl(ii, src);
+        const float sobj = __shfl(obj, src);
+        const int sn = si / perImg, sr = si - sn * perImg;
+        const _Float16* st = head + ((size_t)sn * gh * gw + sr / 3) * hs + (sr % 3) * 85 + 5;
+        float p0 = sobj * sig((float)st[lane]);
+        if (!(p0 > 0.001f)) p0 = 0.f;                 // region layer `thresh`
+        float p1 = 0.f;
+        if (lane < 16) { p1 = sobj * sig((float)st[64 + lane]); if (!(p1 > 0.001f)) p1 = 0.f; }
+        if (rawOut) {
+            float* o = rawOut + (size_t)(rowBase + sr) * 85 + 5;
+            o[lane] = p0;
+            if (lane < 16) o[64 + lane] = p1;
+        }
+        float m = p0; int mc = lane;
+        if (p1 > m) { m = p1; mc = lane + 64; }        // strictly greater: the lower class index wins ties
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float om = __shfl_xor(m, d); const int oc = __shfl_xor(mc, d);
+            if (om > m || (om == m && oc < mc)) { m = om; mc = oc; }
+        }
+        if (lane == src) { best = m; bc = m > 0.f ? mc : 0; }
+    }
+    if (!want) return;
+    const float aw = a == 0 ? aw0 : a == 1 ? aw1 : aw2, ah = a == 0 ? ah0 : a == 1 ? ah1 : ah2;
     const float cx = (sig((float)t[0]) + (float)x) / (float)gw;
     const float cy = (sig((float)t[1]) + (float)y) / (float)gh;
     const float bw = expf((float)t[2]) * aw / (float)netW;
     const float bh = expf((float)t[3]) * ah / (float)netH;
-    const float obj = sig((float)t[4]);
-    float best = 0.f;
-    int bc = 0;
-    for (int c = 0; c < 80; c++) {
-        float p = obj * sig((float)t[5 + c]);
-        if (!(p > 0.001f)) p = 0.f;                 // region layer `thresh`
-        if (p > best) { best = p; bc = c; }         // minMaxLoc: first maximum
-        if (rawOut) rawOut[(size_t)(rowBase + r) * 85 + 5 + c] = p;          // only requested for single-image runs
-    }
     if (rawOut) {
         float* o = rawOut + (size_t)(rowBase + r) * 85;
         o[0] = cx; o[1] = cy; o[2] = bw; o[3] = bh; o[4] = obj;
@@ -591,7 +725,6 @@ __global__ void __launch_bounds__(256) k_region_decode(const _Float16* __restric
         }
     }
 }
-
 
 // yolov3Segment::Segmentation (yolo.cc:34-58) after NMS: rasterise the central half-width of every kept box
 // (postprocess, yolo.cc:128-131), dilate with cv::getStructuringElement(MORPH_ELLIPSE, 31x31) and return

@@ -1327,7 +1327,7 @@ int sd_yolo_create(sd_yolo** out, const sd_yolo_layer* layers, int n_layers, con
             const int pad = l.size / 2;
             r.H = (H + 2 * pad - l.size) / l.stride + 1; r.W = (W + 2 * pad - l.size) / l.stride + 1; r.C = l.filters;
             r.outC = (l.filters + 31) / 32 * 32;            // stored channel count (255 -> 256)
-            r.coutPad = (l.filters + SD_CV_BM - 1) / SD_CV_BM * SD_CV_BM;
+            r.coutPad = (l.filters + SD_G3_BM - 1) / SD_G3_BM * SD_G3_BM;        // weight/bias rows are padded to the widest filter tile
             r.wOff = wOff; r.bOff = bOff;
             wOff += (size_t)r.coutPad * l.size * l.size * r.cinPad;
             bOff += r.coutPad;
@@ -1527,8 +1527,20 @@ int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int heig
                 A.res = y->R[f].out; A.resStride = y->R[f].outC;
             }
             const int npix = n * r.H * r.W;
-            dim3 grd((npix + SD_CV_BN - 1) / SD_CV_BN, r.coutPad / SD_CV_BM);
-            if (l.size == 3 && l.stride == 1 && W <= SD_C3_MAXW && l.filters % SD_G3_BM == 0 && r.cinPad % 32 == 0 && npix >= SD_G3_BN) {
+            dim3 grd((npix + SD_CV_BN - 1) / SD_CV_BN, (l.filters + SD_CV_BM - 1) / SD_CV_BM);
+            if (l.size == 1 && l.stride == 1 && r.cinPad % 32 == 0 && r.coutPad % SD_G3_BM == 0 && npix >= 512) {
+                static bool attr = false;
+                if (!attr) {
+                    HIPCHK(hipFuncSetAttribute((const void*)k_conv1x1_glds<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (512 * 64 + SD_G3_WBYTES)));
+                    HIPCHK(hipFuncSetAttribute((const void*)k_conv1x1_glds<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 * 64 + SD_G3_WBYTES)));
+                    attr = true;
+                }
+                const int ct = r.coutPad / SD_G3_BM;
+                if (((npix + 511) / 512) * ct >= 256)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv1x1_glds<8>), dim3((npix + 511) / 512, ct), dim3(512), 3 * (512 * 64 + SD_G3_WBYTES), s, A);
+                else
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv1x1_glds<4>), dim3((npix + 255) / 256, ct), dim3(256), 3 * (256 * 64 + SD_G3_WBYTES), s, A);
+            } else if (l.size == 3 && l.stride == 1 && W <= SD_C3_MAXW && l.filters % SD_G3_BM == 0 && r.cinPad % 32 == 0 && npix >= SD_G3_BN) {
                 static bool attr = false;
                 if (!attr) { HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_glds, hipFuncAttributeMaxDynamicSharedMemorySize, SD_G3_LDS)); attr = true; }
                 hipLaunchKernelGGL(k_conv3x3_glds, dim3((npix + SD_G3_BN - 1) / SD_G3_BN, l.filters / SD_G3_BM), dim3(512), SD_G3_LDS, s, A);
