@@ -22,6 +22,7 @@ struct SdConvArgs {
     const float* bias;       // [coutPad]
     const _Float16* res;     // shortcut source, same geometry as out (or null)
     _Float16* out;           // [N][Ho][Wo][outStride] written at channel offset outOff
+    const _Float16* zero;    // >= 64 zero bytes (source of padded taps in the LDS-DMA gather)
     int N, H, W, cin, cinStride;
     int Ho, Wo, cout, coutPad, outStride, outOff, resStride;
     int ksize, stride, pad, leaky;
@@ -471,40 +472,62 @@ __device__ __forceinline__ void sd_conv_epilogue(const SdConvArgs& A, sd_f16v (&
     }
 }
 
-// 1x1 convolution (a plain GEMM over pixels) with LDS-DMA staging: NWAVES waves, tile 128 filters x 64*NWAVES pixels,
+// Implicit-GEMM convolution with LDS-DMA staging for everything the flattened 3x3 kernel does not take: 1x1 layers
+// (KS = 1, a plain GEMM over pixels), and 3x3 layers with stride 2 or on maps wider than SD_C3_MAXW (KS = 3, each
+// stage gathers one filter tap's rows; padded taps read a zero page).  NWAVES waves, tile 128 filters x 64*NWAVES pixels,
 // three-stage ring of {X: pixels x 32 channels, W: 128 x 32}; stage s+2 is requested right after the barrier of step s
 // (every wave has then finished reading the slot it overwrites), and the counted vmcnt before the next barrier leaves
-// exactly that one stage in flight.  These layers move cin + cout halfs per pixel for 2*cin*cout flops: they are bound by
-// the activation stream, which this kernel reads once per 128-filter tile in full 64-byte pieces.
-template <int NWAVES>
-__global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 1 : 2) k_conv1x1_glds(SdConvArgs A)
+// exactly that one stage in flight.  The 1x1 layers move cin + cout halfs per pixel for 2*cin*cout flops: they are bound
+// by the activation stream, which is read once per 128-filter tile in full 64-byte pieces.
+template <int NWAVES, int KS>
+__global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 1 : 2) k_conv_glds(SdConvArgs A)
 {
     constexpr int BN = 64 * NWAVES;
     constexpr int XB = BN * 64, STAGE = XB + SD_G3_WBYTES;
     constexpr int WP = 8 / NWAVES;                    // weight pieces per wave per stage
+    constexpr int TAPS = KS * KS;
     extern __shared__ __align__(1024) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r32 = lane & 31, h = lane >> 5;
     const int npix = A.N * A.Ho * A.Wo;
     const int p0 = blockIdx.x * BN, co0 = blockIdx.y * SD_G3_BM;
     const int qsrc = (lane & 3) ^ ((lane >> 4) & 3);
-    const _Float16* xsrc[4];
+    const _Float16* xsrc[4];                          // KS == 1: the pixel's row; KS == 3: the image base
+    int xy[4], xx[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         int gp = p0 + 16 * (wv + NWAVES * i) + (lane >> 2);
         gp = gp >= npix ? npix - 1 : gp;
-        xsrc[i] = A.in + (size_t)gp * A.cinStride + 8 * qsrc;
+        if (KS == 1) { xsrc[i] = A.in + (size_t)gp * A.cinStride + 8 * qsrc; xy[i] = xx[i] = 0; }
+        else {
+            const int n = gp / (A.Ho * A.Wo), r = gp - n * (A.Ho * A.Wo);
+            const int yo = r / A.Wo, xo = r - yo * A.Wo;
+            xy[i] = yo * A.stride - A.pad; xx[i] = xo * A.stride - A.pad;
+            xsrc[i] = A.in + (size_t)n * A.H * A.W * A.cinStride + 8 * qsrc;
+        }
     }
     const _Float16* wsrc[WP];
 #pragma unroll
-    for (int i = 0; i < WP; i++) wsrc[i] = A.wgt + (size_t)(co0 + 16 * (wv + NWAVES * i) + (lane >> 2)) * A.cin + 8 * qsrc;
-    const int nsteps = A.cin / 32;
-    auto issue = [&](int st, int slot) {
-        const int c0 = (st < nsteps ? st : nsteps - 1) * 32;                  // surplus requests re-fetch the last stage
+    for (int i = 0; i < WP; i++) wsrc[i] = A.wgt + (size_t)(co0 + 16 * (wv + NWAVES * i) + (lane >> 2)) * TAPS * A.cin + 8 * qsrc;
+    const int nsteps = TAPS * (A.cin / 32);
+    int it = 0, ic0 = 0, ikh = 0, ikw = 0;            // (tap, channel offset) of the next stage to request
+    auto issue = [&](int slot) {
         unsigned char* sb = smem + slot * STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; i++) SD_GLDS16(xsrc[i] + c0, sb + 1024 * (wv + NWAVES * i));
+        for (int i = 0; i < 4; i++) {
+            const _Float16* src;
+            if (KS == 1) src = xsrc[i] + ic0;
+            else {
+                const int yi = xy[i] + ikh, xi = xx[i] + ikw;
+                src = (yi >= 0 && yi < A.H && xi >= 0 && xi < A.W) ? xsrc[i] + ((size_t)yi * A.W + xi) * A.cinStride + ic0 : A.zero + 8 * (lane & 3);
+            }
+            SD_GLDS16(src, sb + 1024 * (wv + NWAVES * i));
+        }
 #pragma unroll
-        for (int i = 0; i < WP; i++) SD_GLDS16(wsrc[i] + c0, sb + XB + 1024 * (wv + NWAVES * i));
+        for (int i = 0; i < WP; i++) SD_GLDS16(wsrc[i] + (size_t)it * A.cin + ic0, sb + XB + 1024 * (wv + NWAVES * i));
+        if (!(it == TAPS - 1 && ic0 + 32 == A.cin)) {  // saturate: surplus requests re-fetch the last stage
+            ic0 += 32;
+            if (ic0 == A.cin) { ic0 = 0; it++; ikw++; if (ikw == KS) { ikw = 0; ikh++; } }
+        }
     };
     const int aoff = r32 * 64 + ((h ^ ((r32 >> 2) & 3)) << 4);
     int boff[2];
@@ -517,12 +540,12 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 1 : 2) k_conv1x1_gl
         for (int n = 0; n < 2; n++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
-    issue(0, 0); issue(1, 1);
+    issue(0); issue(1);
     int slot = 0;
     for (int s = 0; s < nsteps; s++) {
         if (NWAVES == 8) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        issue(s + 2, slot == 0 ? 2 : slot - 1);                                // (s + 2) % 3
+        issue(slot == 0 ? 2 : slot - 1);                                       // stage s + 2 -> slot (s + 2) % 3
         const unsigned char* xb = smem + slot * STAGE;
         const unsigned char* wb = xb + XB;
         slot = slot == 2 ? 0 : slot + 1;

@@ -1368,6 +1368,8 @@ int sd_yolo_create(sd_yolo** out, const sd_yolo_layer* layers, int n_layers, con
     bool ok = true;
     const size_t nB = (size_t)max_batch;
     ok = ok && alloc((void**)&y->d_blob4, nB * net_h * net_w * 4 * 2);
+    ok = ok && alloc((void**)&y->d_zero, 256);
+    if (ok) ok = hipMemset(y->d_zero, 0, 256) == hipSuccess;
 
     ok = ok && alloc((void**)&y->d_wgt, wOff * 2 + 64);
     ok = ok && alloc((void**)&y->d_bias, bOff * 4 + 64);
@@ -1518,7 +1520,7 @@ int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int heig
             LAUNCH_CHECK("k_conv_first");
         } else if (l.type == SD_YOLO_CONV) {
             SdConvArgs A;
-            A.in = cur; A.wgt = y->d_wgt + r.wOff; A.bias = y->d_bias + r.bOff; A.res = nullptr; A.out = r.out;
+            A.zero = y->d_zero; A.in = cur; A.wgt = y->d_wgt + r.wOff; A.bias = y->d_bias + r.bOff; A.res = nullptr; A.out = r.out;
             A.N = n; A.H = H; A.W = W; A.cin = r.cinPad; A.cinStride = Cs;
             A.Ho = r.H; A.Wo = r.W; A.cout = l.filters; A.coutPad = r.coutPad; A.outStride = r.outC; A.outOff = 0; A.resStride = 0;
             A.ksize = l.size; A.stride = l.stride; A.pad = l.size / 2; A.leaky = l.leaky;
@@ -1528,19 +1530,25 @@ int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int heig
             }
             const int npix = n * r.H * r.W;
             dim3 grd((npix + SD_CV_BN - 1) / SD_CV_BN, (l.filters + SD_CV_BM - 1) / SD_CV_BM);
-            if (l.size == 1 && l.stride == 1 && r.cinPad % 32 == 0 && r.coutPad % SD_G3_BM == 0 && npix >= 512) {
+            const bool flat3 = l.size == 3 && l.stride == 1 && W <= SD_C3_MAXW && l.filters % SD_G3_BM == 0 && r.cinPad % 32 == 0 && npix >= SD_G3_BN;
+            if (!flat3 && r.cinPad % 32 == 0 && npix >= 512) {
                 static bool attr = false;
+                const int lds8 = 3 * (512 * 64 + SD_G3_WBYTES), lds4 = 3 * (256 * 64 + SD_G3_WBYTES);
                 if (!attr) {
-                    HIPCHK(hipFuncSetAttribute((const void*)k_conv1x1_glds<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (512 * 64 + SD_G3_WBYTES)));
-                    HIPCHK(hipFuncSetAttribute((const void*)k_conv1x1_glds<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 * 64 + SD_G3_WBYTES)));
+                    HIPCHK(hipFuncSetAttribute((const void*)k_conv_glds<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds8));
+                    HIPCHK(hipFuncSetAttribute((const void*)k_conv_glds<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4));
+                    HIPCHK(hipFuncSetAttribute((const void*)k_conv_glds<8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds8));
+                    HIPCHK(hipFuncSetAttribute((const void*)k_conv_glds<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4));
                     attr = true;
                 }
                 const int ct = r.coutPad / SD_G3_BM;
-                if (((npix + 511) / 512) * ct >= 256)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv1x1_glds<8>), dim3((npix + 511) / 512, ct), dim3(512), 3 * (512 * 64 + SD_G3_WBYTES), s, A);
-                else
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv1x1_glds<4>), dim3((npix + 255) / 256, ct), dim3(256), 3 * (256 * 64 + SD_G3_WBYTES), s, A);
-            } else if (l.size == 3 && l.stride == 1 && W <= SD_C3_MAXW && l.filters % SD_G3_BM == 0 && r.cinPad % 32 == 0 && npix >= SD_G3_BN) {
+                const bool big = ((npix + 511) / 512) * ct >= 256;
+                const dim3 g8((npix + 511) / 512, ct), g4((npix + 255) / 256, ct);
+                if (l.size == 1 && big) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_glds<8, 1>), g8, dim3(512), lds8, s, A);
+                else if (l.size == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_glds<4, 1>), g4, dim3(256), lds4, s, A);
+                else if (big) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_glds<8, 3>), g8, dim3(512), lds8, s, A);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_glds<4, 3>), g4, dim3(256), lds4, s, A);
+            } else if (flat3) {
                 static bool attr = false;
                 if (!attr) { HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_glds, hipFuncAttributeMaxDynamicSharedMemorySize, SD_G3_LDS)); attr = true; }
                 hipLaunchKernelGGL(k_conv3x3_glds, dim3((npix + SD_G3_BN - 1) / SD_G3_BN, l.filters / SD_G3_BM), dim3(512), SD_G3_LDS, s, A);

@@ -16,7 +16,7 @@ struct sd_yolo {
     int netW = 0, netH = 0, classes = 80, maxBatch = 0, nconv = 0;
     float anchors[18];
     _Float16* d_blob4 = nullptr;   // network input, NHWC f16 x 4 channels
-    _Float16* d_wgt = nullptr; float* d_bias = nullptr;
+    _Float16* d_wgt = nullptr; float* d_bias = nullptr; _Float16* d_zero = nullptr;
     short4* d_ct = nullptr; short4* d_rt = nullptr;
     SdDet* d_dets = nullptr; int* d_ndet = nullptr; float* d_raw = nullptr;
     int detCap = 0, totalRows = 0;
