@@ -300,31 +300,38 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_flat(SdConvArgs A)
 //     the same XOR, which keeps every ds_read_b128 lane group on 16 distinct bank quads.
 #define SD_G3_BM 128
 #define SD_G3_BN 512
-#define SD_G3_ZROW 688                      // (512 + 2*80 + 2 = 674 rows) rounded up to 16; row 688 is all zero
-#define SD_G3_XBYTES 44288                  // 692 rows x 64 B (a multiple of 256 B so both buffers bank alike)
 #define SD_G3_NW 5
 #define SD_G3_WBYTES (SD_G3_BM * 64)
-#define SD_G3_LDS (2 * SD_G3_XBYTES + SD_G3_NW * SD_G3_WBYTES)
-#define SD_G3_XPIECES 6                     // LDS-DMA instructions per wave per X chunk (43 groups of 16 rows over 8 waves)
+// per maximum map width MAXW (80 for the 80/40/20-wide maps, 160 for the 160-wide ones):
+//   ZROW    (512 + 2*MAXW + 2 rows) rounded up to 16; row ZROW is all zero
+//   XBYTES  one activation buffer, (ZROW + 1) rows x 64 B rounded to 256 B so both buffers bank alike
+//   XPIECES LDS-DMA instructions per wave per activation chunk (ZROW/16 groups of 16 rows over 8 waves)
+#define SD_G3_ZROW(MAXW) ((SD_G3_BN + 2 * (MAXW) + 2 + 15) / 16 * 16)
+#define SD_G3_XBYTES(MAXW) (((SD_G3_ZROW(MAXW) + 1) * 64 + 255) / 256 * 256)
+#define SD_G3_XPIECES(MAXW) ((SD_G3_ZROW(MAXW) / 16 + 7) / 8)
+#define SD_G3_LDS(MAXW) (2 * SD_G3_XBYTES(MAXW) + SD_G3_NW * SD_G3_WBYTES)
 typedef __attribute__((address_space(3))) void sd_lds_void;
 typedef const __attribute__((address_space(1))) void sd_glb_void;
 #define SD_GLDS16(gsrc, ldst) __builtin_amdgcn_global_load_lds((sd_glb_void*)(gsrc), (sd_lds_void*)(ldst), 16, 0, 0)
+template <int N> __device__ __forceinline__ void sd_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+template <int MAXW>
 __global__ void __launch_bounds__(512, 1) k_conv3x3_glds(SdConvArgs A)
 {
+    constexpr int ZROW = SD_G3_ZROW(MAXW), XBYTES = SD_G3_XBYTES(MAXW), XPIECES = SD_G3_XPIECES(MAXW);
     extern __shared__ __align__(1024) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r32 = lane & 31, h = lane >> 5;
     const int W = A.W, H = A.H;
     const int npix = A.N * H * W;
     const int p0 = blockIdx.x * SD_G3_BN, co0 = blockIdx.y * SD_G3_BM;
     const int xrows = SD_G3_BN + 2 * W + 2, ngroups = (xrows + 15) >> 4;
-    if (tid < 8) *(uint4*)(smem + (tid >> 2) * SD_G3_XBYTES + SD_G3_ZROW * 64 + 16 * (tid & 3)) = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 8) *(uint4*)(smem + (tid >> 2) * XBYTES + ZROW * 64 + 16 * (tid & 3)) = make_uint4(0u, 0u, 0u, 0u);
     // ---- LDS-DMA sources of this lane: slot (row = lane>>2, q' = lane&3) of a 16-row group holds channel group q' ^ sw
     const int qsrc = (lane & 3) ^ ((lane >> 4) & 3);
-    const _Float16* xsrc[SD_G3_XPIECES];
-    int xdst[SD_G3_XPIECES];
+    const _Float16* xsrc[XPIECES];
+    int xdst[XPIECES];
 #pragma unroll
-    for (int i = 0; i < SD_G3_XPIECES; i++) {
+    for (int i = 0; i < XPIECES; i++) {
         int g = wv + 8 * i;
         if (g >= ngroups) g -= 8;                       // surplus piece: rewrite this wave's previous group with the same bytes
         const int r = 16 * g + (lane >> 2);
@@ -334,12 +341,12 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_glds(SdConvArgs A)
         xdst[i] = 1024 * g;
     }
     const _Float16* wsrc = A.wgt + (size_t)(co0 + 16 * wv + (lane >> 2)) * 9 * A.cin + 8 * qsrc;
-    unsigned char* const wring = smem + 2 * SD_G3_XBYTES;
+    unsigned char* const wring = smem + 2 * XBYTES;
     const int nchunks = A.cin / 32;
     auto issueX = [&](int ch) {
-        unsigned char* xb = smem + (ch & 1) * SD_G3_XBYTES;
+        unsigned char* xb = smem + (ch & 1) * XBYTES;
 #pragma unroll
-        for (int i = 0; i < SD_G3_XPIECES; i++) SD_GLDS16(xsrc[i] + ch * 32, xb + xdst[i]);
+        for (int i = 0; i < XPIECES; i++) SD_GLDS16(xsrc[i] + ch * 32, xb + xdst[i]);
     };
     int wtap = 0, wch = 0, wslot = 0;                   // the next weight stage to request
     auto issueW = [&]() {
@@ -369,14 +376,14 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_glds(SdConvArgs A)
     issueX(0); issueW(); issueW(); issueW();
     int rslot = 0;
     for (int ch = 0; ch < nchunks; ch++) {
-        const unsigned char* xb = smem + (ch & 1) * SD_G3_XBYTES;
+        const unsigned char* xb = smem + (ch & 1) * XBYTES;
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             issueW();                                    // stage s+3 -> the slot read at step s-2
             if (tap == 1) issueX(ch + 1 < nchunks ? ch + 1 : ch);
             // retire W(s) (and X(ch) at tap 0): everything requested after it may stay in flight
-            if (tap >= 1 && tap <= 4) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            if (tap >= 1 && tap <= 4) sd_wait_vmcnt<3 + XPIECES>();
+            else sd_wait_vmcnt<3>();
             __builtin_amdgcn_s_barrier();
             const unsigned char* wb = wring + rslot * SD_G3_WBYTES;
             rslot = rslot == SD_G3_NW - 1 ? 0 : rslot + 1;
@@ -385,7 +392,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_glds(SdConvArgs A)
 #pragma unroll
             for (int n = 0; n < 2; n++) {
                 const int yy = jy[n] + kh - 1, xx = jx[n] + kw - 1;
-                const int row = (jok[n] && yy >= 0 && yy < H && xx >= 0 && xx < W) ? jrow[n] + kh * W + kw : SD_G3_ZROW;
+                const int row = (jok[n] && yy >= 0 && yy < H && xx >= 0 && xx < W) ? jrow[n] + kh * W + kw : ZROW;
                 boff[n] = row * 64 + ((h ^ ((row >> 2) & 3)) << 4);
             }
 #pragma unroll

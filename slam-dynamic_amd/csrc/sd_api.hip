@@ -1530,8 +1530,8 @@ int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int heig
             }
             const int npix = n * r.H * r.W;
             dim3 grd((npix + SD_CV_BN - 1) / SD_CV_BN, (l.filters + SD_CV_BM - 1) / SD_CV_BM);
-            const bool flat3 = l.size == 3 && l.stride == 1 && W <= SD_C3_MAXW && l.filters % SD_G3_BM == 0 && r.cinPad % 32 == 0 && npix >= SD_G3_BN;
-            if (!flat3 && r.cinPad % 32 == 0 && npix >= 512) {
+            const bool flat3 = l.size == 3 && l.stride == 1 && W <= 160 && l.filters % SD_G3_BM == 0 && r.cinPad % 32 == 0 && npix >= SD_G3_BN;
+            if (!flat3 && r.cinPad % 32 == 0 && npix >= 512 && (l.size == 1 || l.filters >= SD_G3_BM)) {
                 static bool attr = false;
                 const int lds8 = 3 * (512 * 64 + SD_G3_WBYTES), lds4 = 3 * (256 * 64 + SD_G3_WBYTES);
                 if (!attr) {
@@ -1550,8 +1550,14 @@ int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int heig
                 else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_glds<4, 3>), g4, dim3(256), lds4, s, A);
             } else if (flat3) {
                 static bool attr = false;
-                if (!attr) { HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_glds, hipFuncAttributeMaxDynamicSharedMemorySize, SD_G3_LDS)); attr = true; }
-                hipLaunchKernelGGL(k_conv3x3_glds, dim3((npix + SD_G3_BN - 1) / SD_G3_BN, l.filters / SD_G3_BM), dim3(512), SD_G3_LDS, s, A);
+                if (!attr) {
+                    HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_glds<80>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_G3_LDS(80)));
+                    HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_glds<160>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_G3_LDS(160)));
+                    attr = true;
+                }
+                const dim3 g3((npix + SD_G3_BN - 1) / SD_G3_BN, l.filters / SD_G3_BM);
+                if (W <= 80) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv3x3_glds<80>), g3, dim3(512), SD_G3_LDS(80), s, A);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv3x3_glds<160>), g3, dim3(512), SD_G3_LDS(160), s, A);
             } else if (l.size == 3 && l.stride == 1 && W <= SD_C3_MAXW && l.filters % SD_C3_BM == 0 && r.cinPad % SD_C3_BK == 0)
                 hipLaunchKernelGGL(k_conv3x3_flat, dim3((npix + SD_C3_BN - 1) / SD_C3_BN, l.filters / SD_C3_BM), dim3(256), 0, s, A);
             else if (r.cinPad % 64 == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_mfma<64>), grd, dim3(256), 0, s, A);
