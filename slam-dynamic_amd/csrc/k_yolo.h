@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256) k_conv_mfma(SdConvArgs A)
                 for (int e = 0; e < 4; e++) {
                     float x = acc[m][n][4 * g + e] + A.bias[co + e];
                     if (A.leaky) x = x > 0.f ? x : 0.1f * x;
-                    v[e] = x;
+                    v[e] = (float)(_Float16)x;          // rounded before the shortcut add, as sd_conv_epilogue does: every kernel gives the same bits
                 }
                 if (A.res) {
                     const sd_h4 rr = *(const sd_h4*)(A.res + (size_t)p * A.resStride + co);
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_flat(SdConvArgs A)
                 for (int e = 0; e < 4; e++) {
                     float x = acc[m][n][4 * g + e] + A.bias[co + e];
                     if (A.leaky) x = x > 0.f ? x : 0.1f * x;
-                    v[e] = x;
+                    v[e] = (float)(_Float16)x;          // rounded before the shortcut add, as sd_conv_epilogue does: every kernel gives the same bits
                 }
                 if (A.res) {
                     const sd_h4 rr = *(const sd_h4*)(A.res + (size_t)p * A.resStride + co);
@@ -314,6 +314,70 @@ typedef __attribute__((address_space(3))) void sd_lds_void;
 typedef const __attribute__((address_space(1))) void sd_glb_void;
 #define SD_GLDS16(gsrc, ldst) __builtin_amdgcn_global_load_lds((sd_glb_void*)(gsrc), (sd_lds_void*)(ldst), 16, 0, 0)
 template <int N> __device__ __forceinline__ void sd_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Epilogue shared by the LDS-DMA kernels: wave tile 128 filters x 64 pixels held as acc[4][2] (D layout of
+// v_mfma_f32_32x32x16: column = pixel lane&31, rows = filters (reg&3) + 8*(reg>>2) + 4*(lane>>5)).  A lane owns 4
+// consecutive filters of ONE pixel, so direct stores would be 8-byte pieces 2*outStride bytes apart.  Instead each wave
+// transposes through its private LDS region (the staging buffers are dead by now): bias + leaky ReLU in f32, f16 rows
+// of 64 filters (+16 B pad), then every lane moves 16-byte pieces so one wave-instruction covers 8 pixels x 128
+// contiguous bytes for the shortcut read and the store alike.  Two passes of 64 filters keep the region at 9 KiB/wave.
+#define SD_EP_ROW 144
+#define SD_EP_WAVE (64 * SD_EP_ROW)
+__device__ __forceinline__ void sd_conv_epilogue(const SdConvArgs& A, sd_f16v (&acc)[4][2], unsigned char* smem, int wv, int pbase,
+                                                 int co0, int npix, int lane)
+{
+    const int r32 = lane & 31, h = lane >> 5;
+    unsigned char* reg = smem + wv * SD_EP_WAVE;
+    const int cend = (A.cout + 7) & ~7;                       // whole 16-byte pieces may be stored up to here
+    const bool wide = cend <= A.outStride - A.outOff;
+    __syncthreads();                                           // every wave is done with the staging buffers
+#pragma unroll
+    for (int mh = 0; mh < 2; mh++) {
+        if (co0 + 64 * mh >= A.cout) break;
+#pragma unroll
+        for (int mm = 0; mm < 2; mm++)
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int cl = 32 * mm + 8 * g + 4 * h, co = co0 + 64 * mh + cl;
+                    sd_h4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        float x = acc[2 * mh + mm][n][4 * g + e] + A.bias[co + e];      // bias rows are padded to the filter tile
+                        if (A.leaky) x = x > 0.f ? x : 0.1f * x;
+                        o[e] = (_Float16)x;
+                    }
+                    *(sd_h4*)(reg + (32 * n + r32) * SD_EP_ROW + cl * 2) = o;
+                }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const int c = lane + 64 * t, px = c >> 3, part = c & 7;
+            const int p = pbase + px, co = co0 + 64 * mh + 8 * part;
+            if (p >= npix || co >= A.cout) continue;
+            sd_h8 v = *(const sd_h8*)(reg + px * SD_EP_ROW + part * 16);
+            _Float16* dst = A.out + (size_t)p * A.outStride + A.outOff + co;
+            if (wide && co + 8 <= cend) {
+                if (A.res) {
+                    const sd_h8 rr = *(const sd_h8*)(A.res + (size_t)p * A.resStride + co);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] = (_Float16)((float)v[e] + (float)rr[e]);
+                }
+                *(sd_h8*)dst = v;
+            } else {
+                for (int e = 0; e < 8 && co + e < A.cout; e++) {
+                    float x = (float)v[e];
+                    if (A.res) x += (float)A.res[(size_t)p * A.resStride + co + e];
+                    dst[e] = (_Float16)x;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                       // pass 2 overwrites the region
+    }
+}
 
 template <int MAXW>
 __global__ void __launch_bounds__(512, 1) k_conv3x3_glds(SdConvArgs A)
@@ -411,72 +475,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_glds(SdConvArgs A)
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // surplus LDS-DMA must not outlive the workgroup's LDS
-#pragma unroll
-    for (int n = 0; n < 2; n++) {
-        const int p = p0 + 64 * wv + 32 * n + r32;
-        if (p >= npix) continue;
-#pragma unroll
-        for (int m = 0; m < 4; m++)
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int co = co0 + 32 * m + 8 * g + 4 * h;
-                if (co >= A.cout) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float x = acc[m][n][4 * g + e] + A.bias[co + e];
-                    if (A.leaky) x = x > 0.f ? x : 0.1f * x;
-                    v[e] = x;
-                }
-                if (A.res) {
-                    const sd_h4 rr = *(const sd_h4*)(A.res + (size_t)p * A.resStride + co);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] += (float)rr[e];
-                }
-                sd_h4 o;
-#pragma unroll
-                for (int e = 0; e < 4; e++) o[e] = (_Float16)v[e];
-                _Float16* dst = A.out + (size_t)p * A.outStride + A.outOff + co;
-                if (co + 3 < A.cout) *(sd_h4*)dst = o;
-                else for (int e = 0; e < 4 && co + e < A.cout; e++) dst[e] = o[e];
-            }
-    }
-}
-
-// Epilogue shared by the LDS-DMA kernels: wave tile 128 filters x 64 pixels held as acc[4][2] (D layout of
-// v_mfma_f32_32x32x16: column = pixel lane&31, rows = filters (reg&3) + 8*(reg>>2) + 4*(lane>>5)).
-__device__ __forceinline__ void sd_conv_epilogue(const SdConvArgs& A, sd_f16v (&acc)[4][2], int pbase, int co0, int npix, int r32, int h)
-{
-#pragma unroll
-    for (int n = 0; n < 2; n++) {
-        const int p = pbase + 32 * n + r32;
-        if (p >= npix) continue;
-#pragma unroll
-        for (int m = 0; m < 4; m++)
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int co = co0 + 32 * m + 8 * g + 4 * h;
-                if (co >= A.cout) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float x = acc[m][n][4 * g + e] + A.bias[co + e];
-                    if (A.leaky) x = x > 0.f ? x : 0.1f * x;
-                    v[e] = x;
-                }
-                if (A.res) {
-                    const sd_h4 rr = *(const sd_h4*)(A.res + (size_t)p * A.resStride + co);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] += (float)rr[e];
-                }
-                sd_h4 o;
-#pragma unroll
-                for (int e = 0; e < 4; e++) o[e] = (_Float16)v[e];
-                _Float16* dst = A.out + (size_t)p * A.outStride + A.outOff + co;
-                if (co + 3 < A.cout) *(sd_h4*)dst = o;
-                else for (int e = 0; e < 4 && co + e < A.cout; e++) dst[e] = o[e];
-            }
-    }
+    sd_conv_epilogue(A, acc, smem, wv, p0 + 64 * wv, co0, npix, lane);
 }
 
 // Implicit-GEMM convolution with LDS-DMA staging for everything the flattened 3x3 kernel does not take: 1x1 layers
@@ -571,7 +570,7 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 1 : 2) k_conv_glds(
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // surplus LDS-DMA must not outlive the workgroup's LDS
-    sd_conv_epilogue(A, acc, p0 + 64 * wv, co0, npix, r32, h);
+    sd_conv_epilogue(A, acc, smem, wv, p0 + 64 * wv, co0, npix, lane);
 }
 
 // blobFromImage(image, 1/255, Size(640,480), Scalar(0,0,0), swapRB = true, crop = false): bilinear resize of
