@@ -154,6 +154,30 @@ int sd_batch_download_mappoints(sd_batch* b, int image, float* xw, uint8_t* flag
 int sd_batch_search_by_projection(sd_batch* b, int n_pairs, const int32_t* cur_index, const int32_t* last_index,
                                   const float* Tcw_host, const float* Tlw_host, const sd_camera* cam, float th, int bMono,
                                   int checkOrientation, const uint8_t* d_occupied, const uint8_t* d_mp_desc, void* stream);
+/* Tracking::SearchLocalPoints (src/Tracking.cc:2014-2064) = Frame::isInFrustum(pMP, viewing_cos_limit)
+ * (src/Frame.cc:677-733) for every local map point, then ORBmatcher::SearchByProjection(Frame& F, const
+ * vector<MapPoint*>& vpMapPoints, th) with mfNNratio = nnratio (src/ORBmatcher.cc:45-129; the caller passes th = 1,
+ * 3 for RGB-D, 5 after a relocalisation, Tracking.cc:2055-2063).  Frame f < n_frames is batch slot frame_index[f]
+ * (sd_batch_assign_grid must have run on it) with local map points [point_offset[f], point_offset[f+1]) of the flat
+ * device arrays d_points / d_point_desc (pMP->GetDescriptor(), 32 B each), pose Tcw_host[f] (row-major 4x4 mTcw).
+ * d_occupied (nullable, [n_frames][cap] u8): F.mvpMapPoints[i] already holds a point with Observations() > 0.
+ * Outputs (device): d_track[m] = mbTrackInView / mTrackProjX / mTrackProjY / mTrackProjXR / mnTrackScaleLevel /
+ * mTrackViewCos; d_point_match[m] = keypoint index given to point m or -1; d_kp_match[f][i] (row stride =
+ * sd_batch cap) = index, relative to point_offset[f], of the point this call leaves in F.mvpMapPoints[i], or -1;
+ * d_nmatches[f] = the function's return value. */
+typedef struct sd_map_point {
+    float xw[3];          /* GetWorldPos() */
+    float normal[3];      /* GetNormal() */
+    float min_distance;   /* mfMinDistance (GetMinDistanceInvariance() / 0.8f) */
+    float max_distance;   /* mfMaxDistance (GetMaxDistanceInvariance() / 1.2f) */
+    uint32_t flags;       /* bit0: !isBad() && mnLastFrameSeen != F.mnId; bit1: Observations() > 0 */
+} sd_map_point;           /* 36 bytes */
+typedef struct sd_track_info { float proj_x, proj_y, proj_xr, view_cos; int32_t level; int32_t in_view; } sd_track_info;   /* 24 bytes */
+int sd_batch_search_local_map(sd_batch* b, int n_frames, const int32_t* frame_index, const int32_t* point_offset,
+                              const sd_map_point* d_points, const uint8_t* d_point_desc, const float* Tcw_host,
+                              const sd_camera* cam, float th, float nnratio, float viewing_cos_limit,
+                              const uint8_t* d_occupied, sd_track_info* d_track, int32_t* d_point_match,
+                              int32_t* d_kp_match, int32_t* d_nmatches, void* stream);
 /* Frame copy constructor (src/Frame.cc:39-63), as in `mLastFrame = Frame(mCurrentFrame)`: copies the frame
  * results of slot src (keypoints, descriptors, mvuRight/mvDepth, grid cells, map-point table) to slot dst. */
 int sd_batch_copy_frame(sd_batch* b, int src, int dst, void* stream);

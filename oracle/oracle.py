@@ -194,6 +194,30 @@ def search_by_projection(kpC, descC, uRightC, kpL, dMP, xw, flags, Tcw, Tlw, cam
     return match, pairs[:npairs.value].copy(), nm
 
 
+MAP_POINT_DTYPE = np.dtype([("xw", "<f4", 3), ("normal", "<f4", 3), ("min_distance", "<f4"), ("max_distance", "<f4"),
+                            ("flags", "<u4")])          # sd_map_point, 36 B
+TRACK_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("view_cos", "<f4"), ("level", "<i4"),
+                        ("in_view", "<i4")])            # sd_track_info, 24 B
+
+
+def search_local_map(kpF, descF, uRightF, mps, mp_desc, Tcw, cam10, scale_factors, th, nnratio, viewing_cos_limit=0.5,
+                     occupied=None):
+    """Frame::isInFrustum + ORBmatcher::SearchByProjection(Frame, MapPoints, th) -> (track, mp_match, kp_match, nmatches)."""
+    kpF = np.ascontiguousarray(kpF); descF = np.ascontiguousarray(descF, np.uint8)
+    uR = np.ascontiguousarray(uRightF, np.float32)
+    mps = np.ascontiguousarray(mps, MAP_POINT_DTYPE); md = np.ascontiguousarray(mp_desc, np.uint8)
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+    c = np.ascontiguousarray(cam10, np.float32); sf = np.ascontiguousarray(scale_factors, np.float32)
+    N, M = len(kpF), len(mps)
+    track = np.zeros(M, TRACK_DTYPE); mpm = np.zeros(M, np.int32); kpm = np.zeros(N, np.int32)
+    occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+    f = lib().orc_search_local_map
+    f.restype = C.c_int
+    nm = f(_p(kpF), _p(descF), _p(uR), N, _p(mps), _p(md), M, _p(T), _p(c), _p(sf), len(sf), C.c_float(th), C.c_float(nnratio),
+           C.c_float(viewing_cos_limit), _p(occ) if occ is not None else None, _p(track), _p(mpm), _p(kpm))
+    return track, mpm, kpm, nm
+
+
 MAXB = 32
 
 

@@ -671,3 +671,280 @@ __global__ void __launch_bounds__(64) k_proj_resolve(
     for (int i = lane; i < Nc; i += 64) matchOut[(size_t)pair * cap + i] = s_match[i];
     if (lane == 0) { npairsOut[pair] = np; nmatchOut[pair] = np - culled; }
 }
+
+// =====================================================================================
+// Local-map search (Tracking::SearchLocalPoints, Tracking.cc:2014-2064)
+//   k_local_candidates  Frame::isInFrustum (Frame.cc:677-733) + the search part of
+//                       ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th)   ORBmatcher.cc:45-98
+//   k_local_resolve     ... best / second best in assignment order, ratio test            ORBmatcher.cc:99-129
+// =====================================================================================
+struct SdMapPoint { float xw[3]; float normal[3]; float minDistance, maxDistance; unsigned flags; };     // sd_map_point
+struct SdTrack { float projX, projY, projXR, viewCos; int level; int inView; };                          // sd_track_info
+
+// std::log(float), taken correctly rounded (the oracle's logf_cr)
+__device__ __forceinline__ float sd_logf_cr(float x) { return (float)log((double)x); }
+
+// wave-wide ascending bitonic sort of one 64-bit key per lane
+__device__ __forceinline__ unsigned long long sd_wave_sort64(unsigned long long key, int lane)
+{
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)key, j, 64);
+            const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(key >> 32), j, 64);
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            const bool takeMin = (((lane & k) == 0) == ((lane & j) == 0));
+            key = takeMin ? (key < other ? key : other) : (key > other ? key : other);
+        }
+    return key;
+}
+// merge two ascending 64-key sequences held one per lane, keep the 64 smallest (ascending)
+__device__ __forceinline__ unsigned long long sd_wave_merge_low64(unsigned long long a, unsigned long long b, int lane)
+{
+    const unsigned lo = (unsigned)__shfl((int)(unsigned)b, 63 - lane, 64);
+    const unsigned hi = (unsigned)__shfl((int)(unsigned)(b >> 32), 63 - lane, 64);
+    const unsigned long long br = ((unsigned long long)hi << 32) | lo;
+    unsigned long long key = a < br ? a : br;                 // bitonic: the 64 smallest of both
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+        const unsigned l2 = (unsigned)__shfl_xor((int)(unsigned)key, j, 64);
+        const unsigned h2 = (unsigned)__shfl_xor((int)(unsigned)(key >> 32), j, 64);
+        const unsigned long long other = ((unsigned long long)h2 << 32) | l2;
+        key = ((lane & j) == 0) ? (key < other ? key : other) : (key > other ? key : other);
+    }
+    return key;
+}
+
+// One wave per local map point.  cand[m][k] = (dist << 16 | keypoint index) of the SD_PROJ_K nearest members of
+// GetFeaturesInArea (all distances: the second best may exceed TH_HIGH) ordered by (distance, visiting order);
+// ncand[m] = min(count, 64); overflow[m] = 1 when more than 64 keypoints were in the window.
+__global__ void __launch_bounds__(256) k_local_candidates(
+    const sd_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc, const float* __restrict__ uRight,
+    const int* __restrict__ count, const short* __restrict__ cellOf, const unsigned short* __restrict__ sortedIdx,
+    const unsigned short* __restrict__ cellStart, const SdMapPoint* __restrict__ mps, const uint8_t* __restrict__ mpDesc,
+    const int* __restrict__ frameOf /*[n_frames] image slot*/, const int* __restrict__ ptOff /*[n_frames+1]*/,
+    const float* __restrict__ Tcw, SdTrack* __restrict__ track, unsigned* __restrict__ cand, uint8_t* __restrict__ ncand,
+    uint8_t* __restrict__ overflow, const SdDevPlan* __restrict__ PP, SdCamera cam, float th, float viewingCosLimit)
+{
+    const SdDevPlan& P = *PP;
+    __shared__ unsigned long long s_keys[4][SD_PROJ_K];
+    const int f = blockIdx.y;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m0 = ptOff[f], M = ptOff[f + 1] - m0;
+    const int ml = blockIdx.x * 4 + wv;
+    if (ml >= M) return;
+    const int m = m0 + ml;
+    const int img = frameOf[f];
+    const int cap = P.kpCap;
+    const float* T = Tcw + (size_t)f * 16;
+    const SdMapPoint mp = mps[m];
+    // ---- Frame::isInFrustum
+    SdTrack t; t.projX = t.projY = t.projXR = t.viewCos = 0.f; t.level = 0; t.inView = 0;
+    bool ok = (mp.flags & 1u) != 0;
+    float invz = 0.f;
+    if (ok) {
+        float xc, yc, zc;
+        sd_mat3_mul_add(T, mp.xw[0], mp.xw[1], mp.xw[2], xc, yc, zc);
+        if (zc < 0.0f) ok = false;
+        invz = 1.0f / zc;
+        const float u = cam.fx * xc * invz + cam.cx;
+        const float v = cam.fy * yc * invz + cam.cy;
+        if (u < cam.mnMinX || u > cam.mnMaxX) ok = false;
+        if (v < cam.mnMinY || v > cam.mnMaxY) ok = false;
+        // mOw = -mRcw.t()*mtcw (Frame.cc:667-674)
+        float ox, oy, oz, s;
+        s = (-T[0]) * T[3] + (-T[4]) * T[7]; ox = s + (-T[8]) * T[11];
+        s = (-T[1]) * T[3] + (-T[5]) * T[7]; oy = s + (-T[9]) * T[11];
+        s = (-T[2]) * T[3] + (-T[6]) * T[7]; oz = s + (-T[10]) * T[11];
+        const float px = mp.xw[0] - ox, py = mp.xw[1] - oy, pz = mp.xw[2] - oz;
+        double s2 = (double)px * (double)px; s2 += (double)py * (double)py; s2 += (double)pz * (double)pz;
+        const float dist = (float)sqrt(s2);
+        if (dist < 0.8f * mp.minDistance || dist > 1.2f * mp.maxDistance) ok = false;
+        double dot = (double)px * (double)mp.normal[0]; dot += (double)py * (double)mp.normal[1]; dot += (double)pz * (double)mp.normal[2];
+        const float viewCos = (float)(dot / (double)dist);
+        if (viewCos < viewingCosLimit) ok = false;
+        if (ok) {
+            const float ratio = mp.maxDistance / dist;
+            const float logScaleFactor = sd_logf_cr(P.lv[1].scale);
+            int nScale = (int)ceilf(sd_logf_cr(ratio) / logScaleFactor);
+            if (nScale < 0) nScale = 0; else if (nScale >= P.nlevels) nScale = P.nlevels - 1;
+            t.inView = 1; t.projX = u; t.projXR = u - cam.mbf * invz; t.projY = v; t.level = nScale; t.viewCos = viewCos;
+        }
+    }
+    if (lane == 0) track[m] = t;
+    // ---- candidates
+    unsigned long long best = ~0ull;           // lane k holds the k-th smallest key so far
+    int total_hits = 0;
+    if (ok) {
+        float r = (double)t.viewCos > 0.998 ? 2.5f : 4.0f;
+        if (th != 1.0f) r *= th;
+        const float radius = r * P.lv[t.level].scale;
+        const int minLevel = t.level - 1, maxLevel = t.level;
+        const float u = t.projX, v = t.projY;
+        const float wInv = (float)SD_GRID_COLS / (cam.mnMaxX - cam.mnMinX);
+        const float hInv = (float)SD_GRID_ROWS / (cam.mnMaxY - cam.mnMinY);
+        const int nMinCellX = max(0, (int)floorf((u - cam.mnMinX - radius) * wInv));
+        const int nMaxCellX = min(SD_GRID_COLS - 1, (int)ceilf((u - cam.mnMinX + radius) * wInv));
+        const int nMinCellY = max(0, (int)floorf((v - cam.mnMinY - radius) * hInv));
+        const int nMaxCellY = min(SD_GRID_ROWS - 1, (int)ceilf((v - cam.mnMinY + radius) * hInv));
+        if (!(nMinCellX >= SD_GRID_COLS || nMaxCellX < 0 || nMinCellY >= SD_GRID_ROWS || nMaxCellY < 0)) {
+            const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+            const uint4* dl = (const uint4*)(mpDesc + (size_t)m * 32);
+            const uint4 l0 = dl[0], l1 = dl[1];
+            const sd_keypoint* kC = kp + (size_t)img * cap;
+            const short* cellC = cellOf + (size_t)img * cap;
+            const float* urC = uRight + (size_t)img * cap;
+            const uint8_t* dC = desc + (size_t)img * cap * 32;
+            const unsigned short* sorted = sortedIdx + (size_t)img * cap;
+            const unsigned short* cs = cellStart + (size_t)img * (SD_GRID_CELLS + 8);
+            const int nColsA = nMaxCellX - nMinCellX + 1;
+            int runS = 0, runN = 0;
+            if (lane < nColsA) {
+                const int ix = nMinCellX + lane;
+                runS = cs[ix * SD_GRID_ROWS + nMinCellY];
+                runN = cs[ix * SD_GRID_ROWS + nMaxCellY + 1] - runS;
+            }
+            int incl = runN;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int tt = __shfl_up(incl, o, 64); if (lane >= o) incl += tt; }
+            const int total = __shfl(incl, 63, 64);
+            const int excl = incl - runN;
+            int nbuf = 0;                          // keys waiting in s_keys[wv]
+            for (int base = 0; base < total; base += 64) {
+                const int tt = base + lane;
+                bool hit = false;
+                unsigned long long key = 0;
+                int col = 0;
+                for (int j = 1; j < nColsA; j++) { const int ej = __shfl(excl, j, 64); if (ej <= tt) col = j; }
+                const int cS = __shfl(runS, col, 64), cE = __shfl(excl, col, 64);
+                if (tt < total) {
+                    const int i2 = sorted[cS + (tt - cE)];
+                    const sd_keypoint k = kC[i2];
+                    bool lv = true;
+                    if (bCheckLevels) {
+                        if (k.octave < minLevel) lv = false;
+                        if (maxLevel >= 0 && k.octave > maxLevel) lv = false;
+                    }
+                    const float distx = k.x - u, disty = k.y - v;
+                    if (lv && fabsf(distx) < radius && fabsf(disty) < radius) {
+                        bool rOk = true;
+                        const float r2 = urC[i2];
+                        if (r2 > 0) { const float er = fabsf(t.projXR - r2); if (er > radius) rOk = false; }
+                        if (rOk) {
+                            const uint4* dr = (const uint4*)(dC + (size_t)i2 * 32);
+                            const int dist = sd_hamming256(l0, l1, dr[0], dr[1]);
+                            hit = true;
+                            key = ((unsigned long long)dist << 32) | ((unsigned long long)cellC[i2] << 16) | (unsigned)i2;
+                        }
+                    }
+                }
+                const unsigned long long hm = __ballot(hit);
+                const int h = __popcll(hm);
+                if (nbuf + h > SD_PROJ_K) {        // flush the waiting keys into the running best-64
+                    unsigned long long kb = lane < nbuf ? s_keys[wv][lane] : ~0ull;
+                    kb = sd_wave_sort64(kb, lane);
+                    best = sd_wave_merge_low64(best, kb, lane);
+                    nbuf = 0;
+                }
+                if (hit) s_keys[wv][nbuf + __popcll(hm & ((1ull << lane) - 1ull))] = key;
+                nbuf += h;
+                total_hits += h;
+            }
+            unsigned long long kb = lane < nbuf ? s_keys[wv][lane] : ~0ull;
+            kb = sd_wave_sort64(kb, lane);
+            best = sd_wave_merge_low64(best, kb, lane);
+        }
+    }
+    const int n = total_hits < SD_PROJ_K ? total_hits : SD_PROJ_K;
+    if (lane < n) cand[(size_t)m * SD_PROJ_K + lane] = (unsigned)((best >> 32) << 16) | (unsigned)(best & 0xFFFFu);
+    if (lane == 0) { ncand[m] = (uint8_t)n; overflow[m] = total_hits > SD_PROJ_K; }
+}
+
+// One wave per frame walks its local map points in order (ORBmatcher.cc:51) in chunks of 64: lane = map point.  With the
+// candidate list sorted by (distance, visiting order), the reference's running best / second best over the keypoints
+// that are not taken are the first two free entries of the list.  A chunk is committed in parallel unless an earlier
+// point of the chunk (one with observations, whose keypoint becomes taken) picks a keypoint that a later point uses as its
+// best or second best; then the chunk is replayed serially.
+__global__ void __launch_bounds__(64) k_local_resolve(
+    const sd_keypoint* __restrict__ kp, const int* __restrict__ count, const SdMapPoint* __restrict__ mps,
+    const int* __restrict__ frameOf, const int* __restrict__ ptOff, const unsigned* __restrict__ cand,
+    const uint8_t* __restrict__ ncand, const uint8_t* __restrict__ overflow, const uint8_t* __restrict__ occupied,
+    int* __restrict__ mpMatch, int* __restrict__ kpMatch, int* __restrict__ nmatchOut, int* __restrict__ errFlag,
+    const SdDevPlan* __restrict__ PP, float nnratio)
+{
+    const SdDevPlan& P = *PP;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int cap = P.kpCap;
+    int* s_match = (int*)smem;                              // [cap]
+    uint8_t* s_taken = (uint8_t*)(s_match + cap);           // [cap]
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const int img = frameOf[f];
+    const int N = count[img];
+    const int m0 = ptOff[f], M = ptOff[f + 1] - m0;
+    const sd_keypoint* kF = kp + (size_t)img * cap;
+    for (int i = lane; i < N; i += 64) { s_match[i] = -1; s_taken[i] = occupied ? occupied[(size_t)f * cap + i] : 0; }
+    __syncthreads();
+    int nm = 0;
+    // decision of one map point against the current taken[] state; returns the chosen keypoint or -1, c1 = the second free entry
+    auto decide = [&](int m, int n, bool ovf, int& c1out) -> int {
+        int c0 = -1, c1 = -1, d0 = 256, d1 = 256, j = 0;
+        for (; j < n; j++) {
+            const unsigned e = cand[(size_t)m * SD_PROJ_K + j];
+            const int c = (int)(e & 0xFFFFu);
+            if (s_taken[c]) continue;
+            if (c0 < 0) { c0 = c; d0 = (int)(e >> 16); }
+            else { c1 = c; d1 = (int)(e >> 16); break; }
+        }
+        if (ovf && c1 < 0) atomicOr(errFlag, 64);           // the truncated list ran out: the 65th+ nearest would matter
+        c1out = c1;
+        if (c0 < 0 || d0 > SD_TH_HIGH) return -1;
+        const int lv0 = kF[c0].octave, lv1 = c1 >= 0 ? kF[c1].octave : -1;
+        if (lv0 == lv1 && (float)d0 > nnratio * (float)d1) return -1;
+        return c0;
+    };
+    for (int base = 0; base < M; base += 64) {
+        const int ml = base + lane;
+        const bool act = ml < M;
+        const int m = m0 + (act ? ml : 0);
+        const int n = act ? ncand[m] : 0;
+        const bool ovf = act && overflow[m];
+        const bool obs = act && (mps[m].flags & 2u) != 0;
+        int c1 = -1;
+        int pick = n > 0 ? decide(m, n, ovf, c1) : -1;
+        // the first free entry when the ratio test rejected it still matters to nobody; what matters is whether an
+        // earlier taker removes this lane's first or second free entry
+        int c0any = -1;
+        if (n > 0) { for (int j = 0; j < n; j++) { const int c = (int)(cand[(size_t)m * SD_PROJ_K + j] & 0xFFFFu); if (!s_taken[c]) { c0any = c; break; } } }
+        bool conflict = false;
+        const unsigned long long takers = __ballot(obs && pick >= 0);
+        if (takers) {
+            for (int s = 1; s < 64; s++) {
+                const int src = lane - s;
+                const int op = __shfl(pick, src & 63, 64);
+                const int oo = __shfl((int)obs, src & 63, 64);
+                if (src >= 0 && oo && op >= 0 && (op == c0any || op == c1)) conflict = true;
+            }
+        }
+        if (__ballot(conflict)) {
+            for (int l = 0; l < 64; l++) {
+                const int il = base + l;
+                if (il >= M) break;
+                const int mm = m0 + il;
+                int cc;
+                const int p = decide(mm, ncand[mm], overflow[mm] != 0, cc);      // every lane computes the same value
+                if (lane == l) pick = p;
+                if (p >= 0 && (mps[mm].flags & 2u) && lane == 0) s_taken[p] = 1;
+                __syncthreads();
+            }
+        } else {
+            if (pick >= 0 && obs) s_taken[pick] = 1;
+        }
+        if (act) mpMatch[m] = pick;
+        if (pick >= 0) atomicMax(&s_match[pick], ml);        // F.mvpMapPoints[bestIdx] = pMP: the later point stays
+        nm += __popcll(__ballot(pick >= 0));
+        __syncthreads();
+    }
+    for (int i = lane; i < N; i += 64) kpMatch[(size_t)f * cap + i] = s_match[i];
+    if (lane == 0) nmatchOut[f] = nm;
+}

@@ -28,11 +28,11 @@ struct sd_extractor {
     SdParams prm;
 };
 
-enum KernelId { K_PYR0, K_PYR, K_FAST, K_QTREE, K_ORIENT, K_BLUR, K_DESC, K_STEREO, K_STEREO_F, K_RGBD, K_GRID, K_UNPROJ, K_PROJ_A, K_PROJ_B, K_BOXSEP, K_SEPARATE, K_UPDATE, K_COUNT };
+enum KernelId { K_PYR0, K_PYR, K_FAST, K_QTREE, K_ORIENT, K_BLUR, K_DESC, K_STEREO, K_STEREO_F, K_RGBD, K_GRID, K_UNPROJ, K_PROJ_A, K_PROJ_B, K_BOXSEP, K_SEPARATE, K_UPDATE, K_LOCAL_A, K_LOCAL_B, K_COUNT };
 static const char* kKernelNames[K_COUNT] = {"k_pyr_level0", "k_pyr_level", "k_fast_cells", "k_quadtree", "k_orient",
                                             "k_blur", "k_describe", "k_stereo_match", "k_stereo_filter", "k_rgbd",
                                             "k_grid_cells", "k_unproject", "k_proj_candidates", "k_proj_resolve",
-                                            "k_box_separate", "k_separate", "k_update_frame"};
+                                            "k_box_separate", "k_separate", "k_update_frame", "k_local_candidates", "k_local_resolve"};
 
 struct sd_batch {
     sd_extractor* ex = nullptr;
@@ -76,6 +76,7 @@ struct sd_batch {
     uint8_t* d_flags = nullptr;     // bit0: has map point (not outlier); bit1: Observations() > 0
     unsigned short* d_pcand = nullptr;
     uint8_t* d_pncand = nullptr;
+    unsigned* d_lmCand = nullptr; uint8_t* d_lmN = nullptr; uint8_t* d_lmOvf = nullptr; int* d_lmIdx = nullptr; int lmCap = 0;   // local-map search scratch
     int* d_match = nullptr;
     int* d_pairs = nullptr;
     int* d_npairs = nullptr;
@@ -205,7 +206,8 @@ static void batch_free(sd_batch* b)
                     b->d_pcand, b->d_pncand, b->d_match, b->d_pairs, b->d_npairs, b->d_nmatch, b->d_pose, b->d_pairIdx, b->d_sortedIdx, b->d_cellStart,
                     b->d_fb, b->d_boxItems, b->d_kpT, b->d_descT, b->d_urT, b->d_depT, b->d_slots, b->d_HorF, b->d_sepFlag,
                     b->d_lastIdx, b->d_lastStatus, b->d_nLast, b->d_dynStart, b->d_dynStatus, b->d_sepMatches, b->d_sepRet,
-                    b->d_sepPairs, b->d_kpD, b->d_descD, b->d_urD, b->d_depD, b->d_rowIdx, b->d_rowStart};
+                    b->d_sepPairs, b->d_kpD, b->d_descD, b->d_urD, b->d_depD, b->d_rowIdx, b->d_rowStart,
+                    b->d_lmCand, b->d_lmN, b->d_lmOvf, b->d_lmIdx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& r : b->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : b->pool) (void)hipEventDestroy(e);
@@ -485,7 +487,7 @@ int sd_batch_sync(sd_batch* b)
     HIPCHK(hipMemcpy(&err, b->d_err, 4, hipMemcpyDeviceToHost));
     if (err) {
         (void)hipMemset(b->d_err, 0, 4);
-        return set_err(SD_ERR_UNSUPPORTED, "device capacity exceeded: 1|2 quadtree nodes, 4 projection candidates, 8|16|32 box tables (flag " + std::to_string(err) + ")");
+        return set_err(SD_ERR_UNSUPPORTED, "device capacity exceeded: 1|2 quadtree nodes, 4 projection candidates, 8|16|32 box tables, 64 local-map candidates (flag " + std::to_string(err) + ")");
     }
     return SD_OK;
 }
@@ -916,6 +918,64 @@ int sd_batch_search_by_projection(sd_batch* b, int n_pairs, const int32_t* cur_i
     }
     LAUNCH_CHECK("k_proj_resolve");
     b->nPairs = n_pairs;
+    return SD_OK;
+}
+
+// Tracking::SearchLocalPoints (Tracking.cc:2014-2064): Frame::isInFrustum for every local map point, then
+// ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (ORBmatcher.cc:45-129).
+int sd_batch_search_local_map(sd_batch* b, int n_frames, const int32_t* frame_index, const int32_t* point_offset,
+                              const sd_map_point* d_points, const uint8_t* d_point_desc, const float* Tcw_host,
+                              const sd_camera* cam, float th, float nnratio, float viewing_cos_limit,
+                              const uint8_t* d_occupied, sd_track_info* d_track, int32_t* d_point_match,
+                              int32_t* d_kp_match, int32_t* d_nmatches, void* stream_)
+{
+    if (!b || n_frames < 0 || n_frames > b->maxImages || !cam_ok(cam) || !(th > 0) ||
+        (n_frames > 0 && (!frame_index || !point_offset || !Tcw_host || !d_track || !d_point_match || !d_kp_match || !d_nmatches)))
+        return set_err(SD_ERR_INVALID, "bad search_local_map arguments");
+    if (n_frames == 0) return SD_OK;
+    int maxM = 0;
+    for (int f = 0; f < n_frames; f++) {
+        if (!slot_ok(b, frame_index[f])) return set_err(SD_ERR_STATE, "search_local_map: frame slot holds no results");
+        const int M = point_offset[f + 1] - point_offset[f];
+        if (M < 0 || point_offset[0] != 0) return set_err(SD_ERR_INVALID, "search_local_map: point offsets must start at 0 and ascend");
+        maxM = std::max(maxM, M);
+    }
+    const int total = point_offset[n_frames];
+    if (total > 0 && (!d_points || !d_point_desc)) return set_err(SD_ERR_INVALID, "search_local_map: no map points given");
+    if (b->plan.kpCap > 65535) return set_err(SD_ERR_UNSUPPORTED, "more than 65535 keypoints per image");
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
+    b->lastStream = s;
+    if (total > b->lmCap) {                       // candidate scratch grows with the largest local map seen
+        HIPCHK(hipStreamSynchronize(s));
+        if (b->d_lmCand) { hipFree(b->d_lmCand); hipFree(b->d_lmN); hipFree(b->d_lmOvf); b->d_lmCand = nullptr; b->d_lmN = b->d_lmOvf = nullptr; }
+        const int want = std::max(total, 2 * b->lmCap);
+        HIPCHK(hipMalloc((void**)&b->d_lmCand, (size_t)want * SD_PROJ_K * 4));
+        HIPCHK(hipMalloc((void**)&b->d_lmN, (size_t)want));
+        HIPCHK(hipMalloc((void**)&b->d_lmOvf, (size_t)want));
+        b->lmCap = want;
+    }
+    if (!b->d_lmIdx) HIPCHK(hipMalloc((void**)&b->d_lmIdx, (size_t)(2 * b->maxImages + 2) * sizeof(int)));
+    int* dFrameOf = b->d_lmIdx;
+    int* dOff = b->d_lmIdx + b->maxImages;
+    HIPCHK(hipMemcpyAsync(dFrameOf, frame_index, (size_t)n_frames * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dOff, point_offset, (size_t)(n_frames + 1) * 4, hipMemcpyHostToDevice, s));
+    float* dT = b->d_pose;
+    HIPCHK(hipMemcpyAsync(dT, Tcw_host, (size_t)n_frames * 64, hipMemcpyHostToDevice, s));
+    const int cap = b->plan.kpCap;
+    if (maxM > 0) {
+        ProfScope ps(b, s, K_LOCAL_A);
+        hipLaunchKernelGGL(k_local_candidates, dim3((maxM + 3) / 4, n_frames), dim3(256), 0, s, b->d_kp, b->d_desc, b->d_uright, b->d_count,
+                           b->d_cellOf, b->d_sortedIdx, b->d_cellStart, (const SdMapPoint*)d_points, d_point_desc, dFrameOf, dOff, dT,
+                           (SdTrack*)d_track, b->d_lmCand, b->d_lmN, b->d_lmOvf, b->d_plan, to_cam(cam), th, viewing_cos_limit);
+        LAUNCH_CHECK("k_local_candidates");
+    }
+    {
+        ProfScope ps(b, s, K_LOCAL_B);
+        const size_t lds = (size_t)cap * 4 + cap + 16;
+        hipLaunchKernelGGL(k_local_resolve, dim3(n_frames), dim3(64), lds, s, b->d_kp, b->d_count, (const SdMapPoint*)d_points, dFrameOf, dOff,
+                           b->d_lmCand, b->d_lmN, b->d_lmOvf, d_occupied, d_point_match, d_kp_match, d_nmatches, b->d_err, b->d_plan, nnratio);
+        LAUNCH_CHECK("k_local_resolve");
+    }
     return SD_OK;
 }
 

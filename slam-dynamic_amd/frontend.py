@@ -290,6 +290,19 @@ class Batch:
                                                   th, int(bMono), int(checkOrientation), C.c_void_p(d_occupied or 0),
                                                   C.c_void_p(d_mp_desc or 0), C.c_void_p(stream or 0)))
 
+    def search_local_map(self, frame_index, point_offset, d_points, d_point_desc, Tcw, cam, th, nnratio, d_track,
+                         d_point_match, d_kp_match, d_nmatches, viewing_cos_limit=0.5, d_occupied=None, stream=None):
+        """Tracking::SearchLocalPoints: Frame::isInFrustum + ORBmatcher::SearchByProjection(Frame, MapPoints, th).
+        d_* are device pointers (ints); see include/sd_frontend.h for the layouts."""
+        c = camera_array(cam)
+        fi = np.ascontiguousarray(frame_index, np.int32); po = np.ascontiguousarray(point_offset, np.int32)
+        n = len(fi)
+        T = np.ascontiguousarray(Tcw, np.float32).reshape(n, 16)
+        check(lib().sd_batch_search_local_map(self.h, n, _p(fi), _p(po), C.c_void_p(d_points), C.c_void_p(d_point_desc), _p(T),
+                                              _p(c), C.c_float(th), C.c_float(nnratio), C.c_float(viewing_cos_limit),
+                                              C.c_void_p(d_occupied or 0), C.c_void_p(d_track), C.c_void_p(d_point_match),
+                                              C.c_void_p(d_kp_match), C.c_void_p(d_nmatches), C.c_void_p(stream or 0)))
+
     def copy_frame(self, src, dst, stream=None):
         check(lib().sd_batch_copy_frame(self.h, src, dst, C.c_void_p(stream or 0)))
 

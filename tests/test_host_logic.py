@@ -80,3 +80,36 @@ def test_multi_rank_gather_and_timing_gloo():
         assert p.exitcode == 0
     for rank, shape, means, t, vsum in res:
         assert tuple(shape) == (2, 5, 7) and means == [1, 2] and t == 2.0 and vsum == sum(range(100))
+
+
+def test_oracle_local_map_best_second_ratio():
+    """ORBmatcher::SearchByProjection(Frame, MapPoints) (ORBmatcher.cc:45-129) on a hand-made case: the ratio test only
+    applies when best and second best share a level; a keypoint taken by an earlier point with observations is skipped."""
+    import numpy as np
+    import __graft_entry__ as g
+    orc = g.load_oracle()
+    KP = orc.KP_DTYPE
+    cam10 = np.array([500, 500, 320, 240, 40, 0.08, 0, 640, 0, 480], np.float32)
+    sf = np.array([1.2 ** l for l in range(8)], np.float32)
+    kp = np.zeros(3, KP)
+    kp["x"] = [320, 322, 318]; kp["y"] = [240, 241, 239]; kp["octave"] = [0, 0, 1]
+    desc = np.zeros((3, 32), np.uint8)
+    desc[1, 0] = 0xF0          # 4 bits from the map point descriptor (all zero)
+    desc[2, :2] = 0xFF         # 16 bits
+    desc[0, 0] = 0x0F          # 4 bits, visited first (same cell, lower index)
+    ur = -np.ones(3, np.float32)
+    mp = np.zeros(2, orc.MAP_POINT_DTYPE)
+    mp["xw"] = [[0, 0, 5], [0, 0, 5]]; mp["normal"] = [[0, 0, 1], [0, 0, 1]]
+    mp["min_distance"] = 1; mp["max_distance"] = 5.5; mp["flags"] = [3, 3]
+    md = np.zeros((2, 32), np.uint8)
+    T = np.eye(4, dtype=np.float32)
+    track, mpm, kpm, nm = orc.search_local_map(kp, desc, ur, mp, md, T, cam10, sf, 1.0, 0.8)
+    assert track["in_view"].tolist() == [1, 1] and track["level"].tolist() == [1, 1]
+    assert track["proj_x"][0] == 320 and track["proj_y"][0] == 240 and track["view_cos"][0] == 1.0
+    # point 0: best = kp0 (4 bits, level 0), second = kp1 (4 bits, level 0): 4 > 0.8*4 -> rejected by the ratio test
+    # point 1: same candidates, same outcome
+    assert mpm.tolist() == [-1, -1] and nm == 0
+    desc[1, 0] = 0xFF          # second best now 8 bits: 4 <= 6.4 -> accepted; point 1 then sees kp0 taken:
+    track, mpm, kpm, nm = orc.search_local_map(kp, desc, ur, mp, md, T, cam10, sf, 1.0, 0.8)
+    # its best is kp1 (8 bits, level 0), second kp2 (16 bits, level 1): levels differ -> no ratio test
+    assert mpm.tolist() == [0, 1] and kpm.tolist() == [0, 1, -1] and nm == 2
