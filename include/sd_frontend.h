@@ -178,6 +178,46 @@ int sd_batch_search_local_map(sd_batch* b, int n_frames, const int32_t* frame_in
                               const sd_camera* cam, float th, float nnratio, float viewing_cos_limit,
                               const uint8_t* d_occupied, sd_track_info* d_track, int32_t* d_point_match,
                               int32_t* d_kp_match, int32_t* d_nmatches, void* stream);
+/* ---- vocabulary + bag of words (Thirdparty/DBoW2, src/Frame.cc:803-810, src/ORBmatcher.cc:159-288) ----
+ * sd_vocab = ORBVocabulary (DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>): one packed buffer in HBM
+ * (header | desc[n][32] | weight[n] f64 | parent[n] | childStart[n+1] | childIdx[n-1] | wordId[n]; node ids and the
+ * order of children are the text file's).  The buffer is what a multi-GPU job broadcasts once at start-up:
+ * rank 0 loads, every rank allocates sd_vocab_packed_bytes(n_nodes), RCCL-broadcasts into it and adopts it with
+ * sd_vocab_from_packed_device (the buffer stays owned by the caller). */
+typedef struct sd_vocab sd_vocab;
+/* TemplatedVocabulary::loadFromTextFile (TemplatedVocabulary.h:1338-1424; System.cc:70-78 loads ORBvoc.txt with it).
+ * Errors: unreadable file or a header outside k<=20, 1<=L<=10, scoring<=5, weighting<=3 -> SD_ERR_INVALID with the
+ * reference's message. */
+int sd_vocab_load_text(sd_vocab** out, const char* path);
+/* The same from parsed node lines (line i = node i+1): parent id, isLeaf, 32 descriptor bytes, weight. */
+int sd_vocab_from_nodes(sd_vocab** out, int k, int L, int scoring, int weighting, int n_lines, const int32_t* parent,
+                        const uint8_t* is_leaf, const uint8_t* desc, const double* weight);
+int sd_vocab_from_packed_device(sd_vocab** out, void* d_blob, size_t bytes);
+void sd_vocab_destroy(sd_vocab* v);
+int sd_vocab_info(const sd_vocab* v, int* k, int* L, int* scoring, int* weighting, int* n_nodes, int* n_words);
+int sd_vocab_packed_device(sd_vocab* v, void** d_blob, size_t* bytes);
+size_t sd_vocab_packed_bytes(int n_nodes);
+int sd_vocab_download_nodes(const sd_vocab* v, int32_t* parent, int32_t* n_children, int32_t* word_id, uint8_t* desc, double* weight);
+
+/* Frame::ComputeBoW (src/Frame.cc:803-810): mpORBvocabulary->transform(descriptors, mBowVec, mFeatVec, levelsup = 4)
+ * for the listed image slots.  Per slot: the BowVector (distinct word ids ascending + f64 values, normalised as the
+ * vocabulary's scoring asks), the FeatureVector flattened in map order (node id at level L - levelsup, feature index),
+ * and per feature the word / weight / node of TemplatedVocabulary::transform(feature, ...).
+ * meta[image][4] = {listed features, distinct nodes, distinct words, 0}. */
+int sd_batch_compute_bow(sd_batch* b, const sd_vocab* v, int n_images, const int32_t* image_index, int levelsup, void* stream);
+int sd_batch_bow_device(sd_batch* b, uint32_t** d_bow_word, double** d_bow_value, uint32_t** d_fv_node, uint32_t** d_fv_feature,
+                        int32_t** d_meta, int* cap);
+int sd_batch_download_bow(sd_batch* b, int image, uint32_t* bow_word, double* bow_value, int* n_words, uint32_t* fv_node,
+                          uint32_t* fv_feature, int* n_features, uint32_t* feature_word, double* feature_weight,
+                          uint32_t* feature_node, int cap);
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches) (src/ORBmatcher.cc:159-288;
+ * callers Tracking::TrackReferenceKeyFrame and Relocalization): pair p matches keyframe slot kf_index[p] against frame
+ * slot frame_index[p] (sd_batch_compute_bow must have run on both).  d_kf_valid (nullable, [n_pairs][cap] u8):
+ * pKF->GetMapPointMatches()[i] != NULL && !isBad().  Results through sd_batch_download_matches: match[iF] = index of the
+ * keyframe feature whose map point lands in vpMapPointMatches[iF] (or -1), nmatches = the return value; no pairs. */
+int sd_batch_search_by_bow(sd_batch* b, int n_pairs, const int32_t* kf_index, const int32_t* frame_index,
+                           const uint8_t* d_kf_valid, float nnratio, int checkOrientation, void* stream);
+
 /* Frame copy constructor (src/Frame.cc:39-63), as in `mLastFrame = Frame(mCurrentFrame)`: copies the frame
  * results of slot src (keypoints, descriptors, mvuRight/mvDepth, grid cells, map-point table) to slot dst. */
 int sd_batch_copy_frame(sd_batch* b, int src, int dst, void* stream);

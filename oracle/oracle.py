@@ -300,3 +300,84 @@ def update_frame(kp, boxStart, boxItems, dynStart, dynStatus):
     f.restype = C.c_int
     n = f(_p(kp), _p(bs), _p(it), len(bs) - 1, _p(ds), _p(dy), _p(out))
     return out[:n].copy()
+
+
+# ---- bag of words (oracle/bow_oracle.inc) ----
+class Vocabulary:
+    def __init__(self, handle):
+        if not handle:
+            raise ValueError("vocabulary could not be built / loaded")
+        self.h = C.c_void_p(handle)
+
+    @classmethod
+    def from_nodes(cls, voc):
+        f = lib().orc_vocab_create
+        f.restype = C.c_void_p
+        par = np.ascontiguousarray(voc["parent"], np.int32); leaf = np.ascontiguousarray(voc["is_leaf"], np.uint8)
+        d = np.ascontiguousarray(voc["desc"], np.uint8); w = np.ascontiguousarray(voc["weight"], np.float64)
+        return cls(f(int(voc["k"]), int(voc["L"]), int(voc["scoring"]), int(voc["weighting"]), len(par), _p(par), _p(leaf), _p(d), _p(w)))
+
+    @classmethod
+    def load_text(cls, path):
+        f = lib().orc_vocab_load_text
+        f.restype = C.c_void_p
+        return cls(f(str(path).encode()))
+
+    def info(self):
+        h = np.zeros(4, np.int32)
+        lib().orc_vocab_header(self.h, _p(h))
+        return dict(k=int(h[0]), L=int(h[1]), scoring=int(h[2]), weighting=int(h[3]), n_nodes=int(lib().orc_vocab_nodes(self.h)),
+                    n_words=int(lib().orc_vocab_words(self.h)))
+
+    def nodes(self):
+        n = self.info()["n_nodes"]
+        par = np.zeros(n, np.int32); nch = np.zeros(n, np.int32); wid = np.zeros(n, np.int32)
+        d = np.zeros((n, 32), np.uint8); w = np.zeros(n, np.float64)
+        lib().orc_vocab_export(self.h, _p(par), _p(nch), _p(wid), _p(d), _p(w))
+        return dict(parent=par, n_children=nch, word_id=wid, desc=d, weight=w)
+
+    def transform(self, desc, levelsup=4):
+        desc = np.ascontiguousarray(desc, np.uint8); N = len(desc)
+        word = np.zeros(N, np.uint32); weight = np.zeros(N, np.float64); nid = np.zeros(N, np.uint32)
+        lib().orc_transform(self.h, _p(desc), N, levelsup, _p(word), _p(weight), _p(nid))
+        return word, weight, nid
+
+    def compute_bow(self, desc, levelsup=4):
+        desc = np.ascontiguousarray(desc, np.uint8); N = len(desc)
+        bw = np.zeros(N, np.uint32); bv = np.zeros(N, np.float64); fn = np.zeros(N, np.uint32); ff = np.zeros(N, np.uint32)
+        nf = C.c_int()
+        nb = lib().orc_compute_bow(self.h, _p(desc), N, levelsup, _p(bw), _p(bv), _p(fn), _p(ff), C.byref(nf))
+        return dict(word=bw[:nb].copy(), value=bv[:nb].copy(), fv_node=fn[:nf.value].copy(), fv_feature=ff[:nf.value].copy())
+
+    def close(self):
+        if self.h:
+            lib().orc_vocab_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def bow_score_l1(a, b):
+    f = lib().orc_bow_score_l1
+    f.restype = C.c_double
+    w1 = np.ascontiguousarray(a["word"], np.uint32); v1 = np.ascontiguousarray(a["value"], np.float64)
+    w2 = np.ascontiguousarray(b["word"], np.uint32); v2 = np.ascontiguousarray(b["value"], np.float64)
+    return float(f(_p(w1), _p(v1), len(w1), _p(w2), _p(v2), len(w2)))
+
+
+def search_by_bow(kpKF, descKF, kf_valid, bowKF, kpF, descF, bowF, nnratio, checkOrientation=True):
+    kpKF = np.ascontiguousarray(kpKF); kpF = np.ascontiguousarray(kpF)
+    dK = np.ascontiguousarray(descKF, np.uint8); dF = np.ascontiguousarray(descF, np.uint8)
+    val = np.ascontiguousarray(kf_valid, np.uint8)
+    nK = np.ascontiguousarray(bowKF["fv_node"], np.uint32); fK = np.ascontiguousarray(bowKF["fv_feature"], np.uint32)
+    nF = np.ascontiguousarray(bowF["fv_node"], np.uint32); fF = np.ascontiguousarray(bowF["fv_feature"], np.uint32)
+    match = np.zeros(len(kpF), np.int32)
+    f = lib().orc_search_by_bow
+    f.restype = C.c_int
+    nm = f(_p(kpKF), _p(dK), _p(val), _p(nK), _p(fK), len(nK), _p(kpF), _p(dF), len(kpF), _p(nF), _p(fF), len(nF), C.c_float(nnratio),
+           int(checkOrientation), _p(match))
+    return match, nm

@@ -19,6 +19,10 @@
 #include <cstdio>
 #include <climits>
 #include <cstddef>
+#include <map>
+#include <fstream>
+#include <sstream>
+#include <string>
 using std::ptrdiff_t;
 
 using namespace cvl;
@@ -634,5 +638,6 @@ int orc_stereo_matches(void* hL, void* hR, const void* kL_, const uint8_t* dL, i
 
 #include "frame_oracle.inc"
 #include "cull_oracle.inc"
+#include "bow_oracle.inc"
 
 } // extern "C"

@@ -1,0 +1,319 @@
+// Bag-of-words kernels: the DBoW2 vocabulary tree of the reference (vendored, Thirdparty/DBoW2) and
+// ORBmatcher::SearchByBoW.
+//   k_bow_transform     TemplatedVocabulary::transform(feature, word, weight, nid, levelsup)   TemplatedVocabulary.h:1218-1259
+//   k_bow_finalize      ... transform(features, BowVector, FeatureVector, levelsup)           TemplatedVocabulary.h:1127-1203
+//                       BowVector::addWeight / addIfNotExist / normalize                      BowVector.cpp:35-85
+//                       FeatureVector::addFeature                                             FeatureVector.cpp:30-46
+//   k_search_by_bow     ORBmatcher::SearchByBoW(KeyFrame*, Frame&, matches)                   src/ORBmatcher.cc:159-288
+// The vocabulary is ONE packed buffer (the object bench.py broadcasts over RCCL at start-up):
+//   SdVocabHeader | desc[n][32] u8 | weight[n] f64 | parent[n] i32 | childStart[n+1] i32 | childIdx[n-1] i32 | wordId[n] i32
+// Node ids are the reference's (line number of the text file, root = 0); children keep file order, which decides ties.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct SdVocabHeader {
+    uint32_t magic, version, k, L, scoring, weighting, nNodes, nWords;
+    uint64_t offDesc, offWeight, offParent, offChildStart, offChildIdx, offWordId, totalBytes;
+    uint64_t pad[5];
+};                                     // 128 bytes
+#define SD_VOCAB_MAGIC 0x42564453u     // "SDVB"
+
+struct SdVocabDev {                    // device pointers into the packed buffer
+    const uint8_t* desc; const double* weight; const int* childStart; const int* childIdx; const int* wordId;
+    int L, scoring, weighting, nNodes;
+};
+
+// 16 lanes per feature: lane j scores child j (k <= 20 children: at most two rounds), a 16-lane butterfly keeps the
+// first minimum in child order (the reference's strict `d < best_d`).
+__global__ void __launch_bounds__(256) k_bow_transform(const uint8_t* __restrict__ desc, const int* __restrict__ count,
+                                                       const int* __restrict__ imgOf, SdVocabDev V, int levelsup, int cap,
+                                                       unsigned* __restrict__ wordOut, double* __restrict__ weightOut,
+                                                       unsigned* __restrict__ nidOut)
+{
+    const int img = imgOf[blockIdx.y];
+    const int sub = threadIdx.x & 15;
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int N = count[img];
+    const bool act = i < N;                       // whole 16-lane groups go inactive together
+    const size_t o = (size_t)img * cap + (act ? i : 0);
+    const uint4* df = (const uint4*)(desc + o * 32);
+    const uint4 f0 = df[0], f1 = df[1];
+    const int nid_level = V.L - levelsup;
+    unsigned node = 0, nid = 0;
+    bool nidSet = nid_level <= 0;
+    int level = 0;
+    while (true) {
+        const int cs = V.childStart[node], ce = V.childStart[node + 1];
+        if (cs == ce) break;                      // leaf
+        level++;
+        unsigned best = 0xFFFFFFFFu;
+        for (int c0 = cs; c0 < ce; c0 += 16) {
+            const int idx = c0 + sub;
+            unsigned key = 0xFFFFFFFFu;
+            if (idx < ce) {
+                const unsigned child = (unsigned)V.childIdx[idx];
+                const uint4* dn = (const uint4*)(V.desc + (size_t)child * 32);
+                key = ((unsigned)sd_hamming256(f0, f1, dn[0], dn[1]) << 16) | (unsigned)(idx - cs);
+            }
+            best = key < best ? key : best;
+        }
+#pragma unroll
+        for (int d = 8; d > 0; d >>= 1) { const unsigned o2 = (unsigned)__shfl_xor((int)best, d, 16); best = o2 < best ? o2 : best; }
+        node = (unsigned)V.childIdx[cs + (int)(best & 0xFFFFu)];
+        if (level == nid_level) { nid = node; nidSet = true; }
+    }
+    if (!nidSet) nid = node;                      // spec Q12: the reference leaves *nid unwritten here
+    if (act && sub == 0) { wordOut[o] = (unsigned)V.wordId[node]; weightOut[o] = V.weight[node]; nidOut[o] = nid; }
+}
+
+// ascending bitonic sort of n (power of two) 64-bit keys in LDS by one workgroup
+__device__ __forceinline__ void sd_block_sort64(unsigned long long* keys, int n, int tid, int nthreads)
+{
+    for (int k = 2; k <= n; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < n; t += nthreads) {
+                const int p = t ^ j;
+                if (p > t) {
+                    const unsigned long long a = keys[t], b = keys[p];
+                    const bool up = (t & k) == 0;
+                    if ((a > b) == up) { keys[t] = b; keys[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+// One workgroup per image.  FeatureVector = the features with weight > 0 sorted by (node id, feature index), + its runs;
+// BowVector = the distinct words ascending; a word seen c times holds ((w + w) + ...) summed c times in feature order (all
+// terms are the word's own weight) for TF / TF-IDF, w for IDF / BINARY; then the reference's normalisation, summed in
+// ascending word order by one lane (double additions do not commute bit-for-bit).
+__global__ void __launch_bounds__(256) k_bow_finalize(const int* __restrict__ count, const int* __restrict__ imgOf,
+                                                      const unsigned* __restrict__ word, const double* __restrict__ weight,
+                                                      const unsigned* __restrict__ nid, int cap, int sortN, int scoring, int weighting,
+                                                      unsigned* __restrict__ fvNode, unsigned* __restrict__ fvFeat,
+                                                      int* __restrict__ fvRunStart, unsigned* __restrict__ fvRunNode,
+                                                      unsigned* __restrict__ bowWord, double* __restrict__ bowVal,
+                                                      int* __restrict__ meta /*[img][4]: nf, nRuns, nb, -*/)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned long long* keys = (unsigned long long*)smem;       // [sortN]
+    int* s_scan = (int*)(keys + sortN);                          // [256 + 1]
+    __shared__ double s_norm;
+    const int img = imgOf[blockIdx.x], tid = threadIdx.x;
+    const int N = count[img];
+    const size_t base = (size_t)img * cap;
+    // ---------------- FeatureVector
+    for (int t = tid; t < sortN; t += 256) {
+        unsigned long long key = ~0ull;
+        if (t < N && weight[base + t] > 0) key = ((unsigned long long)nid[base + t] << 32) | (unsigned)t;
+        keys[t] = key;
+    }
+    __syncthreads();
+    sd_block_sort64(keys, sortN, tid, 256);
+    // nf = number of real keys; runs = distinct node ids.  Chunked scan: thread t owns items [t*per, (t+1)*per)
+    const int per = sortN / 256 > 0 ? sortN / 256 : 1;
+    {
+        int nfLocal = 0, runsLocal = 0;
+        for (int q = 0; q < per; q++) {
+            const int t = tid * per + q;
+            if (t < sortN && keys[t] != ~0ull) {
+                nfLocal++;
+                if (t == 0 || (keys[t] >> 32) != (keys[t - 1] >> 32)) runsLocal++;
+            }
+        }
+        s_scan[tid] = runsLocal;
+        __syncthreads();
+        if (tid == 0) { int acc = 0; for (int k = 0; k < 256; k++) { const int v = s_scan[k]; s_scan[k] = acc; acc += v; } s_scan[256] = acc; }
+        __syncthreads();
+        int r = s_scan[tid];
+        for (int q = 0; q < per; q++) {
+            const int t = tid * per + q;
+            if (t < sortN && keys[t] != ~0ull) {
+                fvNode[base + t] = (unsigned)(keys[t] >> 32); fvFeat[base + t] = (unsigned)(keys[t] & 0xFFFFFFFFu);
+                if (t == 0 || (keys[t] >> 32) != (keys[t - 1] >> 32)) { fvRunStart[(size_t)img * (cap + 1) + r] = t; fvRunNode[base + r] = (unsigned)(keys[t] >> 32); r++; }
+            }
+        }
+        const int nRuns = s_scan[256];
+        __syncthreads();
+        s_scan[tid] = nfLocal;
+        __syncthreads();
+        if (tid == 0) {
+            int nf = 0; for (int k = 0; k < 256; k++) nf += s_scan[k];
+            meta[img * 4 + 0] = nf; meta[img * 4 + 1] = nRuns;
+            fvRunStart[(size_t)img * (cap + 1) + nRuns] = nf;
+        }
+        __syncthreads();
+    }
+    // ---------------- BowVector
+    for (int t = tid; t < sortN; t += 256) {
+        unsigned long long key = ~0ull;
+        if (t < N && weight[base + t] > 0) key = ((unsigned long long)word[base + t] << 32) | (unsigned)t;
+        keys[t] = key;
+    }
+    __syncthreads();
+    sd_block_sort64(keys, sortN, tid, 256);
+    {
+        int local = 0;
+        for (int q = 0; q < per; q++) {
+            const int t = tid * per + q;
+            if (t < sortN && keys[t] != ~0ull && (t == 0 || (keys[t] >> 32) != (keys[t - 1] >> 32))) local++;
+        }
+        s_scan[tid] = local;
+        __syncthreads();
+        if (tid == 0) { int acc = 0; for (int k = 0; k < 256; k++) { const int v = s_scan[k]; s_scan[k] = acc; acc += v; } s_scan[256] = acc; }
+        __syncthreads();
+        int r = s_scan[tid];
+        const int nb = s_scan[256];
+        for (int q = 0; q < per; q++) {
+            const int t = tid * per + q;
+            if (t < sortN && keys[t] != ~0ull && (t == 0 || (keys[t] >> 32) != (keys[t - 1] >> 32))) {
+                const unsigned w = (unsigned)(keys[t] >> 32);
+                int c = 1;
+                while (t + c < sortN && (unsigned)(keys[t + c] >> 32) == w) c++;
+                const double wv = weight[base + (unsigned)(keys[t] & 0xFFFFFFFFu)];
+                double v = wv;
+                if (weighting == 0 || weighting == 1) for (int a = 1; a < c; a++) v += wv;       // addWeight, once per feature
+                bowWord[base + r] = w; bowVal[base + r] = v;
+                r++;
+            }
+        }
+        __syncthreads();
+        const bool must = scoring != 5;
+        if ((weighting == 0 || weighting == 1) && nb > 0 && !must) {
+            const double nd = (double)nb;
+            for (int t = tid; t < nb; t += 256) bowVal[base + t] /= nd;
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (must) {
+            if (tid == 0) {
+                double norm = 0.0;
+                if (scoring != 1) { for (int t = 0; t < nb; t++) norm += fabs(bowVal[base + t]); }
+                else { for (int t = 0; t < nb; t++) norm += bowVal[base + t] * bowVal[base + t]; norm = sqrt(norm); }
+                s_norm = norm;
+            }
+            __syncthreads();
+            const double norm = s_norm;
+            if (norm > 0.0) for (int t = tid; t < nb; t += 256) bowVal[base + t] /= norm;
+        }
+        if (tid == 0) meta[img * 4 + 2] = nb;
+    }
+}
+
+// One workgroup per (keyframe, frame) pair; a wave takes the vocabulary nodes both FeatureVectors share.  A frame feature
+// belongs to exactly one node, so waves never contend for a keypoint; inside a node the keyframe features are walked in
+// order (the order that decides which frame keypoints are already taken, ORBmatcher.cc:206-207).  Best / second best over
+// the not-yet-taken frame features = first and second entry of the (distance, position) order (see k_local_resolve).
+__global__ void __launch_bounds__(256) k_search_by_bow(
+    const sd_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc, const int* __restrict__ count,
+    const unsigned* __restrict__ fvFeat, const int* __restrict__ fvRunStart, const unsigned* __restrict__ fvRunNode,
+    const int* __restrict__ meta, const uint8_t* __restrict__ kfValid /*nullable [pair][cap]*/, const int2* __restrict__ pairIdx,
+    int cap, float nnratio, int checkOrientation, int* __restrict__ matchOut, int* __restrict__ nmatchOut)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    int* s_match = (int*)smem;                               // [cap]
+    uint8_t* s_bin = (uint8_t*)(s_match + cap);              // [cap]
+    __shared__ int s_hist[SD_HISTO];
+    __shared__ int s_ind[3];
+    __shared__ int s_nm;
+    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int imgK = pairIdx[pair].x, imgF = pairIdx[pair].y;
+    const int NF = count[imgF];
+    for (int i = tid; i < NF; i += 256) s_match[i] = -1;
+    if (tid < SD_HISTO) s_hist[tid] = 0;
+    if (tid == 0) s_nm = 0;
+    __syncthreads();
+    const int runsK = meta[imgK * 4 + 1], runsF = meta[imgF * 4 + 1];
+    const int* rsK = fvRunStart + (size_t)imgK * (cap + 1);
+    const int* rsF = fvRunStart + (size_t)imgF * (cap + 1);
+    const unsigned* rnK = fvRunNode + (size_t)imgK * cap;
+    const unsigned* rnF = fvRunNode + (size_t)imgF * cap;
+    const unsigned* ffK = fvFeat + (size_t)imgK * cap;
+    const unsigned* ffF = fvFeat + (size_t)imgF * cap;
+    const uint8_t* dK = desc + (size_t)imgK * cap * 32;
+    const uint8_t* dF = desc + (size_t)imgF * cap * 32;
+    const sd_keypoint* kK = kp + (size_t)imgK * cap;
+    const sd_keypoint* kF = kp + (size_t)imgF * cap;
+    const float factor = 1.0f / SD_HISTO;
+    int nm = 0;
+    for (int rk = wv; rk < runsK; rk += 4) {
+        const unsigned node = rnK[rk];
+        int lo = 0, hi = runsF;                               // lower_bound of node in the frame's runs
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (rnF[mid] < node) lo = mid + 1; else hi = mid; }
+        if (lo >= runsF || rnF[lo] != node) continue;
+        const int a0 = rsK[rk], a1 = rsK[rk + 1], c0 = rsF[lo], c1 = rsF[lo + 1];
+        for (int a = a0; a < a1; a++) {
+            const unsigned iK = ffK[a];
+            if (kfValid && !kfValid[(size_t)pair * cap + iK]) continue;
+            const uint4* pk = (const uint4*)(dK + (size_t)iK * 32);
+            const uint4 k0 = pk[0], k1 = pk[1];
+            unsigned best1 = 0xFFFFFFFFu;                     // dist << 16 | position in the node's frame list
+            for (int c = c0 + lane; c < c1; c += 64) {
+                const unsigned iF = ffF[c];
+                if (s_match[iF] >= 0) continue;
+                const uint4* pf = (const uint4*)(dF + (size_t)iF * 32);
+                const unsigned key = ((unsigned)sd_hamming256(k0, k1, pf[0], pf[1]) << 16) | (unsigned)(c - c0);
+                best1 = key < best1 ? key : best1;
+            }
+            unsigned b1 = best1;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)b1, d, 64); b1 = o < b1 ? o : b1; }
+            if (b1 == 0xFFFFFFFFu) continue;                  // no free frame feature in this node
+            unsigned best2 = 0xFFFFFFFFu;                     // the smallest key other than the winner
+            for (int c = c0 + lane; c < c1; c += 64) {
+                const unsigned iF = ffF[c];
+                if (s_match[iF] >= 0 || (unsigned)(c - c0) == (b1 & 0xFFFFu)) continue;
+                const uint4* pf = (const uint4*)(dF + (size_t)iF * 32);
+                const unsigned key = ((unsigned)sd_hamming256(k0, k1, pf[0], pf[1]) << 16) | (unsigned)(c - c0);
+                best2 = key < best2 ? key : best2;
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)best2, d, 64); best2 = o < best2 ? o : best2; }
+            const int bestDist1 = (int)(b1 >> 16), bestDist2 = best2 == 0xFFFFFFFFu ? 256 : (int)(best2 >> 16);
+            if (bestDist1 <= SD_TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) {
+                const unsigned iF = ffF[c0 + (int)(b1 & 0xFFFFu)];
+                if (lane == 0) {
+                    s_match[iF] = (int)iK;
+                    int bin = 0;
+                    if (checkOrientation) {
+                        float rot = kK[iK].angle - kF[iF].angle;
+                        if (rot < 0.0f) rot += 360.0f;
+                        bin = (int)roundf(rot * factor);
+                        if (bin == SD_HISTO) bin = 0;
+                        atomicAdd(&s_hist[bin], 1);
+                    }
+                    s_bin[iF] = (uint8_t)bin;
+                }
+                nm++;
+                __builtin_amdgcn_wave_barrier();
+            }
+            __threadfence_block();                            // s_match written by lane 0 is read by every lane next round
+        }
+    }
+    if (lane == 0) atomicAdd(&s_nm, nm);
+    __syncthreads();
+    if (checkOrientation) {
+        if (tid == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;     // ComputeThreeMaxima (ORBmatcher.cc:1758-1799)
+            for (int b = 0; b < SD_HISTO; b++) {
+                const int s = s_hist[b];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = b; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = b; }
+                else if (s > max3) { max3 = s; ind3 = b; }
+            }
+            if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+            s_ind[0] = ind1; s_ind[1] = ind2; s_ind[2] = ind3;
+        }
+        __syncthreads();
+        const int i1 = s_ind[0], i2 = s_ind[1], i3 = s_ind[2];
+        int culled = 0;
+        for (int i = tid; i < NF; i += 256)
+            if (s_match[i] >= 0) { const int b = s_bin[i]; if (b != i1 && b != i2 && b != i3) { s_match[i] = -1; culled++; } }
+        if (culled) atomicSub(&s_nm, culled);
+        __syncthreads();
+    }
+    for (int i = tid; i < NF; i += 256) matchOut[(size_t)pair * cap + i] = s_match[i];
+    if (tid == 0) nmatchOut[pair] = s_nm;
+}

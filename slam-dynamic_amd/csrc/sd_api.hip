@@ -12,6 +12,7 @@
 #include "k_fast.h"
 #include "k_cull.h"
 #include "sd_yolo.h"
+#include "sd_vocab.h"
 
 static thread_local std::string g_err;
 static int set_err(int code, const std::string& msg) { g_err = msg; return code; }
@@ -28,11 +29,11 @@ struct sd_extractor {
     SdParams prm;
 };
 
-enum KernelId { K_PYR0, K_PYR, K_FAST, K_QTREE, K_ORIENT, K_BLUR, K_DESC, K_STEREO, K_STEREO_F, K_RGBD, K_GRID, K_UNPROJ, K_PROJ_A, K_PROJ_B, K_BOXSEP, K_SEPARATE, K_UPDATE, K_LOCAL_A, K_LOCAL_B, K_COUNT };
+enum KernelId { K_PYR0, K_PYR, K_FAST, K_QTREE, K_ORIENT, K_BLUR, K_DESC, K_STEREO, K_STEREO_F, K_RGBD, K_GRID, K_UNPROJ, K_PROJ_A, K_PROJ_B, K_BOXSEP, K_SEPARATE, K_UPDATE, K_LOCAL_A, K_LOCAL_B, K_BOW_T, K_BOW_F, K_BOW_S, K_COUNT };
 static const char* kKernelNames[K_COUNT] = {"k_pyr_level0", "k_pyr_level", "k_fast_cells", "k_quadtree", "k_orient",
                                             "k_blur", "k_describe", "k_stereo_match", "k_stereo_filter", "k_rgbd",
                                             "k_grid_cells", "k_unproject", "k_proj_candidates", "k_proj_resolve",
-                                            "k_box_separate", "k_separate", "k_update_frame", "k_local_candidates", "k_local_resolve"};
+                                            "k_box_separate", "k_separate", "k_update_frame", "k_local_candidates", "k_local_resolve", "k_bow_transform", "k_bow_finalize", "k_search_by_bow"};
 
 struct sd_batch {
     sd_extractor* ex = nullptr;
@@ -76,6 +77,10 @@ struct sd_batch {
     uint8_t* d_flags = nullptr;     // bit0: has map point (not outlier); bit1: Observations() > 0
     unsigned short* d_pcand = nullptr;
     uint8_t* d_pncand = nullptr;
+    // bag of words (per image): per-feature word / weight / node, FeatureVector (sorted) + runs, BowVector
+    unsigned* d_bowWordF = nullptr; double* d_bowWF = nullptr; unsigned* d_bowNidF = nullptr; unsigned* d_fvNode = nullptr; unsigned* d_fvFeat = nullptr;
+    int* d_fvRunStart = nullptr; unsigned* d_fvRunNode = nullptr; unsigned* d_bowWord = nullptr; double* d_bowVal = nullptr; int* d_bowMeta = nullptr;
+    int* d_bowImg = nullptr; std::vector<uint8_t> bowValid;
     unsigned* d_lmCand = nullptr; uint8_t* d_lmN = nullptr; uint8_t* d_lmOvf = nullptr; int* d_lmIdx = nullptr; int lmCap = 0;   // local-map search scratch
     int* d_match = nullptr;
     int* d_pairs = nullptr;
@@ -207,7 +212,8 @@ static void batch_free(sd_batch* b)
                     b->d_fb, b->d_boxItems, b->d_kpT, b->d_descT, b->d_urT, b->d_depT, b->d_slots, b->d_HorF, b->d_sepFlag,
                     b->d_lastIdx, b->d_lastStatus, b->d_nLast, b->d_dynStart, b->d_dynStatus, b->d_sepMatches, b->d_sepRet,
                     b->d_sepPairs, b->d_kpD, b->d_descD, b->d_urD, b->d_depD, b->d_rowIdx, b->d_rowStart,
-                    b->d_lmCand, b->d_lmN, b->d_lmOvf, b->d_lmIdx};
+                    b->d_lmCand, b->d_lmN, b->d_lmOvf, b->d_lmIdx, b->d_bowWordF, b->d_bowWF, b->d_bowNidF, b->d_fvNode, b->d_fvFeat,
+                    b->d_fvRunStart, b->d_fvRunNode, b->d_bowWord, b->d_bowVal, b->d_bowMeta, b->d_bowImg};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& r : b->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : b->pool) (void)hipEventDestroy(e);
@@ -979,6 +985,248 @@ int sd_batch_search_local_map(sd_batch* b, int n_frames, const int32_t* frame_in
     return SD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Vocabulary (Thirdparty/DBoW2 TemplatedVocabulary) and the bag-of-words matcher
+// ---------------------------------------------------------------------------------------------------------
+static int require_device()
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(SD_ERR_NO_DEVICE, "no HIP device: the vocabulary lives in HBM, there is no CPU fallback");
+    return SD_OK;
+}
+
+static int vocab_from_lines(sd_vocab** out, const SdVocabLines& lines)
+{
+    std::vector<uint8_t> blob;
+    if (!vocab_pack(lines, blob)) return set_err(SD_ERR_INVALID, "vocabulary: a node names a parent that does not precede it");
+    sd_vocab* v = new sd_vocab();
+    memcpy(&v->h, blob.data(), sizeof(SdVocabHeader));
+    if (hipMalloc(&v->d_blob, blob.size()) != hipSuccess) { delete v; return set_err(SD_ERR_HIP, "hipMalloc(vocabulary)"); }
+    v->owned = true;
+    if (hipMemcpy(v->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(v->d_blob); delete v; return set_err(SD_ERR_HIP, "hipMemcpy(vocabulary)"); }
+    vocab_bind(v);
+    *out = v;
+    return SD_OK;
+}
+
+int sd_vocab_load_text(sd_vocab** out, const char* path)
+{
+    if (!out || !path) return set_err(SD_ERR_INVALID, "null argument");
+    *out = nullptr;
+    int rc = require_device();
+    if (rc != SD_OK) return rc;
+    SdVocabLines lines;
+    std::string err;
+    if (!vocab_parse_text(path, lines, err)) return set_err(SD_ERR_INVALID, err);
+    return vocab_from_lines(out, lines);
+}
+
+int sd_vocab_from_nodes(sd_vocab** out, int k, int L, int scoring, int weighting, int n_lines, const int32_t* parent,
+                        const uint8_t* is_leaf, const uint8_t* desc, const double* weight)
+{
+    if (!out || n_lines < 0 || (n_lines > 0 && (!parent || !is_leaf || !desc || !weight))) return set_err(SD_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (k < 0 || k > 20 || L < 1 || L > 10 || scoring < 0 || scoring > 5 || weighting < 0 || weighting > 3)
+        return set_err(SD_ERR_INVALID, "Vocabulary loading failure: This is not a correct text file!");
+    int rc = require_device();
+    if (rc != SD_OK) return rc;
+    SdVocabLines lines;
+    lines.k = k; lines.L = L; lines.scoring = scoring; lines.weighting = weighting;
+    lines.parent.assign(parent, parent + n_lines); lines.isLeaf.assign(is_leaf, is_leaf + n_lines);
+    lines.desc.assign(desc, desc + (size_t)n_lines * 32); lines.weight.assign(weight, weight + n_lines);
+    return vocab_from_lines(out, lines);
+}
+
+int sd_vocab_from_packed_device(sd_vocab** out, void* d_blob, size_t bytes)
+{
+    if (!out || !d_blob || bytes < sizeof(SdVocabHeader)) return set_err(SD_ERR_INVALID, "null argument");
+    *out = nullptr;
+    int rc = require_device();
+    if (rc != SD_OK) return rc;
+    SdVocabHeader h;
+    HIPCHK(hipMemcpy(&h, d_blob, sizeof(h), hipMemcpyDeviceToHost));
+    SdVocabHeader chk = h;
+    if (h.magic != SD_VOCAB_MAGIC || h.version != 1 || vocab_layout(chk) != h.totalBytes || h.totalBytes > bytes ||
+        chk.offWordId != h.offWordId || chk.offDesc != h.offDesc)
+        return set_err(SD_ERR_INVALID, "not a packed vocabulary");
+    sd_vocab* v = new sd_vocab();
+    v->h = h; v->d_blob = d_blob; v->owned = false;
+    vocab_bind(v);
+    *out = v;
+    return SD_OK;
+}
+
+void sd_vocab_destroy(sd_vocab* v)
+{
+    if (!v) return;
+    if (v->owned && v->d_blob) (void)hipFree(v->d_blob);
+    delete v;
+}
+
+int sd_vocab_info(const sd_vocab* v, int* k, int* L, int* scoring, int* weighting, int* n_nodes, int* n_words)
+{
+    if (!v) return SD_ERR_INVALID;
+    if (k) *k = (int)v->h.k; if (L) *L = (int)v->h.L; if (scoring) *scoring = (int)v->h.scoring; if (weighting) *weighting = (int)v->h.weighting;
+    if (n_nodes) *n_nodes = (int)v->h.nNodes; if (n_words) *n_words = (int)v->h.nWords;
+    return SD_OK;
+}
+
+int sd_vocab_packed_device(sd_vocab* v, void** d_blob, size_t* bytes)
+{
+    if (!v) return SD_ERR_INVALID;
+    if (d_blob) *d_blob = v->d_blob;
+    if (bytes) *bytes = (size_t)v->h.totalBytes;
+    return SD_OK;
+}
+
+size_t sd_vocab_packed_bytes(int n_nodes)
+{
+    SdVocabHeader h = {};
+    h.nNodes = (uint32_t)(n_nodes < 0 ? 0 : n_nodes);
+    return vocab_layout(h);
+}
+
+int sd_vocab_download_nodes(const sd_vocab* v, int32_t* parent, int32_t* n_children, int32_t* word_id, uint8_t* desc, double* weight)
+{
+    if (!v) return SD_ERR_INVALID;
+    const int n = (int)v->h.nNodes;
+    const uint8_t* p = (const uint8_t*)v->d_blob;
+    if (parent) HIPCHK(hipMemcpy(parent, p + v->h.offParent, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (word_id) HIPCHK(hipMemcpy(word_id, p + v->h.offWordId, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (desc) HIPCHK(hipMemcpy(desc, p + v->h.offDesc, (size_t)n * 32, hipMemcpyDeviceToHost));
+    if (weight) HIPCHK(hipMemcpy(weight, p + v->h.offWeight, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (n_children) {
+        std::vector<int> cs(n + 1);
+        HIPCHK(hipMemcpy(cs.data(), p + v->h.offChildStart, (size_t)(n + 1) * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; i++) n_children[i] = cs[i + 1] - cs[i];
+    }
+    return SD_OK;
+}
+
+static int bow_alloc(sd_batch* b)
+{
+    if (b->d_bowWordF) return SD_OK;
+    const size_t nI = b->maxImages, cap = b->plan.kpCap;
+    HIPCHK(hipMalloc((void**)&b->d_bowWordF, nI * cap * 4)); HIPCHK(hipMalloc((void**)&b->d_bowWF, nI * cap * 8));
+    HIPCHK(hipMalloc((void**)&b->d_bowNidF, nI * cap * 4)); HIPCHK(hipMalloc((void**)&b->d_fvNode, nI * cap * 4));
+    HIPCHK(hipMalloc((void**)&b->d_fvFeat, nI * cap * 4)); HIPCHK(hipMalloc((void**)&b->d_fvRunStart, nI * (cap + 1) * 4));
+    HIPCHK(hipMalloc((void**)&b->d_fvRunNode, nI * cap * 4)); HIPCHK(hipMalloc((void**)&b->d_bowWord, nI * cap * 4));
+    HIPCHK(hipMalloc((void**)&b->d_bowVal, nI * cap * 8)); HIPCHK(hipMalloc((void**)&b->d_bowMeta, nI * 4 * 4));
+    HIPCHK(hipMalloc((void**)&b->d_bowImg, nI * 4));
+    HIPCHK(hipMemset(b->d_bowMeta, 0, nI * 16));
+    b->bowValid.assign(nI, 0);
+    return SD_OK;
+}
+
+// Frame::ComputeBoW (src/Frame.cc:803-810) for the listed image slots.
+int sd_batch_compute_bow(sd_batch* b, const sd_vocab* v, int n_images, const int32_t* image_index, int levelsup, void* stream_)
+{
+    if (!b || !v || n_images < 0 || n_images > b->maxImages || (n_images > 0 && !image_index) || levelsup < 0)
+        return set_err(SD_ERR_INVALID, "bad compute_bow arguments");
+    if (v->h.nNodes <= 1) return set_err(SD_ERR_INVALID, "compute_bow: empty vocabulary");
+    for (int i = 0; i < n_images; i++) if (!slot_ok(b, image_index[i])) return set_err(SD_ERR_STATE, "compute_bow: image slot holds no results");
+    const int cap = b->plan.kpCap;
+    int sortN = 64;
+    while (sortN < cap) sortN <<= 1;
+    if (sortN > 8192) return set_err(SD_ERR_UNSUPPORTED, "compute_bow: more than 8192 keypoints per image");
+    int rc = bow_alloc(b);
+    if (rc != SD_OK) return rc;
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
+    b->lastStream = s;
+    if (n_images == 0) return SD_OK;
+    HIPCHK(hipMemcpyAsync(b->d_bowImg, image_index, (size_t)n_images * 4, hipMemcpyHostToDevice, s));
+    {
+        ProfScope ps(b, s, K_BOW_T);
+        hipLaunchKernelGGL(k_bow_transform, dim3((cap + 15) / 16, n_images), dim3(256), 0, s, b->d_desc, b->d_count, b->d_bowImg, v->dev, levelsup, cap,
+                           b->d_bowWordF, b->d_bowWF, b->d_bowNidF);
+        LAUNCH_CHECK("k_bow_transform");
+    }
+    {
+        ProfScope ps(b, s, K_BOW_F);
+        const size_t lds = (size_t)sortN * 8 + 257 * 4 + 16;
+        hipLaunchKernelGGL(k_bow_finalize, dim3(n_images), dim3(256), lds, s, b->d_count, b->d_bowImg, b->d_bowWordF, b->d_bowWF, b->d_bowNidF, cap, sortN,
+                           (int)v->h.scoring, (int)v->h.weighting, b->d_fvNode, b->d_fvFeat, b->d_fvRunStart, b->d_fvRunNode, b->d_bowWord,
+                           b->d_bowVal, b->d_bowMeta);
+        LAUNCH_CHECK("k_bow_finalize");
+    }
+    for (int i = 0; i < n_images; i++) b->bowValid[image_index[i]] = 1;
+    return SD_OK;
+}
+
+int sd_batch_bow_device(sd_batch* b, uint32_t** d_bow_word, double** d_bow_value, uint32_t** d_fv_node, uint32_t** d_fv_feature,
+                        int32_t** d_meta, int* cap)
+{
+    if (!b) return SD_ERR_INVALID;
+    int rc = bow_alloc(b);
+    if (rc != SD_OK) return rc;
+    if (d_bow_word) *d_bow_word = b->d_bowWord; if (d_bow_value) *d_bow_value = b->d_bowVal;
+    if (d_fv_node) *d_fv_node = b->d_fvNode; if (d_fv_feature) *d_fv_feature = b->d_fvFeat;
+    if (d_meta) *d_meta = b->d_bowMeta; if (cap) *cap = b->plan.kpCap;
+    return SD_OK;
+}
+
+int sd_batch_download_bow(sd_batch* b, int image, uint32_t* bow_word, double* bow_value, int* n_words, uint32_t* fv_node,
+                          uint32_t* fv_feature, int* n_features, uint32_t* feature_word, double* feature_weight, uint32_t* feature_node, int cap)
+{
+    if (!b || image < 0 || image >= b->maxImages) return SD_ERR_INVALID;
+    int rc = sd_batch_sync(b);
+    if (rc != SD_OK) return rc;
+    if (!b->d_bowWordF || !b->bowValid[image]) return set_err(SD_ERR_STATE, "download_bow: no bag of words computed for this slot");
+    int meta[4];
+    HIPCHK(hipMemcpy(meta, b->d_bowMeta + image * 4, 16, hipMemcpyDeviceToHost));
+    int cnt = 0;
+    HIPCHK(hipMemcpy(&cnt, b->d_count + image, 4, hipMemcpyDeviceToHost));
+    if (cnt > cap) return set_err(SD_ERR_CAPACITY, "bow buffer too small");
+    const size_t off = (size_t)image * b->plan.kpCap;
+    if (n_words) *n_words = meta[2];
+    if (n_features) *n_features = meta[0];
+    if (meta[2] > 0) {
+        if (bow_word) HIPCHK(hipMemcpy(bow_word, b->d_bowWord + off, (size_t)meta[2] * 4, hipMemcpyDeviceToHost));
+        if (bow_value) HIPCHK(hipMemcpy(bow_value, b->d_bowVal + off, (size_t)meta[2] * 8, hipMemcpyDeviceToHost));
+    }
+    if (meta[0] > 0) {
+        if (fv_node) HIPCHK(hipMemcpy(fv_node, b->d_fvNode + off, (size_t)meta[0] * 4, hipMemcpyDeviceToHost));
+        if (fv_feature) HIPCHK(hipMemcpy(fv_feature, b->d_fvFeat + off, (size_t)meta[0] * 4, hipMemcpyDeviceToHost));
+    }
+    if (cnt > 0) {
+        if (feature_word) HIPCHK(hipMemcpy(feature_word, b->d_bowWordF + off, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+        if (feature_weight) HIPCHK(hipMemcpy(feature_weight, b->d_bowWF + off, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+        if (feature_node) HIPCHK(hipMemcpy(feature_node, b->d_bowNidF + off, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    }
+    return SD_OK;
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches) (src/ORBmatcher.cc:159-288)
+int sd_batch_search_by_bow(sd_batch* b, int n_pairs, const int32_t* kf_index, const int32_t* frame_index, const uint8_t* d_kf_valid,
+                           float nnratio, int checkOrientation, void* stream_)
+{
+    if (!b || n_pairs < 0 || n_pairs > b->maxImages || (n_pairs > 0 && (!kf_index || !frame_index)))
+        return set_err(SD_ERR_INVALID, "bad search_by_bow arguments");
+    std::vector<int2> idx(n_pairs);
+    for (int p = 0; p < n_pairs; p++) {
+        if (!slot_ok(b, kf_index[p]) || !slot_ok(b, frame_index[p])) return set_err(SD_ERR_STATE, "search_by_bow: frame slot holds no results");
+        if (!b->d_bowWordF || !b->bowValid[kf_index[p]] || !b->bowValid[frame_index[p]])
+            return set_err(SD_ERR_STATE, "search_by_bow: sd_batch_compute_bow has not run on these slots");
+        idx[p] = make_int2(kf_index[p], frame_index[p]);
+    }
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
+    b->lastStream = s;
+    b->nPairs = 0;
+    if (n_pairs == 0) return SD_OK;
+    HIPCHK(hipMemcpyAsync(b->d_pairIdx, idx.data(), (size_t)n_pairs * sizeof(int2), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(b->d_npairs, 0, (size_t)n_pairs * 4, s));
+    const int cap = b->plan.kpCap;
+    {
+        ProfScope ps(b, s, K_BOW_S);
+        const size_t lds = (size_t)cap * 4 + cap + 16;
+        hipLaunchKernelGGL(k_search_by_bow, dim3(n_pairs), dim3(256), lds, s, b->d_kp, b->d_desc, b->d_count, b->d_fvFeat, b->d_fvRunStart, b->d_fvRunNode,
+                           b->d_bowMeta, d_kf_valid, b->d_pairIdx, cap, nnratio, checkOrientation, b->d_match, b->d_nmatch);
+        LAUNCH_CHECK("k_search_by_bow");
+    }
+    b->nPairs = n_pairs;
+    return SD_OK;
+}
+
 // Frame copy (mLastFrame = Frame(mCurrentFrame), Tracking.cc; Frame.cc:39-63): keypoints, descriptors,
 // stereo coordinates, grid cells and the map-point table of slot `src` into slot `dst`.
 int sd_batch_copy_frame(sd_batch* b, int src, int dst, void* stream_)
@@ -1005,6 +1253,7 @@ int sd_batch_copy_frame(sd_batch* b, int src, int dst, void* stream_)
     hipLaunchKernelGGL(k_copy_segments, dim3(32, nseg), dim3(256), 0, s, segs);      // one launch instead of 19 small copies
     LAUNCH_CHECK("k_copy_segments");
     b->slotValid[dst] = 1;
+    if (!b->bowValid.empty()) b->bowValid[dst] = 0;      // mBowVec / mFeatVec are recomputed on demand (ComputeBoW's `if(mBowVec.empty())`)
     return SD_OK;
 }
 

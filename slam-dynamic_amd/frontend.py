@@ -303,6 +303,27 @@ class Batch:
                                               C.c_void_p(d_occupied or 0), C.c_void_p(d_track), C.c_void_p(d_point_match),
                                               C.c_void_p(d_kp_match), C.c_void_p(d_nmatches), C.c_void_p(stream or 0)))
 
+    # -- Frame::ComputeBoW, ORBmatcher::SearchByBoW
+    def compute_bow(self, vocab, image_index, levelsup=4, stream=None):
+        ii = np.ascontiguousarray(image_index, np.int32)
+        check(lib().sd_batch_compute_bow(self.h, vocab.h, len(ii), _p(ii), levelsup, C.c_void_p(stream or 0)))
+
+    def download_bow(self, image):
+        """-> dict(word, value: the BowVector; fv_node, fv_feature: the flattened FeatureVector; f_word, f_weight, f_node: per feature)"""
+        cap = self.cap
+        bw = np.zeros(cap, np.uint32); bv = np.zeros(cap, np.float64); fn = np.zeros(cap, np.uint32); ff = np.zeros(cap, np.uint32)
+        fw = np.zeros(cap, np.uint32); fwt = np.zeros(cap, np.float64); fnd = np.zeros(cap, np.uint32)
+        nw, nf = C.c_int(), C.c_int()
+        check(lib().sd_batch_download_bow(self.h, image, _p(bw), _p(bv), C.byref(nw), _p(fn), _p(ff), C.byref(nf), _p(fw), _p(fwt), _p(fnd), cap))
+        n = int(self.counts(image + 1)[image])
+        return dict(word=bw[:nw.value].copy(), value=bv[:nw.value].copy(), fv_node=fn[:nf.value].copy(), fv_feature=ff[:nf.value].copy(),
+                    f_word=fw[:n].copy(), f_weight=fwt[:n].copy(), f_node=fnd[:n].copy())
+
+    def search_by_bow(self, kf_index, frame_index, nnratio, checkOrientation=True, d_kf_valid=None, stream=None):
+        ki = np.ascontiguousarray(kf_index, np.int32); fi = np.ascontiguousarray(frame_index, np.int32)
+        check(lib().sd_batch_search_by_bow(self.h, len(ki), _p(ki), _p(fi), C.c_void_p(d_kf_valid or 0), C.c_float(nnratio),
+                                           int(checkOrientation), C.c_void_p(stream or 0)))
+
     def copy_frame(self, src, dst, stream=None):
         check(lib().sd_batch_copy_frame(self.h, src, dst, C.c_void_p(stream or 0)))
 
@@ -487,3 +508,66 @@ def device_count():
     n = C.c_int()
     rc = lib().sd_device_count(C.byref(n))
     return n.value if rc == SD_OK else 0
+
+
+class Vocabulary:
+    """ORBVocabulary (DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>) as one packed buffer in HBM."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def load_text(cls, path):
+        h = C.c_void_p()
+        check(lib().sd_vocab_load_text(C.byref(h), str(path).encode()))
+        return cls(h)
+
+    @classmethod
+    def from_nodes(cls, voc):
+        """voc: dict(k, L, scoring, weighting, parent, is_leaf, desc, weight) = the node lines of the text file."""
+        h = C.c_void_p()
+        par = np.ascontiguousarray(voc["parent"], np.int32); leaf = np.ascontiguousarray(voc["is_leaf"], np.uint8)
+        d = np.ascontiguousarray(voc["desc"], np.uint8); w = np.ascontiguousarray(voc["weight"], np.float64)
+        check(lib().sd_vocab_from_nodes(C.byref(h), int(voc["k"]), int(voc["L"]), int(voc["scoring"]), int(voc["weighting"]), len(par),
+                                        _p(par), _p(leaf), _p(d), _p(w)))
+        return cls(h)
+
+    @classmethod
+    def from_packed_device(cls, d_ptr, nbytes):
+        h = C.c_void_p()
+        check(lib().sd_vocab_from_packed_device(C.byref(h), C.c_void_p(d_ptr), C.c_size_t(nbytes)))
+        return cls(h)
+
+    @staticmethod
+    def packed_bytes(n_nodes):
+        f = lib().sd_vocab_packed_bytes
+        f.restype = C.c_size_t
+        return int(f(int(n_nodes)))
+
+    def info(self):
+        v = [C.c_int() for _ in range(6)]
+        check(lib().sd_vocab_info(self.h, *[C.byref(x) for x in v]))
+        return dict(zip(("k", "L", "scoring", "weighting", "n_nodes", "n_words"), [x.value for x in v]))
+
+    def packed_device(self):
+        p = C.c_void_p(); n = C.c_size_t()
+        check(lib().sd_vocab_packed_device(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def nodes(self):
+        n = self.info()["n_nodes"]
+        par = np.zeros(n, np.int32); nch = np.zeros(n, np.int32); wid = np.zeros(n, np.int32)
+        d = np.zeros((n, 32), np.uint8); w = np.zeros(n, np.float64)
+        check(lib().sd_vocab_download_nodes(self.h, _p(par), _p(nch), _p(wid), _p(d), _p(w)))
+        return dict(parent=par, n_children=nch, word_id=wid, desc=d, weight=w)
+
+    def close(self):
+        if self.h:
+            lib().sd_vocab_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

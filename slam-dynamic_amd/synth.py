@@ -175,3 +175,50 @@ def random_image(width, height, seed, kind="texture"):
         return rng.integers(0, 256, (height, width), dtype=np.uint8)
     tex = base_texture(width, height, seq=seed % 97, margin=0)
     return np.ascontiguousarray(tex[:height, :width])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Synthetic ORB vocabulary in the shape of ORBvoc.txt (k = 10, L = 6, L1 scoring, TF-IDF weighting): the real
+# file is a download that never was in the reference repository.
+# ---------------------------------------------------------------------------------------------------------
+def vocabulary(k=10, L=3, seed=7, early_leaf_frac=0.02, stop_frac=0.01):
+    """Returns the content of the text file's node lines, in file order (parents before children):
+    dict(k, L, scoring, weighting, parent int32[n], is_leaf u8[n], desc u8[n, 32], weight f64[n]); node id = line + 1."""
+    rng = np.random.default_rng(seed)
+    parent, is_leaf, desc, weight = [], [], [], []
+    level_ids = np.array([0], np.int64)                      # node ids of the current level (root = 0)
+    level_desc = rng.integers(0, 256, (1, 32), dtype=np.uint8)
+    next_id = 1
+    for level in range(1, L + 1):
+        n_par = len(level_ids)
+        par = np.repeat(level_ids, k)
+        base = np.repeat(level_desc, k, axis=0)
+        nflip = max(4, 96 >> level)                          # children drift less from their parent further down
+        d = base.copy()
+        bits = rng.integers(0, 256, (len(d), nflip))
+        for j in range(nflip):
+            d[np.arange(len(d)), bits[:, j] >> 3] ^= (1 << (bits[:, j] & 7)).astype(np.uint8)
+        if level == 1:
+            d = rng.integers(0, 256, (len(d), 32), dtype=np.uint8)
+        leaf = np.ones(len(d), np.uint8) if level == L else (rng.random(len(d)) < early_leaf_frac).astype(np.uint8)
+        w = np.where(leaf > 0, rng.uniform(0.5, 9.0, len(d)), 0.0)
+        w = np.where((leaf > 0) & (rng.random(len(d)) < stop_frac), 0.0, w)
+        ids = next_id + np.arange(len(d), dtype=np.int64)
+        next_id += len(d)
+        parent.append(par.astype(np.int32)); is_leaf.append(leaf); desc.append(d); weight.append(w.astype(np.float64))
+        keep = leaf == 0
+        level_ids, level_desc = ids[keep], d[keep]
+        if len(level_ids) == 0:
+            break
+    return dict(k=k, L=L, scoring=0, weighting=0, parent=np.concatenate(parent), is_leaf=np.concatenate(is_leaf),
+                desc=np.concatenate(desc), weight=np.concatenate(weight))
+
+
+def write_vocabulary_text(voc, path):
+    """TemplatedVocabulary::saveToTextFile's format: header `k L scoring weighting`, then one line per node:
+    `parent isLeaf d0 .. d31 weight` (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1427-1458)."""
+    with open(path, "w") as f:
+        f.write("%d %d %d %d\n" % (voc["k"], voc["L"], voc["scoring"], voc["weighting"]))
+        for i in range(len(voc["parent"])):
+            f.write("%d %d %s %s\n" % (voc["parent"][i], voc["is_leaf"][i], " ".join(str(int(b)) for b in voc["desc"][i]),
+                                       repr(float(voc["weight"][i]))))
