@@ -17,7 +17,7 @@ i.e. per frame (reference call stack SURVEY 3.2, 3-argument TrackRGBD):
 
 Multi-GPU (driver launches one rank per GPU through torch.distributed.run): independent frames are
 sharded, every rank runs the same per-GPU batch (weak scaling), there is no data-path collective.
-Start-up: RCCL broadcast of the packed ORB vocabulary (synthetic k=10, L=6 tree, ~45 MB) from rank 0.
+Start-up: RCCL broadcast of the packed ORB vocabulary (synthetic k=10, L=6 tree, ~60 MB: sd_vocab) from rank 0; every rank adopts it.
 Per step: asynchronous gather (to rank 0) of the fixed-stride per-frame result records, overlapped with the next step.  value = frames of ALL ranks / max
 rank time.
 
@@ -168,7 +168,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="frames per step per GPU")
-    ap.add_argument("--workload", choices=["rgbd", "stereo", "rgbd-cull"], default="rgbd")
+    ap.add_argument("--workload", choices=["rgbd", "stereo", "rgbd-cull", "rgbd-bow"], default="rgbd")
     ap.add_argument("--cpu-frames", type=int, default=320, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents")
     ap.add_argument("--streams", type=int, default=1,
@@ -208,7 +208,8 @@ def main():
         raise SystemExit("--batch must be a multiple of --streams")
     Bs = B // S
     cull = args.workload == "rgbd-cull"
-    if cull:
+    bow = args.workload == "rgbd-bow"
+    if cull or bow:
         args.workload = "rgbd"
     if args.workload == "rgbd":
         cfg = synth.KITTI03_RGBD
@@ -216,6 +217,9 @@ def main():
         if cull:
             workload_name = ("RGB-D 1241x376, 2000 feat/frame, extract + match + dynamic cull with 3 given boxes/frame "
                              "(firstSeparate, Separate vs the frame 0.2 s back, UpdateFrame); detector off (BASELINE configs[3] data path)")
+        if bow:
+            workload_name = ("RGB-D 1241x376, 2000 feat/frame, extract + projection match + Frame::ComputeBoW (k=10, L=6 vocabulary) + "
+                             "SearchByBoW against the previous frame (TrackReferenceKeyFrame's matcher)")
         imgs_per_frame, th = 1, 15.0
     else:
         cfg = synth.KITTI_STEREO
@@ -235,20 +239,29 @@ def main():
         d_gray = torch.from_numpy(np.stack([im for f in fr for im in (f[0], f[1])])).to(dev)
     del fr
 
-    # ---- start-up collective: packed ORB vocabulary (k=10, L=6 -> 1,111,111 nodes x 41 B), rank 0 -> all (RCCL)
-    voc_bytes = 1111111 * (32 + 4 + 4 + 1)
+    # ---- start-up collective: the packed ORB vocabulary (synthetic k=10, L=6 tree in ORBvoc.txt's shape; the real file
+    # is a download that never was in the reference), rank 0 -> all over RCCL; every rank adopts the received buffer
+    # (sd_vocab_from_packed_device) and Frame::ComputeBoW / SearchByBoW read it from HBM.
     voc_ms = None
     if rank == 0:
-        g = torch.Generator(device=dev); g.manual_seed(1234)
-        voc = torch.randint(0, 256, (voc_bytes,), dtype=torch.uint8, device=dev, generator=g)
+        voc0 = fe.Vocabulary.from_nodes(synth.vocabulary(k=10, L=6, seed=1234))
+        vptr, voc_bytes = voc0.packed_device()
+        n_nodes_t = torch.tensor([voc0.info()["n_nodes"]], dtype=torch.int64, device=dev)
     else:
-        voc = torch.empty((voc_bytes,), dtype=torch.uint8, device=dev)
+        n_nodes_t = torch.zeros(1, dtype=torch.int64, device=dev)
     if dist is not None:
+        dist.broadcast(n_nodes_t, src=0)
+        voc_bytes = fe.Vocabulary.packed_bytes(int(n_nodes_t.item()))
+        voc_buf = fe.as_torch_u8(vptr, voc_bytes) if rank == 0 else torch.empty((voc_bytes,), dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        dist.broadcast(voc, src=0)
+        dist.broadcast(voc_buf, src=0)
         torch.cuda.synchronize()
         voc_ms = (time.perf_counter() - t0) * 1e3
+        vocab = voc0 if rank == 0 else fe.Vocabulary.from_packed_device(voc_buf.data_ptr(), voc_bytes)
+    else:
+        vocab = voc0
+    assert vocab.info()["n_nodes"] == int(n_nodes_t.item()) and vocab.info()["k"] == 10 and vocab.info()["L"] == 6
 
     ex = fe.ORBextractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
     n_img = Bs * imgs_per_frame                     # images per stream
@@ -314,6 +327,9 @@ def main():
             bt.separate(cs["cur"], cs["ref"], cs["H"], cs["flag"], None, None, stream=st, packed_last=cs["last"])
             bt.update_frame(True, st)
             bt.assign_grid(n_img, cam, st)                       # UpdateFeaturesToGrid
+        if bow:
+            bt.compute_bow(vocab, cur_idx, 4, st)
+            bt.search_by_bow(cur_idx[:-1], cur_idx[1:], 0.7, True, stream=st)
         bt.copy_frame(int(cur_idx[-1]), n_img, st)
 
     def step(first=False):
@@ -362,7 +378,7 @@ def main():
                 a, c = kt.get(k, (0.0, 0))
                 kt[k] = (a + ms, c + n)
     counts = batch.counts(n_img)
-    m, pairs, nm = batch.download_matches(Bs - 1)
+    m, pairs, nm = batch.download_matches(Bs - 2 if bow else Bs - 1)      # rgbd-bow: the last SearchByBoW pair
 
     if rank == 0:
         total_frames = world * B * args.steps
@@ -403,11 +419,16 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload_name, "frames_per_step_per_gpu": B, "images_per_frame": imgs_per_frame,
-                       "features_per_image": int(np.mean(counts)), "projection_matches_last_pair": int(nm),
+                       "features_per_image": int(np.mean(counts)), ("bow_matches_last_pair" if bow else "projection_matches_last_pair"): int(nm),
                        "sharding": "independent frame batches per rank, no data-path collective; per-step async gather of results to rank 0"
                        if world > 1 else "single GPU"},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        # the broadcast vocabulary's consumer, outside the timed region: Frame::ComputeBoW of frame 0
+        batch.compute_bow(vocab, [0], 4)
+        b0 = batch.download_bow(0)
+        out["vocabulary"] = {"nodes": vocab.info()["n_nodes"], "words": vocab.info()["n_words"], "packed_bytes": int(voc_bytes),
+                             "frame0_bow_words": int(len(b0["word"])), "frame0_feature_vector_nodes": int(len(np.unique(b0["fv_node"])))}
         if voc_ms is not None:
             out["vocabulary_broadcast_ms"] = round(voc_ms, 3)
         print(json.dumps(out))

@@ -178,34 +178,40 @@ __global__ void __launch_bounds__(256) k_bow_finalize(const int* __restrict__ co
                 r++;
             }
         }
+        __threadfence_block();
+        __syncthreads();
+        double* vals = (double*)keys;                          // the sorted keys are dead: stage the values for the serial sum
+        for (int t = tid; t < nb; t += 256) vals[t] = bowVal[base + t];
         __syncthreads();
         const bool must = scoring != 5;
         if ((weighting == 0 || weighting == 1) && nb > 0 && !must) {
             const double nd = (double)nb;
-            for (int t = tid; t < nb; t += 256) bowVal[base + t] /= nd;
+            for (int t = tid; t < nb; t += 256) vals[t] /= nd;
         }
-        __threadfence_block();
         __syncthreads();
         if (must) {
             if (tid == 0) {
                 double norm = 0.0;
-                if (scoring != 1) { for (int t = 0; t < nb; t++) norm += fabs(bowVal[base + t]); }
-                else { for (int t = 0; t < nb; t++) norm += bowVal[base + t] * bowVal[base + t]; norm = sqrt(norm); }
+                if (scoring != 1) { for (int t = 0; t < nb; t++) norm += fabs(vals[t]); }
+                else { for (int t = 0; t < nb; t++) norm += vals[t] * vals[t]; norm = sqrt(norm); }
                 s_norm = norm;
             }
             __syncthreads();
             const double norm = s_norm;
-            if (norm > 0.0) for (int t = tid; t < nb; t += 256) bowVal[base + t] /= norm;
+            if (norm > 0.0) for (int t = tid; t < nb; t += 256) vals[t] /= norm;
         }
+        for (int t = tid; t < nb; t += 256) bowVal[base + t] = vals[t];
         if (tid == 0) meta[img * 4 + 2] = nb;
     }
 }
 
-// One workgroup per (keyframe, frame) pair; a wave takes the vocabulary nodes both FeatureVectors share.  A frame feature
+#define SD_BOW_REGF 128          // frame features of a node that the register path holds (two per lane)
+// One workgroup per (keyframe, frame) pair; a wave takes a vocabulary node both FeatureVectors share.  A frame feature
 // belongs to exactly one node, so waves never contend for a keypoint; inside a node the keyframe features are walked in
 // order (the order that decides which frame keypoints are already taken, ORBmatcher.cc:206-207).  Best / second best over
 // the not-yet-taken frame features = first and second entry of the (distance, position) order (see k_local_resolve).
-__global__ void __launch_bounds__(256) k_search_by_bow(
+#define SD_BOW_WAVES 16
+__global__ void __launch_bounds__(64 * SD_BOW_WAVES) k_search_by_bow(
     const sd_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc, const int* __restrict__ count,
     const unsigned* __restrict__ fvFeat, const int* __restrict__ fvRunStart, const unsigned* __restrict__ fvRunNode,
     const int* __restrict__ meta, const uint8_t* __restrict__ kfValid /*nullable [pair][cap]*/, const int2* __restrict__ pairIdx,
@@ -220,7 +226,7 @@ __global__ void __launch_bounds__(256) k_search_by_bow(
     const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int imgK = pairIdx[pair].x, imgF = pairIdx[pair].y;
     const int NF = count[imgF];
-    for (int i = tid; i < NF; i += 256) s_match[i] = -1;
+    for (int i = tid; i < NF; i += 64 * SD_BOW_WAVES) s_match[i] = -1;
     if (tid < SD_HISTO) s_hist[tid] = 0;
     if (tid == 0) s_nm = 0;
     __syncthreads();
@@ -237,12 +243,88 @@ __global__ void __launch_bounds__(256) k_search_by_bow(
     const sd_keypoint* kF = kp + (size_t)imgF * cap;
     const float factor = 1.0f / SD_HISTO;
     int nm = 0;
-    for (int rk = wv; rk < runsK; rk += 4) {
+    // ---- nodes with up to 128 frame features (the usual case: ~20 x 20 features at level L - 4): the wave keeps the node's
+    // frame descriptors in registers (lane l owns positions l and l + 64, and with them their taken flags), gathers the
+    // keyframe descriptors 64 at a time and broadcasts one per step by shuffles: no memory access inside the serial loop.
+    for (int rk = wv; rk < runsK; rk += SD_BOW_WAVES) {
         const unsigned node = rnK[rk];
         int lo = 0, hi = runsF;                               // lower_bound of node in the frame's runs
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (rnF[mid] < node) lo = mid + 1; else hi = mid; }
         if (lo >= runsF || rnF[lo] != node) continue;
         const int a0 = rsK[rk], a1 = rsK[rk + 1], c0 = rsF[lo], c1 = rsF[lo + 1];
+        if (c1 - c0 > SD_BOW_REGF) continue;                  // left to the generic path below
+        unsigned iFl[2]; uint4 f0[2], f1[2]; bool freeF[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int c = c0 + lane + 64 * q;
+            freeF[q] = c < c1;
+            iFl[q] = freeF[q] ? ffF[c] : 0u;
+            const uint4* pf = (const uint4*)(dF + (size_t)iFl[q] * 32);
+            f0[q] = pf[0]; f1[q] = pf[1];
+        }
+        for (int kb = a0; kb < a1; kb += 64) {
+            const int a = kb + lane;
+            const unsigned iKl = a < a1 ? ffK[a] : 0u;
+            const int validK = a < a1 && (!kfValid || kfValid[(size_t)pair * cap + iKl]);
+            const uint4* pk = (const uint4*)(dK + (size_t)iKl * 32);
+            const uint4 kl0 = pk[0], kl1 = pk[1];
+            const float angK = kK[iKl].angle;
+            const int nstep = a1 - kb < 64 ? a1 - kb : 64;
+            for (int t = 0; t < nstep; t++) {
+                if (!__builtin_amdgcn_readlane(validK, t)) continue;
+                uint4 k0, k1;                                  // t is wave-uniform: v_readlane, no LDS crossbar
+                k0.x = (unsigned)__builtin_amdgcn_readlane((int)kl0.x, t); k0.y = (unsigned)__builtin_amdgcn_readlane((int)kl0.y, t);
+                k0.z = (unsigned)__builtin_amdgcn_readlane((int)kl0.z, t); k0.w = (unsigned)__builtin_amdgcn_readlane((int)kl0.w, t);
+                k1.x = (unsigned)__builtin_amdgcn_readlane((int)kl1.x, t); k1.y = (unsigned)__builtin_amdgcn_readlane((int)kl1.y, t);
+                k1.z = (unsigned)__builtin_amdgcn_readlane((int)kl1.z, t); k1.w = (unsigned)__builtin_amdgcn_readlane((int)kl1.w, t);
+                unsigned key[2];
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+                    key[q] = freeF[q] ? (((unsigned)sd_hamming256(k0, k1, f0[q], f1[q]) << 16) | (unsigned)(lane + 64 * q)) : 0xFFFFFFFFu;
+                // one butterfly for the smallest and the second smallest key (keys are unique: position in the low bits)
+                unsigned b1 = key[0] < key[1] ? key[0] : key[1];
+                unsigned b2 = key[0] < key[1] ? key[1] : key[0];
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) {
+                    const unsigned o1 = (unsigned)__shfl_xor((int)b1, d, 64), o2 = (unsigned)__shfl_xor((int)b2, d, 64);
+                    const unsigned hi1 = b1 > o1 ? b1 : o1, lo2 = b2 < o2 ? b2 : o2;
+                    b1 = b1 < o1 ? b1 : o1;
+                    b2 = hi1 < lo2 ? hi1 : lo2;
+                }
+                if (b1 == 0xFFFFFFFFu) continue;
+                const int bestDist1 = (int)(b1 >> 16), bestDist2 = b2 == 0xFFFFFFFFu ? 256 : (int)(b2 >> 16);
+                if (bestDist1 <= SD_TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) {
+                    const int pos = (int)(b1 & 0xFFFFu);
+                    const unsigned iKt = (unsigned)__builtin_amdgcn_readlane((int)iKl, t);
+                    const float aK = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(angK), t));
+                    if ((pos & 63) == lane) {
+                        const int q = pos >> 6;
+                        const unsigned iF = q ? iFl[1] : iFl[0];
+                        if (q) freeF[1] = false; else freeF[0] = false;
+                        s_match[iF] = (int)iKt;
+                        int bin = 0;
+                        if (checkOrientation) {
+                            float rot = aK - kF[iF].angle;
+                            if (rot < 0.0f) rot += 360.0f;
+                            bin = (int)roundf(rot * factor);
+                            if (bin == SD_HISTO) bin = 0;
+                            atomicAdd(&s_hist[bin], 1);
+                        }
+                        s_bin[iF] = (uint8_t)bin;
+                    }
+                    nm++;
+                }
+            }
+        }
+    }
+    // ---- nodes with more frame features than the registers hold: a wave per node, lanes over the frame's features, from memory
+    for (int rk = wv; rk < runsK; rk += SD_BOW_WAVES) {
+        const unsigned node = rnK[rk];
+        int lo = 0, hi = runsF;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (rnF[mid] < node) lo = mid + 1; else hi = mid; }
+        if (lo >= runsF || rnF[lo] != node) continue;
+        const int a0 = rsK[rk], a1 = rsK[rk + 1], c0 = rsF[lo], c1 = rsF[lo + 1];
+        if (c1 - c0 <= SD_BOW_REGF) continue;
         for (int a = a0; a < a1; a++) {
             const unsigned iK = ffK[a];
             if (kfValid && !kfValid[(size_t)pair * cap + iK]) continue;
@@ -309,11 +391,11 @@ __global__ void __launch_bounds__(256) k_search_by_bow(
         __syncthreads();
         const int i1 = s_ind[0], i2 = s_ind[1], i3 = s_ind[2];
         int culled = 0;
-        for (int i = tid; i < NF; i += 256)
+        for (int i = tid; i < NF; i += 64 * SD_BOW_WAVES)
             if (s_match[i] >= 0) { const int b = s_bin[i]; if (b != i1 && b != i2 && b != i3) { s_match[i] = -1; culled++; } }
         if (culled) atomicSub(&s_nm, culled);
         __syncthreads();
     }
-    for (int i = tid; i < NF; i += 256) matchOut[(size_t)pair * cap + i] = s_match[i];
+    for (int i = tid; i < NF; i += 64 * SD_BOW_WAVES) matchOut[(size_t)pair * cap + i] = s_match[i];
     if (tid == 0) nmatchOut[pair] = s_nm;
 }

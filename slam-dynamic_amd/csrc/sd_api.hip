@@ -1219,7 +1219,7 @@ int sd_batch_search_by_bow(sd_batch* b, int n_pairs, const int32_t* kf_index, co
     {
         ProfScope ps(b, s, K_BOW_S);
         const size_t lds = (size_t)cap * 4 + cap + 16;
-        hipLaunchKernelGGL(k_search_by_bow, dim3(n_pairs), dim3(256), lds, s, b->d_kp, b->d_desc, b->d_count, b->d_fvFeat, b->d_fvRunStart, b->d_fvRunNode,
+        hipLaunchKernelGGL(k_search_by_bow, dim3(n_pairs), dim3(64 * SD_BOW_WAVES), lds, s, b->d_kp, b->d_desc, b->d_count, b->d_fvFeat, b->d_fvRunStart, b->d_fvRunNode,
                            b->d_bowMeta, d_kf_valid, b->d_pairIdx, cap, nnratio, checkOrientation, b->d_match, b->d_nmatch);
         LAUNCH_CHECK("k_search_by_bow");
     }
