@@ -218,6 +218,16 @@ int sd_batch_download_bow(sd_batch* b, int image, uint32_t* bow_word, double* bo
 int sd_batch_search_by_bow(sd_batch* b, int n_pairs, const int32_t* kf_index, const int32_t* frame_index,
                            const uint8_t* d_kf_valid, float nnratio, int checkOrientation, void* stream);
 
+/* The model fit of Tracking::TrackHomo (src/Tracking.cc:1026-1075) for every pair of the preceding
+ * sd_batch_search_by_projection, from its points_last / points_current: replaces cv::findHomography(points_last,
+ * points_current, RANSAC, 3, inliers_H), cv::findFundamentalMat(..., RANSAC, 3, 0.99, inliers_F), the inlier counts
+ * and the choice `n_H > n_F ? (H, return 1) : (F, return 2)` when either count exceeds 10 (else 0).  The estimator is
+ * this library's own specification (OpenCV's cannot be matched bit for bit without OpenCV); HorF / flag
+ * are what sd_batch_separate takes.  Masks are indexed like the pair list of sd_batch_download_matches. */
+int sd_batch_estimate_motion(sd_batch* b, void* stream);
+int sd_batch_download_motion(sd_batch* b, int pair, double* H, double* F, uint8_t* mask_h, uint8_t* mask_f, int cap,
+                             int* n_points, int* n_h, int* n_f, float* HorF, int* flag);
+
 /* Frame copy constructor (src/Frame.cc:39-63), as in `mLastFrame = Frame(mCurrentFrame)`: copies the frame
  * results of slot src (keypoints, descriptors, mvuRight/mvDepth, grid cells, map-point table) to slot dst. */
 int sd_batch_copy_frame(sd_batch* b, int src, int dst, void* stream);

@@ -381,3 +381,15 @@ def search_by_bow(kpKF, descKF, kf_valid, bowKF, kpF, descF, bowF, nnratio, chec
     nm = f(_p(kpKF), _p(dK), _p(val), _p(nK), _p(fK), len(nK), _p(kpF), _p(dF), len(kpF), _p(nF), _p(fF), len(nF), C.c_float(nnratio),
            int(checkOrientation), _p(match))
     return match, nm
+
+
+def estimate_motion(points_last, points_current):
+    """The H / F fit of Tracking::TrackHomo (spec Q13) -> dict(H, F, mask_h, mask_f, n_h, n_f, HorF, flag)."""
+    p1 = np.ascontiguousarray(points_last, np.float32).reshape(-1, 2); p2 = np.ascontiguousarray(points_current, np.float32).reshape(-1, 2)
+    N = len(p1)
+    H = np.zeros(9, np.float64); F = np.zeros(9, np.float64); mh = np.zeros(max(N, 1), np.uint8); mf = np.zeros(max(N, 1), np.uint8)
+    nh, nf = C.c_int(), C.c_int(); hf = np.zeros(9, np.float32)
+    f = lib().orc_estimate_motion
+    f.restype = C.c_int
+    flag = f(_p(p1), _p(p2), N, _p(H), _p(F), _p(mh), _p(mf), C.byref(nh), C.byref(nf), _p(hf))
+    return dict(H=H.reshape(3, 3), F=F.reshape(3, 3), mask_h=mh[:N], mask_f=mf[:N], n_h=nh.value, n_f=nf.value, HorF=hf.reshape(3, 3), flag=flag)

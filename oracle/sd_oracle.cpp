@@ -639,5 +639,6 @@ int orc_stereo_matches(void* hL, void* hR, const void* kL_, const uint8_t* dL, i
 #include "frame_oracle.inc"
 #include "cull_oracle.inc"
 #include "bow_oracle.inc"
+#include "motion_oracle.inc"
 
 } // extern "C"

@@ -13,6 +13,7 @@
 #include "k_cull.h"
 #include "sd_yolo.h"
 #include "sd_vocab.h"
+#include "k_motion.h"
 
 static thread_local std::string g_err;
 static int set_err(int code, const std::string& msg) { g_err = msg; return code; }
@@ -29,11 +30,11 @@ struct sd_extractor {
     SdParams prm;
 };
 
-enum KernelId { K_PYR0, K_PYR, K_FAST, K_QTREE, K_ORIENT, K_BLUR, K_DESC, K_STEREO, K_STEREO_F, K_RGBD, K_GRID, K_UNPROJ, K_PROJ_A, K_PROJ_B, K_BOXSEP, K_SEPARATE, K_UPDATE, K_LOCAL_A, K_LOCAL_B, K_BOW_T, K_BOW_F, K_BOW_S, K_COUNT };
+enum KernelId { K_PYR0, K_PYR, K_FAST, K_QTREE, K_ORIENT, K_BLUR, K_DESC, K_STEREO, K_STEREO_F, K_RGBD, K_GRID, K_UNPROJ, K_PROJ_A, K_PROJ_B, K_BOXSEP, K_SEPARATE, K_UPDATE, K_LOCAL_A, K_LOCAL_B, K_BOW_T, K_BOW_F, K_BOW_S, K_MOTION_P, K_MOTION_H, K_MOTION_S, K_COUNT };
 static const char* kKernelNames[K_COUNT] = {"k_pyr_level0", "k_pyr_level", "k_fast_cells", "k_quadtree", "k_orient",
                                             "k_blur", "k_describe", "k_stereo_match", "k_stereo_filter", "k_rgbd",
                                             "k_grid_cells", "k_unproject", "k_proj_candidates", "k_proj_resolve",
-                                            "k_box_separate", "k_separate", "k_update_frame", "k_local_candidates", "k_local_resolve", "k_bow_transform", "k_bow_finalize", "k_search_by_bow"};
+                                            "k_box_separate", "k_separate", "k_update_frame", "k_local_candidates", "k_local_resolve", "k_bow_transform", "k_bow_finalize", "k_search_by_bow", "k_motion_prepare", "k_motion_hyp", "k_motion_select"};
 
 struct sd_batch {
     sd_extractor* ex = nullptr;
@@ -81,6 +82,8 @@ struct sd_batch {
     unsigned* d_bowWordF = nullptr; double* d_bowWF = nullptr; unsigned* d_bowNidF = nullptr; unsigned* d_fvNode = nullptr; unsigned* d_fvFeat = nullptr;
     int* d_fvRunStart = nullptr; unsigned* d_fvRunNode = nullptr; unsigned* d_bowWord = nullptr; double* d_bowVal = nullptr; int* d_bowMeta = nullptr;
     int* d_bowImg = nullptr; std::vector<uint8_t> bowValid;
+    float* d_moPts = nullptr; SdMotionNorm* d_moNorm = nullptr; int* d_moCounts = nullptr; uint8_t* d_moMaskH = nullptr; uint8_t* d_moMaskF = nullptr;
+    SdMotionResult* d_moRes = nullptr; int nMotion = 0;      // TrackHomo model fit
     unsigned* d_lmCand = nullptr; uint8_t* d_lmN = nullptr; uint8_t* d_lmOvf = nullptr; int* d_lmIdx = nullptr; int lmCap = 0;   // local-map search scratch
     int* d_match = nullptr;
     int* d_pairs = nullptr;
@@ -213,7 +216,8 @@ static void batch_free(sd_batch* b)
                     b->d_lastIdx, b->d_lastStatus, b->d_nLast, b->d_dynStart, b->d_dynStatus, b->d_sepMatches, b->d_sepRet,
                     b->d_sepPairs, b->d_kpD, b->d_descD, b->d_urD, b->d_depD, b->d_rowIdx, b->d_rowStart,
                     b->d_lmCand, b->d_lmN, b->d_lmOvf, b->d_lmIdx, b->d_bowWordF, b->d_bowWF, b->d_bowNidF, b->d_fvNode, b->d_fvFeat,
-                    b->d_fvRunStart, b->d_fvRunNode, b->d_bowWord, b->d_bowVal, b->d_bowMeta, b->d_bowImg};
+                    b->d_fvRunStart, b->d_fvRunNode, b->d_bowWord, b->d_bowVal, b->d_bowMeta, b->d_bowImg,
+                    b->d_moPts, b->d_moNorm, b->d_moCounts, b->d_moMaskH, b->d_moMaskF, b->d_moRes};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& r : b->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : b->pool) (void)hipEventDestroy(e);
@@ -1224,6 +1228,61 @@ int sd_batch_search_by_bow(sd_batch* b, int n_pairs, const int32_t* kf_index, co
         LAUNCH_CHECK("k_search_by_bow");
     }
     b->nPairs = n_pairs;
+    return SD_OK;
+}
+
+// The model fit of Tracking::TrackHomo (src/Tracking.cc:1026-1075) for every pair of the preceding
+// sd_batch_search_by_projection: points_last / points_current -> H, F, inlier masks, the choice 1 (H) / 2 (F) / 0.
+int sd_batch_estimate_motion(sd_batch* b, void* stream_)
+{
+    if (!b) return set_err(SD_ERR_INVALID, "null batch");
+    const int n_pairs = b->nPairs;
+    b->nMotion = 0;
+    if (n_pairs <= 0) return set_err(SD_ERR_STATE, "estimate_motion: no preceding sd_batch_search_by_projection");
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
+    b->lastStream = s;
+    const size_t nI = b->maxImages, cap = b->plan.kpCap;
+    if (!b->d_moPts) {
+        HIPCHK(hipMalloc((void**)&b->d_moPts, nI * cap * 16)); HIPCHK(hipMalloc((void**)&b->d_moNorm, nI * sizeof(SdMotionNorm)));
+        HIPCHK(hipMalloc((void**)&b->d_moCounts, nI * SD_MOTION_K * 4)); HIPCHK(hipMalloc((void**)&b->d_moMaskH, nI * cap));
+        HIPCHK(hipMalloc((void**)&b->d_moMaskF, nI * cap)); HIPCHK(hipMalloc((void**)&b->d_moRes, nI * sizeof(SdMotionResult)));
+    }
+    {
+        ProfScope ps(b, s, K_MOTION_P);
+        hipLaunchKernelGGL(k_motion_prepare, dim3(n_pairs), dim3(256), 0, s, b->d_kp, b->d_pairs, b->d_npairs, b->d_pairIdx, (int)cap, b->d_moPts, b->d_moNorm);
+        LAUNCH_CHECK("k_motion_prepare");
+    }
+    {
+        ProfScope ps(b, s, K_MOTION_H);
+        hipLaunchKernelGGL(k_motion_hyp, dim3(SD_MOTION_K / 256, n_pairs), dim3(256), cap * 16, s, b->d_moPts, b->d_moNorm, (int)cap, b->d_moCounts);
+        LAUNCH_CHECK("k_motion_hyp");
+    }
+    {
+        ProfScope ps(b, s, K_MOTION_S);
+        hipLaunchKernelGGL(k_motion_select, dim3(n_pairs), dim3(256), 0, s, b->d_moPts, b->d_moNorm, b->d_moCounts, (int)cap, b->d_moMaskH, b->d_moMaskF, b->d_moRes);
+        LAUNCH_CHECK("k_motion_select");
+    }
+    b->nMotion = n_pairs;
+    return SD_OK;
+}
+
+int sd_batch_download_motion(sd_batch* b, int pair, double* H, double* F, uint8_t* mask_h, uint8_t* mask_f, int cap, int* n_points,
+                             int* n_h, int* n_f, float* HorF, int* flag)
+{
+    if (!b || pair < 0 || pair >= b->nMotion) return SD_ERR_INVALID;
+    int rc = sd_batch_sync(b);
+    if (rc != SD_OK) return rc;
+    SdMotionResult r;
+    HIPCHK(hipMemcpy(&r, b->d_moRes + pair, sizeof(r), hipMemcpyDeviceToHost));
+    int np = 0;
+    HIPCHK(hipMemcpy(&np, b->d_npairs + pair, 4, hipMemcpyDeviceToHost));
+    if (np > cap && (mask_h || mask_f)) return set_err(SD_ERR_CAPACITY, "mask buffer too small");
+    if (H) memcpy(H, r.H, sizeof(r.H)); if (F) memcpy(F, r.F, sizeof(r.F)); if (HorF) memcpy(HorF, r.HorF, sizeof(r.HorF));
+    if (n_h) *n_h = r.nH; if (n_f) *n_f = r.nF; if (flag) *flag = r.flag; if (n_points) *n_points = np;
+    if (np > 0) {
+        if (mask_h) HIPCHK(hipMemcpy(mask_h, b->d_moMaskH + (size_t)pair * b->plan.kpCap, np, hipMemcpyDeviceToHost));
+        if (mask_f) HIPCHK(hipMemcpy(mask_f, b->d_moMaskF + (size_t)pair * b->plan.kpCap, np, hipMemcpyDeviceToHost));
+    }
     return SD_OK;
 }
 

@@ -324,6 +324,18 @@ class Batch:
         check(lib().sd_batch_search_by_bow(self.h, len(ki), _p(ki), _p(fi), C.c_void_p(d_kf_valid or 0), C.c_float(nnratio),
                                            int(checkOrientation), C.c_void_p(stream or 0)))
 
+    # -- Tracking::TrackHomo model fit (H / F from the projection matcher's point pairs)
+    def estimate_motion(self, stream=None):
+        check(lib().sd_batch_estimate_motion(self.h, C.c_void_p(stream or 0)))
+
+    def download_motion(self, pair):
+        H = np.zeros(9, np.float64); F = np.zeros(9, np.float64); mh = np.zeros(self.cap, np.uint8); mf = np.zeros(self.cap, np.uint8)
+        n, nh, nf, flag = C.c_int(), C.c_int(), C.c_int(), C.c_int(); hf = np.zeros(9, np.float32)
+        check(lib().sd_batch_download_motion(self.h, pair, _p(H), _p(F), _p(mh), _p(mf), self.cap, C.byref(n), C.byref(nh), C.byref(nf),
+                                             _p(hf), C.byref(flag)))
+        return dict(H=H.reshape(3, 3), F=F.reshape(3, 3), mask_h=mh[:n.value].copy(), mask_f=mf[:n.value].copy(), n_h=nh.value, n_f=nf.value,
+                    HorF=hf.reshape(3, 3), flag=flag.value)
+
     def copy_frame(self, src, dst, stream=None):
         check(lib().sd_batch_copy_frame(self.h, src, dst, C.c_void_p(stream or 0)))
 

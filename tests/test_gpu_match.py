@@ -110,3 +110,40 @@ def test_copy_frame_then_match(seq, fe, orc):
     m1, p1, n1 = b.download_matches(0)
     assert n0 == n1 and n0 > 50 and np.array_equal(m0, m1) and np.array_equal(p0, p1)
     # restore slot 7 for other tests in this module is not needed: the fixture is read-only elsewhere
+
+
+def test_reprojection_residuals_match_to_1e5(seq, fe, orc):
+    """SURVEY §8a row 28: for a fixed pose and fixed matches the pose-only residuals of Optimizer::PoseOptimization
+    (Optimizer.cc:239-451; stereo edge: e = (u, v, uR) - (fx X/Z + cx, fy Y/Z + cy, u - bf/Z), chi2 = e^T e * invSigma2[octave])
+    computed from the GPU's keypoints / mvuRight equal those computed from the oracle's to 1e-5 (north-star tolerance)."""
+    b, T, cam, cfg = seq["b"], seq["T"], seq["cam"], seq["cfg"]
+    cam10 = fe.camera_array(cam)
+    I = np.eye(4, dtype=np.float32)
+    b.unproject(2, T, cam, np.tile(I, (T, 1, 1)))
+    b.search_by_projection([2], [0], I[None], I[None], cam, 15.0)
+    m, pairs, nm = b.download_matches(0)
+    assert nm > 100
+    cur, last = seq["ref"][1], seq["ref"][0]
+    xw_o, valid_o = orc.unproject(last["kp"], last["depth"], cam10, I)
+    xw_g, _ = b.download_mappoints(0)
+    kp_g, _, _ = b.download(2)
+    ur_g, _, _ = b.download_stereo(1)
+    inv_sigma2 = 1.0 / (np.float32(cfg["scale_factor"]) ** (2 * np.arange(cfg["n_levels"]))).astype(np.float64)
+    fx, fy, cx, cy, bf = [float(cfg[k]) for k in ("fx", "fy", "cx", "cy", "bf")]
+
+    def residuals(kp, ur, xw):
+        out = []
+        for i, i2 in pairs:
+            X, Y, Z = [float(v) for v in xw[i]]
+            u = fx * X / Z + cx; v = fy * Y / Z + cy
+            e = [float(kp["x"][i2]) - u, float(kp["y"][i2]) - v]
+            if ur[i2] > 0:
+                e.append(float(ur[i2]) - (u - bf / Z))
+            out.append((e + [0.0])[:3] + [sum(x * x for x in e) * inv_sigma2[int(kp["octave"][i2])]])
+        return np.array(out)
+
+    rg = residuals(kp_g, ur_g, xw_g)
+    ro = residuals(cur["kp"], cur["ur"], xw_o)
+    assert rg.shape == ro.shape and len(rg) == len(pairs)
+    assert np.max(np.abs(rg - ro)) <= 1e-5
+    assert np.array_equal(rg, ro)            # in fact identical: the inputs are bit-identical
