@@ -333,6 +333,15 @@ int sd_yolo_mask_device(sd_yolo* y, int image, int frame_cols, int frame_rows, f
                         uint8_t* d_mask, size_t stride, int* no_target, void* stream);
 int sd_yolo_boxes(sd_yolo* y, int image, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold, double* boxes,
                   int32_t* class_ids, float* confidences, int cap, int* n);
+/* The same post-processing for the first n_images of the last forward pass on the device (sort by score, greedy NMS,
+ * class filter, rectCenterScale): boxes [n_images][SD_MAX_BOXES][4] f64 (x, y, w, h), class ids / confidences
+ * [n_images][SD_MAX_BOXES], n_boxes[n_images].  _device writes device buffers and does not synchronise; _batch also
+ * downloads (one synchronisation for the whole batch).  More than 4096 rows above the threshold or more than
+ * SD_MAX_BOXES kept boxes in an image -> SD_ERR_CAPACITY (use the per-image host form). */
+int sd_yolo_boxes_device(sd_yolo* y, int n_images, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold,
+                         double* d_boxes, int32_t* d_class_ids, float* d_confidences, int32_t* d_n_boxes, void* stream);
+int sd_yolo_boxes_batch(sd_yolo* y, int n_images, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold,
+                        double* boxes, int32_t* class_ids, float* confidences, int32_t* n_boxes, void* stream);
 
 /* ---- Tracking::GrabImage* preprocessing (src/Tracking.cc:170-343) ---- */
 /* cvtColor(RGB|BGR|RGBA|BGRA -> GRAY); rgb_order = Camera.RGB.  channels 3 or 4. */

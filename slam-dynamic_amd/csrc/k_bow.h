@@ -67,23 +67,6 @@ __global__ void __launch_bounds__(256) k_bow_transform(const uint8_t* __restrict
     if (act && sub == 0) { wordOut[o] = (unsigned)V.wordId[node]; weightOut[o] = V.weight[node]; nidOut[o] = nid; }
 }
 
-// ascending bitonic sort of n (power of two) 64-bit keys in LDS by one workgroup
-__device__ __forceinline__ void sd_block_sort64(unsigned long long* keys, int n, int tid, int nthreads)
-{
-    for (int k = 2; k <= n; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < n; t += nthreads) {
-                const int p = t ^ j;
-                if (p > t) {
-                    const unsigned long long a = keys[t], b = keys[p];
-                    const bool up = (t & k) == 0;
-                    if ((a > b) == up) { keys[t] = b; keys[p] = a; }
-                }
-            }
-            __syncthreads();
-        }
-}
-
 // One workgroup per image.  FeatureVector = the features with weight > 0 sorted by (node id, feature index), + its runs;
 // BowVector = the distinct words ascending; a word seen c times holds ((w + w) + ...) summed c times in feature order (all
 // terms are the word's own weight) for TF / TF-IDF, w for IDF / BINARY; then the reference's normalisation, summed in

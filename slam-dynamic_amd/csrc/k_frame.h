@@ -672,6 +672,23 @@ __global__ void __launch_bounds__(64) k_proj_resolve(
     if (lane == 0) { npairsOut[pair] = np; nmatchOut[pair] = np - culled; }
 }
 
+// ascending bitonic sort of n (power of two) 64-bit keys in LDS by one workgroup
+__device__ __forceinline__ void sd_block_sort64(unsigned long long* keys, int n, int tid, int nthreads)
+{
+    for (int k = 2; k <= n; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < n; t += nthreads) {
+                const int p = t ^ j;
+                if (p > t) {
+                    const unsigned long long a = keys[t], b = keys[p];
+                    const bool up = (t & k) == 0;
+                    if ((a > b) == up) { keys[t] = b; keys[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
 // =====================================================================================
 // Local-map search (Tracking::SearchLocalPoints, Tracking.cc:2014-2064)
 //   k_local_candidates  Frame::isInFrustum (Frame.cc:677-733) + the search part of

@@ -755,6 +755,91 @@ __global__ void __launch_bounds__(256) k_region_decode(const _Float16* __restric
     }
 }
 
+// yolov3Segment::postprocess_ after the confidence filter (yolo.cc:186-205) on the device, one workgroup per image:
+// boxes = (int)(centre * frame dims) etc. as the reference truncates them, cv::dnn::NMSBoxes(conf, nms) = stable sort by
+// score (descending; equal scores keep cv::dnn's row order) + greedy keep while the overlap with every kept box is
+// <= nms (1 - jaccardDistance on cv::Rect, f64), the class filter {person, bicycle, car, bus, truck} ("motorcycle" never
+// matches coco.names' "motorbike") and rectCenterScale(box, (-0.2 w, 0.6 h)).  Output: up to 32 boxes per image as
+// cv::Rect2d (x, y, w, h f64) in kept order, nOut[image] (or -1 - count when a capacity was exceeded).
+#define SD_NMS_MAXDET 4096      // rows above the confidence threshold per image handled on the device
+#define SD_NMS_MAXKEEP 512      // boxes NMS may keep before the class filter
+__global__ void __launch_bounds__(256) k_yolo_nms(const SdDet* __restrict__ dets, const int* __restrict__ ndet, int detCap, int frameCols,
+                                                  int frameRows, float confThreshold, float nmsThreshold, double* __restrict__ boxesOut,
+                                                  int* __restrict__ clsOut, float* __restrict__ confOut, int* __restrict__ nOut)
+{
+    __shared__ unsigned long long keys[SD_NMS_MAXDET];
+    __shared__ int s_x[SD_NMS_MAXKEEP], s_y[SD_NMS_MAXKEEP], s_w[SD_NMS_MAXKEEP], s_h[SD_NMS_MAXKEEP], s_kslot[SD_NMS_MAXKEEP];      // kept rects
+    __shared__ int s_idx[SD_NMS_MAXDET];
+    __shared__ int s_reject, s_nk;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int nd = ndet[img];
+    const SdDet* D = dets + (size_t)img * detCap;
+    if (nd > SD_NMS_MAXDET || nd > detCap) { if (tid == 0) nOut[img] = -1 - nd; return; }
+    int n2 = 64;
+    while (n2 < nd) n2 <<= 1;
+    // sort key: score descending, then cv::dnn row ascending (the stable order of NMSBoxes' input)
+    for (int t = tid; t < n2; t += 256) {
+        unsigned long long k = ~0ull;
+        if (t < nd && D[t].conf > confThreshold) k = ((unsigned long long)(~__float_as_uint(D[t].conf)) << 32) | (unsigned)D[t].row;
+        keys[t] = k;
+    }
+    __syncthreads();
+    sd_block_sort64(keys, n2, tid, 256);
+    // row -> slot in the unsorted list: small lists, linear search per sorted entry (done once)
+    for (int t = tid; t < nd; t += 256) {
+        int slot = -1;
+        if (keys[t] != ~0ull) { const int row = (int)(keys[t] & 0xFFFFFFFFu); for (int j = 0; j < nd; j++) if (D[j].row == row) { slot = j; break; } }
+        s_idx[t] = slot;
+    }
+    if (tid == 0) s_nk = 0;
+    __syncthreads();
+    int nk = 0;
+    for (int t = 0; t < nd; t++) {
+        const int slot = s_idx[t];
+        if (slot < 0) break;                                  // the filtered-out rows sort last
+        const SdDet d = D[slot];
+        const int centerX = (int)(d.cx * frameCols), centerY = (int)(d.cy * frameRows);
+        const int width = (int)(d.w * frameCols), height = (int)(d.h * frameRows);
+        const int rx = centerX - width / 2, ry = centerY - height / 2;
+        if (tid == 0) s_reject = 0;
+        __syncthreads();
+        for (int j = tid; j < nk; j += 256) {
+            const double Aa = (double)width * height, Ab = (double)s_w[j] * s_h[j];
+            float ov;
+            if ((Aa + Ab) <= 2.220446049250313e-16) ov = 1.f;
+            else {
+                const int x1 = max(rx, s_x[j]), y1 = max(ry, s_y[j]);
+                const int x2 = min(rx + width, s_x[j] + s_w[j]), y2 = min(ry + height, s_y[j] + s_h[j]);
+                const double Aab = (x2 > x1 && y2 > y1) ? (double)(x2 - x1) * (y2 - y1) : 0.0;
+                ov = (float)(1. - (1. - Aab / (Aa + Ab - Aab)));
+            }
+            if (!(ov <= nmsThreshold)) s_reject = 1;
+        }
+        __syncthreads();
+        if (!s_reject) {
+            if (nk >= SD_NMS_MAXKEEP) { if (tid == 0) nOut[img] = -1 - nd; return; }       // uniform
+            if (tid == 0) { s_x[nk] = rx; s_y[nk] = ry; s_w[nk] = width; s_h[nk] = height; s_kslot[nk] = slot; }
+            nk++;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int n = 0;
+        for (int k = 0; k < nk; k++) {
+            const SdDet d = D[s_kslot[k]];
+            const int c = d.cls;
+            if (!(c == 0 || c == 1 || c == 2 || c == 5 || c == 7)) continue;
+            if (n >= 32) { n = -1 - nk; break; }
+            const double sw = -0.2 * (double)s_w[k], sh = 0.6 * (double)s_h[k];
+            double* o = boxesOut + ((size_t)img * 32 + n) * 4;
+            o[0] = (double)s_x[k] - sw / 2.0; o[1] = (double)s_y[k] - sh / 2.0; o[2] = (double)s_w[k] + sw; o[3] = (double)s_h[k] + sh;
+            clsOut[img * 32 + n] = c; confOut[img * 32 + n] = d.conf;
+            n++;
+        }
+        nOut[img] = n;
+    }
+}
+
 // yolov3Segment::Segmentation (yolo.cc:34-58) after NMS: rasterise the central half-width of every kept box
 // (postprocess, yolo.cc:128-131), dilate with cv::getStructuringElement(MORPH_ELLIPSE, 31x31) and return
 // 1 - dilated.  One 16x16 pixel tile per workgroup; the rasterised mask of the tile + 15-px halo lives in LDS;

@@ -177,6 +177,14 @@ class Detector:
         fe.check(fe.lib().sd_yolo_boxes(self.h, image, frame_cols, frame_rows, conf, nms, fe._p(b), fe._p(cid), fe._p(cf), cap, C.byref(n)))
         return b[:n.value].copy(), cid[:n.value].copy(), cf[:n.value].copy()
 
+    def boxes_batch(self, n_images, frame_cols, frame_rows, conf=0.5, nms=0.4, stream=None):
+        """postprocess_ of every image of the last forward pass, NMS on the device, one download -> list of (boxes, cls, conf)."""
+        b = np.zeros((n_images, 32, 4), np.float64); cid = np.zeros((n_images, 32), np.int32); cf = np.zeros((n_images, 32), np.float32)
+        nb = np.zeros(n_images, np.int32)
+        fe.check(fe.lib().sd_yolo_boxes_batch(self.h, n_images, frame_cols, frame_rows, C.c_float(conf), C.c_float(nms), fe._p(b), fe._p(cid),
+                                              fe._p(cf), fe._p(nb), C.c_void_p(stream or 0)))
+        return [(b[i, :nb[i]].copy(), cid[i, :nb[i]].copy(), cf[i, :nb[i]].copy()) for i in range(n_images)]
+
     def mask_device(self, image, frame_cols, frame_rows, d_mask_ptr, stride, conf=0.5, nms=0.4, stream=None):
         nt = C.c_int()
         fe.check(fe.lib().sd_yolo_mask_device(self.h, image, frame_cols, frame_rows, conf, nms, C.c_void_p(d_mask_ptr), stride,

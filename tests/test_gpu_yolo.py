@@ -95,6 +95,11 @@ def test_batch_of_two_images(det):
     a0 = d.boxes(0, W, H); a1 = d.boxes(1, W, H)
     assert np.array_equal(a0[0], b0) and np.array_equal(a0[1], c0)          # image 0 unchanged by batching
     assert not np.array_equal(a1[0], b0) or len(b0) == 0                     # the flipped image gives other boxes
+    # postprocess_ on the device (k_yolo_nms) == the host form, image by image, bit for bit
+    both = d.boxes_batch(2, W, H)
+    for i, ref_i in enumerate((a0, a1)):
+        assert np.array_equal(both[i][0], ref_i[0]) and np.array_equal(both[i][1], ref_i[1]) and np.array_equal(both[i][2], ref_i[2])
+    assert len(both[0][0]) > 0
     d.forward_device(dev.data_ptr(), W, H, W * 3, W * H * 3, 1, 0.5)         # restore single-image state
 
 
