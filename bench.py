@@ -168,7 +168,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="frames per step per GPU")
-    ap.add_argument("--workload", choices=["rgbd", "stereo", "rgbd-cull", "rgbd-bow"], default="rgbd")
+    ap.add_argument("--workload", choices=["rgbd", "stereo", "rgbd-cull", "rgbd-bow", "stereo-yolo"], default="rgbd")
     ap.add_argument("--cpu-frames", type=int, default=320, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents")
     ap.add_argument("--streams", type=int, default=1,
@@ -209,8 +209,13 @@ def main():
     Bs = B // S
     cull = args.workload == "rgbd-cull"
     bow = args.workload == "rgbd-bow"
+    yolo_wl = args.workload == "stereo-yolo"
     if cull or bow:
         args.workload = "rgbd"
+    if yolo_wl:
+        args.workload = "stereo"
+        if args.streams != 1:
+            raise SystemExit("--workload stereo-yolo runs on one stream")
     if args.workload == "rgbd":
         cfg = synth.KITTI03_RGBD
         workload_name = "KITTI-03 RGB-D 1241x376, 2000 feat/frame, ORB extract+match, no semantic mask (BASELINE configs[1])"
@@ -224,6 +229,10 @@ def main():
     else:
         cfg = synth.KITTI_STEREO
         workload_name = "KITTI stereo 1241x376, 2000 feat/frame, 2x ORB extract + stereo match + projection match, detector off (BASELINE configs[2] minus YOLOv3)"
+        if yolo_wl:
+            workload_name = ("KITTI stereo 1241x376, 2000 feat/frame: YOLOv3 (640x480, synthetic weights) on the left image -> boxes -> boxTrack -> "
+                             "2x ORB extract + stereo match + firstSeparate + TrackHomo (projection match vs the frame 0.2 s back, H/F fit) + "
+                             "Separate + UpdateFrame + projection match vs the last frame (BASELINE configs[2])")
         imgs_per_frame, th = 2, 7.0
     W, H = cfg["width"], cfg["height"]
 
@@ -294,6 +303,13 @@ def main():
             cull_state.append(dict(packed=packed, slots=np.arange(Bs, dtype=np.int32), cur=np.arange(dt, Bs, dtype=np.int32),
                                    ref=np.arange(0, Bs - dt, dtype=np.int32), H=np.tile(Hm.reshape(1, 9), (npair, 1)),
                                    flag=np.ones(npair, np.int32), last=(li, ls, nl)))
+    det = None
+    if yolo_wl:
+        layers, anchors = pkg.yolo.v3_layers()
+        det = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=B)
+        det.load_weights(pkg.yolo.synth_weights(layers, seed=3)[0])
+        d_bgr = d_gray.view(B, 2, H, W)[:, 0].unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()      # the left image as 3 channels
+        yolo_state = dict(last=None, n_boxes=0)
     recs, gatherer = None, None
     if dist is not None:
         recs = []
@@ -301,6 +317,41 @@ def main():
             kp_p, desc_p, cnt_p, cap = bt.results_device()
             recs += [fe.as_torch_u8(kp_p, n_img * cap * 28), fe.as_torch_u8(desc_p, n_img * cap * 32)]
         gatherer = ResultGather(dist, world, rank, sum(r.numel() for r in recs), dev)
+
+    def run_yolo_step(first):
+        """BASELINE configs[2], one batch of B consecutive stereo frames (frame i's reference frame is frame i-2, 0.2 s back)."""
+        bt, st = batch, main_stream.cuda_stream
+        det.forward_device(d_bgr.data_ptr(), W, H, W * 3, W * H * 3, B, 0.5, st)            # yolo->Segmentation_(imLeft)
+        bt.extract_device(d_gray.data_ptr(), W, W * H, n_img, st)
+        bt.stereo_match(B, cfg["bf"], cfg["fx"], st)
+        dets = det.boxes_batch(B, W, H, stream=st)                                          # one synchronisation per batch
+        # Frame::boxTrack is a host recurrence over the sequence (f64, a handful of boxes)
+        bl, il = [], []
+        lo, li_, lm, lv = np.zeros((0, 4)), np.zeros(0, np.int32), np.zeros(0, np.uint8), np.zeros((0, 2))
+        for i in range(B):
+            bx, idx, omit, vel = fe.box_track(dets[i][0][:fe.MAXB // 2], lo, li_, lm, lv, W, H)
+            bl.append(bx); il.append(idx)
+            lo, li_, lm, lv = bx, idx, omit, vel
+        yolo_state["n_boxes"] = int(np.mean([len(x) for x in bl]))
+        bt.first_separate(cur_idx, None, None, stream=st, packed=fe.Batch.pack_boxes(bl, il))
+        bt.assign_grid(n_img, cam, st)
+        bt.unproject(imgs_per_frame, B, cam, I, st)
+        # Tracking::TrackHomo against the frame 0.2 s back, then Separate / UpdateFrame
+        bt.search_by_projection(cur_idx[2:], cur_idx[:-2], I[2:], I[2:], cam, th, False, True, stream=st)
+        bt.estimate_motion(st)
+        npair = B - 2
+        lidx = np.zeros((npair, fe.MAXB), np.int32); lst = np.full((npair, fe.MAXB), -1, np.int32); nl = np.zeros(npair, np.int32)
+        for p in range(npair):
+            m = min(len(il[p + 1]), fe.MAXB); nl[p] = m; lidx[p, :m] = il[p + 1][:m]         # mLastFrame = frame p+1
+        bt.separate(cur_idx[2:], cur_idx[:-2], None, None, None, None, stream=st, packed_last=(lidx, lst, nl))
+        bt.update_frame(True, st)
+        bt.assign_grid(n_img, cam, st)
+        # TrackWithMotionModel's matcher against the last frame
+        if first:
+            bt.search_by_projection(cur_idx[1:], last_idx[1:], I[1:], I[1:], cam, th, False, True, stream=st)
+        else:
+            bt.search_by_projection(cur_idx, last_idx, I, I, cam, th, False, True, stream=st)
+        bt.copy_frame(int(cur_idx[-1]), n_img, st)
 
     def run_stream(k, first):
         bt, st = batches[k], streams[k].cuda_stream
@@ -333,6 +384,11 @@ def main():
         bt.copy_frame(int(cur_idx[-1]), n_img, st)
 
     def step(first=False):
+        if yolo_wl:
+            run_yolo_step(first)
+            if dist is not None:
+                gatherer.submit(recs)
+            return
         for k in range(S):
             run_stream(k, first)
         if S > 1:                                   # join the side streams into the main one
@@ -424,6 +480,16 @@ def main():
                        if world > 1 else "single GPU"},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if yolo_wl:                               # the detector alone (the MFMA path), timed after the run
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(5):
+                det.forward_device(d_bgr.data_ptr(), W, H, W * 3, W * H * 3, B, 0.5, main_stream.cuda_stream)
+            torch.cuda.synchronize(); dt_det = (time.perf_counter() - t1) / 5
+            fl = det.flops()
+            out["detector"] = {"bound": "mfma", "images_per_s": round(B / dt_det, 1), "achieved": round(fl * B / dt_det / 1e12, 1), "peak": 2500.0,
+                               "unit": "TFLOP/s", "frac": round(fl * B / dt_det / 2.5e15, 4), "gflop_per_image": round(fl / 1e9, 2),
+                               "ms_per_batch": round(dt_det * 1e3, 3), "boxes_per_frame_after_boxTrack": yolo_state["n_boxes"],
+                               "weights": "synthetic (yolov3.weights is a download that never was in the reference)"}
         # the broadcast vocabulary's consumer, outside the timed region: Frame::ComputeBoW of frame 0
         batch.compute_bow(vocab, [0], 4)
         b0 = batch.download_bow(0)

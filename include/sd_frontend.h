@@ -263,7 +263,9 @@ int sd_batch_download_dynamic(sd_batch* b, int slot, sd_keypoint* kp, uint8_t* d
 /* Tracking::Separate(HorF, flag, dynStatus) (src/Tracking.cc:1093-1239) for n_pairs (current, reference) slots:
  * per box with the same id in both frames cv::BFMatcher(NORM_HAMMING, crossCheck).match, the <3 / <20 % skip,
  * classifyH (flag 1, :1241-1309) or classifyF (flag 2, :1311-1367) with H/F row-major 3x3 f32, the static /
- * dynamic box decision and box_status update against mLastFrame's (last_box_idx / last_box_status, [n_pairs][32]). */
+ * dynamic box decision and box_status update against mLastFrame's (last_box_idx / last_box_status, [n_pairs][32]).
+ * HorF == flag == NULL: pair p takes both from pair p of the preceding sd_batch_estimate_motion without leaving the
+ * device; a pair whose TrackHomo flag is 0 is skipped as Tracking::Track_new does (ret 0, nothing classified). */
 int sd_batch_separate(sd_batch* b, int n_pairs, const int32_t* cur_index, const int32_t* ref_index, const float* HorF,
                       const int32_t* flag, const int32_t* last_box_idx, const int32_t* last_box_status,
                       const int32_t* n_last, void* stream);

@@ -282,6 +282,15 @@ __device__ __forceinline__ bool sd_classify_one(const float* M, const float* Mi,
 // One workgroup per (current, reference) pair; boxes in sequence.  Cross-checked brute force: thread = query,
 // train descriptors in LDS; the column minima (nearest query of every train) are LDS atomicMin on
 // (distance << 16 | query), which is exactly "first nearest wins".
+// HorF / flag of pair p from the model fit of the same pair index (sd_batch_estimate_motion -> sd_batch_separate)
+__global__ void k_motion_to_sep(const SdMotionResult* __restrict__ res, float* __restrict__ HorF, int* __restrict__ flag, int n)
+{
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= n) return;
+    for (int k = 0; k < 9; k++) HorF[(size_t)p * 9 + k] = res[p].HorF[k];
+    flag[p] = res[p].flag;
+}
+
 __global__ void __launch_bounds__(256) k_separate(SdCullPtrs A, SdSepArgs G)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -309,6 +318,10 @@ __global__ void __launch_bounds__(256) k_separate(SdCullPtrs A, SdSepArgs G)
     int* mt = G.matches + (size_t)pair * A.itemsCap * 2;
     int pos = 0;
     const int nbC = FC.nb, nbR = FR.nb;
+    if (flag != 1 && flag != 2) {        // TrackHomo returned 0 (taken from sd_batch_estimate_motion): Separate is not called (Tracking.cc:637)
+        if (tid == 0) { for (int b = 0; b <= SD_MAXB; b++) dynStart[b] = 0; G.ret[pair] = 0; }
+        return;
+    }
     for (int nbx = 0; nbx < nbC; nbx++) {
         if (tid == 0) dynStart[nbx] = pos;
         const int id = FC.box_idx[nbx];

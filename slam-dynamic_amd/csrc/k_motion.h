@@ -16,6 +16,7 @@
 #define SD_MOTION_KH 512
 #define SD_MOTION_KF 1024
 #define SD_MOTION_K (SD_MOTION_KH + SD_MOTION_KF)
+#define SD_MOTION_CHUNK 256         // pairs whose DLT rows are staged in LDS at a time (36 KB)
 
 struct SdMotionNorm { double meanX1, meanY1, sX1, sY1, meanX2, meanY2, sX2, sY2; int ok; int n; };
 struct SdMotionResult { double H[9]; double F[9]; float HorF[9]; int nH, nF, flag, bestH, bestF; };
@@ -57,20 +58,27 @@ __global__ void __launch_bounds__(256) k_motion_prepare(const sd_keypoint* __res
     }
     __threadfence_block();
     __syncthreads();
-    if (tid < 2) {                               // lane 0: points_last, lane 1: points_current; serial sums in index order
-        const int o = 2 * tid;
-        double mx = 0, my = 0;
-        for (int i = 0; i < N; i++) { mx += (double)P[4 * i + o]; my += (double)P[4 * i + o + 1]; }
-        mx = mx / N; my = my / N;
-        double dx = 0, dy = 0;
-        for (int i = 0; i < N; i++) { dx += fabs((double)P[4 * i + o] - mx); dy += fabs((double)P[4 * i + o + 1] - my); }
-        dx = dx / N; dy = dy / N;
-        const bool ok = N >= 8 && dx > 0 && dy > 0;
+    // serial f64 sums in index order (the order the oracle uses), one lane per coordinate, from LDS
+    extern __shared__ __align__(16) float sPts[];                 // [N][4]
+    __shared__ double s_mean[4], s_dev[4];
+    for (int i = tid; i < 4 * N; i += 256) sPts[i] = P[i];
+    __syncthreads();
+    if (tid < 4) {
+        double m = 0;
+        for (int i = 0; i < N; i++) m += (double)sPts[4 * i + tid];
+        m = m / N;
+        double d = 0;
+        for (int i = 0; i < N; i++) d += fabs((double)sPts[4 * i + tid] - m);
+        d = d / N;
+        s_mean[tid] = m; s_dev[tid] = d;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const bool ok = N >= 8 && s_dev[0] > 0 && s_dev[1] > 0 && s_dev[2] > 0 && s_dev[3] > 0;
         SdMotionNorm* nm = norm + pair;
-        if (tid == 0) { nm->meanX1 = mx; nm->meanY1 = my; nm->sX1 = ok ? 1.0 / dx : 0; nm->sY1 = ok ? 1.0 / dy : 0; nm->n = N; }
-        else { nm->meanX2 = mx; nm->meanY2 = my; nm->sX2 = ok ? 1.0 / dx : 0; nm->sY2 = ok ? 1.0 / dy : 0; }
-        const int okAll = __all(ok || tid >= 2) ? 1 : 0;        // both point sets usable
-        if (tid == 0) nm->ok = okAll;
+        nm->meanX1 = s_mean[0]; nm->meanY1 = s_mean[1]; nm->meanX2 = s_mean[2]; nm->meanY2 = s_mean[3];
+        nm->sX1 = ok ? 1.0 / s_dev[0] : 0; nm->sY1 = ok ? 1.0 / s_dev[1] : 0; nm->sX2 = ok ? 1.0 / s_dev[2] : 0; nm->sY2 = ok ? 1.0 / s_dev[3] : 0;
+        nm->n = N; nm->ok = ok ? 1 : 0;
     }
 }
 
@@ -252,7 +260,8 @@ __global__ void __launch_bounds__(256) k_motion_select(const float* __restrict__
                                                        uint8_t* __restrict__ maskF, SdMotionResult* __restrict__ res)
 {
     __shared__ int s_best[2], s_cnt[2];
-    __shared__ double s_H[9], s_F[9], s_M[81], s_V[81], s_rot[2];
+    __shared__ double s_H[9], s_F[9], s_M[81], s_V[81];
+    __shared__ double s_rows[SD_MOTION_CHUNK * 18];
     __shared__ int s_okH, s_okF;
     const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const SdMotionNorm n = norm[pair];
@@ -287,20 +296,33 @@ __global__ void __launch_bounds__(256) k_motion_select(const float* __restrict__
     __syncthreads();
     // ---- refit H on its inliers: A^T A, one lane per entry, serial over the pairs in index order (Initializer::ComputeH21 rows)
     if (okH) {
-        if (tid < 81) {
-            const int p = tid / 9, q = tid % 9;
-            double acc = 0;
-            for (int i = 0; i < n.n; i++) {
-                if (!mH[i]) continue;
-                const double u1 = SD_N1X(P, i, n), v1 = SD_N1Y(P, i, n), u2 = SD_N2X(P, i, n), v2 = SD_N2Y(P, i, n);
-                const double r0[9] = {0, 0, 0, -u1, -v1, -1, v2 * u1, v2 * v1, v2};
-                const double r1[9] = {u1, v1, 1, 0, 0, 0, -u2 * u1, -u2 * v1, -u2};
-                acc += r0[p] * r0[q];
-                acc += r1[p] * r1[q];
+        // rows of Initializer::ComputeH21 for a chunk of pairs go to LDS (all threads; rows of non-inliers are zero, and
+        // adding +0 never changes the sum), then lane (p, q) adds its products in index order
+        const int p = tid / 9, q = tid % 9;
+        double acc = 0;
+        for (int c0 = 0; c0 < n.n; c0 += SD_MOTION_CHUNK) {
+            const int cn_ = n.n - c0 < SD_MOTION_CHUNK ? n.n - c0 : SD_MOTION_CHUNK;
+            __syncthreads();
+            for (int j = tid; j < cn_; j += 256) {
+                const int i = c0 + j;
+                double* r0 = s_rows + (size_t)j * 18; double* r1 = r0 + 9;
+                if (mH[i]) {
+                    const double u1 = SD_N1X(P, i, n), v1 = SD_N1Y(P, i, n), u2 = SD_N2X(P, i, n), v2 = SD_N2Y(P, i, n);
+                    r0[0] = 0; r0[1] = 0; r0[2] = 0; r0[3] = -u1; r0[4] = -v1; r0[5] = -1; r0[6] = v2 * u1; r0[7] = v2 * v1; r0[8] = v2;
+                    r1[0] = u1; r1[1] = v1; r1[2] = 1; r1[3] = 0; r1[4] = 0; r1[5] = 0; r1[6] = -u2 * u1; r1[7] = -u2 * v1; r1[8] = -u2;
+                } else {
+                    for (int k = 0; k < 18; k++) r0[k] = 0;
+                }
             }
-            s_M[tid] = acc;
-            s_V[tid] = p == q ? 1.0 : 0.0;
+            __syncthreads();
+            if (tid < 81)
+                for (int j = 0; j < cn_; j++) {
+                    const double* r0 = s_rows + (size_t)j * 18;
+                    acc += r0[p] * r0[q];
+                    acc += r0[9 + p] * r0[9 + q];
+                }
         }
+        if (tid < 81) { s_M[tid] = acc; s_V[tid] = p == q ? 1.0 : 0.0; }
         __syncthreads();
         // cyclic Jacobi, 15 sweeps; the three update loops of a rotation run on 9 lanes (k = lane)
         if (tid < 64) {

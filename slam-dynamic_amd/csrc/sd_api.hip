@@ -10,10 +10,10 @@
 #include "k_extract.h"
 #include "k_frame.h"
 #include "k_fast.h"
+#include "k_motion.h"
 #include "k_cull.h"
 #include "sd_yolo.h"
 #include "sd_vocab.h"
-#include "k_motion.h"
 
 static thread_local std::string g_err;
 static int set_err(int code, const std::string& msg) { g_err = msg; return code; }
@@ -1249,7 +1249,7 @@ int sd_batch_estimate_motion(sd_batch* b, void* stream_)
     }
     {
         ProfScope ps(b, s, K_MOTION_P);
-        hipLaunchKernelGGL(k_motion_prepare, dim3(n_pairs), dim3(256), 0, s, b->d_kp, b->d_pairs, b->d_npairs, b->d_pairIdx, (int)cap, b->d_moPts, b->d_moNorm);
+        hipLaunchKernelGGL(k_motion_prepare, dim3(n_pairs), dim3(256), cap * 16, s, b->d_kp, b->d_pairs, b->d_npairs, b->d_pairIdx, (int)cap, b->d_moPts, b->d_moNorm);
         LAUNCH_CHECK("k_motion_prepare");
     }
     {
@@ -1521,8 +1521,10 @@ int sd_batch_separate(sd_batch* b, int n_pairs, const int32_t* cur_index, const 
                       void* stream_)
 {
     if (!b || n_pairs < 0 || n_pairs > b->maxImages ||
-        (n_pairs > 0 && (!cur_index || !ref_index || !HorF || !flag || !last_box_idx || !last_box_status || !n_last)))
+        (n_pairs > 0 && (!cur_index || !ref_index || (!HorF) != (!flag) || !last_box_idx || !last_box_status || !n_last)))
         return set_err(SD_ERR_INVALID, "bad separate arguments");
+    const bool fromMotion = n_pairs > 0 && !HorF;          // HorF == flag == NULL: pair p uses the model fit of pair p
+    if (fromMotion && b->nMotion < n_pairs) return set_err(SD_ERR_STATE, "separate: no sd_batch_estimate_motion results for these pairs");
     hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
     b->lastStream = s;
     b->nSepPairs = 0;
@@ -1531,13 +1533,18 @@ int sd_batch_separate(sd_batch* b, int n_pairs, const int32_t* cur_index, const 
     idx.resize(n_pairs);
     for (int p = 0; p < n_pairs; p++) {
         if (!slot_ok(b, cur_index[p]) || !slot_ok(b, ref_index[p])) return set_err(SD_ERR_STATE, "separate: slot holds no results");
-        if (flag[p] != 1 && flag[p] != 2) return set_err(SD_ERR_INVALID, "separate: flag must be 1 (H) or 2 (F)");
+        if (!fromMotion && flag[p] != 1 && flag[p] != 2) return set_err(SD_ERR_INVALID, "separate: flag must be 1 (H) or 2 (F)");
         if (n_last[p] < 0 || n_last[p] > SD_MAXB) return set_err(SD_ERR_INVALID, "separate: bad n_last");
         idx[p] = make_int2(cur_index[p], ref_index[p]);
     }
     HIPCHK(hipMemcpyAsync(b->d_sepPairs, idx.data(), (size_t)n_pairs * sizeof(int2), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(b->d_HorF, HorF, (size_t)n_pairs * 36, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(b->d_sepFlag, flag, (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));
+    if (fromMotion) {
+        hipLaunchKernelGGL(k_motion_to_sep, dim3((n_pairs + 63) / 64), dim3(64), 0, s, b->d_moRes, b->d_HorF, b->d_sepFlag, n_pairs);
+        LAUNCH_CHECK("k_motion_to_sep");
+    } else {
+        HIPCHK(hipMemcpyAsync(b->d_HorF, HorF, (size_t)n_pairs * 36, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(b->d_sepFlag, flag, (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));
+    }
     HIPCHK(hipMemcpyAsync(b->d_lastIdx, last_box_idx, (size_t)n_pairs * SD_MAXB * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(b->d_lastStatus, last_box_status, (size_t)n_pairs * SD_MAXB * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(b->d_nLast, n_last, (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));

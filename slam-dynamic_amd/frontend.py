@@ -382,7 +382,10 @@ class Batch:
     def separate(self, cur_index, ref_index, HorF, flag, last_box_idx, last_box_status, stream=None, packed_last=None):
         n = len(cur_index)
         ci = np.ascontiguousarray(cur_index, np.int32); ri = np.ascontiguousarray(ref_index, np.int32)
-        M = np.ascontiguousarray(HorF, np.float32).reshape(n, 9); fl = np.ascontiguousarray(flag, np.int32)
+        if HorF is None:                     # HorF / flag from the preceding estimate_motion, on the device
+            M = fl = None
+        else:
+            M = np.ascontiguousarray(HorF, np.float32).reshape(n, 9); fl = np.ascontiguousarray(flag, np.int32)
         if packed_last is not None:
             li, ls, nl = packed_last
         else:
@@ -390,7 +393,8 @@ class Batch:
             for k in range(n):
                 m = len(last_box_idx[k]); nl[k] = m
                 li[k, :m] = last_box_idx[k]; ls[k, :m] = last_box_status[k]
-        check(lib().sd_batch_separate(self.h, n, _p(ci), _p(ri), _p(M), _p(fl), _p(li), _p(ls), _p(nl), C.c_void_p(stream or 0)))
+        check(lib().sd_batch_separate(self.h, n, _p(ci), _p(ri), _p(M) if M is not None else None, _p(fl) if fl is not None else None, _p(li), _p(ls),
+                                      _p(nl), C.c_void_p(stream or 0)))
 
     def download_separate(self, pair):
         ret = C.c_int(); ds = np.zeros(MAXB + 1, np.int32)

@@ -180,7 +180,7 @@ class DynamicFrontEnd:
                     flag = mo["flag"]
                 if flag != 0:
                     lastb = b.download_boxes(1)
-                    b.separate([0], [ref], mo["HorF"][None], [flag], [lastb["box_idx"]], [lastb["box_status"]], stream=st)
+                    b.separate([0], [ref], None, None, [lastb["box_idx"]], [lastb["box_status"]], stream=st)     # HorF / flag stay on the device
                     b.update_frame(True, st)                         # if(Separate(...) == 1) mCurrentFrame.UpdateFrame(dynStatus)
                     b.assign_grid(1, self.cam, st)
                     ret, ds, dyn, mt = b.download_separate(0)
