@@ -167,7 +167,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--workload", choices=["rgbd", "stereo", "rgbd-cull", "rgbd-bow", "stereo-yolo"], default="rgbd")
     ap.add_argument("--cpu-frames", type=int, default=320, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents")
@@ -239,12 +239,12 @@ def main():
     # ---- synthetic inputs, resident in HBM before the timed region
     seq = 10 + rank
     if args.workload == "rgbd":
-        fr = [synth.rgbd_frame(seq, t, cfg) for t in range(B)]
+        fr = [synth.rgbd_frame(seq + 100 * (t // 128), t % 128, cfg) for t in range(B)]      # a synthetic sequence is valid for ~128 frames (zoom 1.01^t)
         d_rgb = torch.from_numpy(np.stack([f[0] for f in fr])).to(dev)
         d_depth = torch.from_numpy(np.stack([f[1] for f in fr]).view(np.int16)).to(dev)
         d_gray = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
     else:
-        fr = [synth.stereo_frame(seq, t, cfg) for t in range(B)]
+        fr = [synth.stereo_frame(seq + 100 * (t // 128), t % 128, cfg) for t in range(B)]
         d_gray = torch.from_numpy(np.stack([im for f in fr for im in (f[0], f[1])])).to(dev)
     del fr
 

@@ -290,33 +290,43 @@ __global__ void __launch_bounds__(256) k_blur_wide(const uint8_t* __restrict__ p
     }
 }
 
-// ------------------------------------------------------------------ cvtColor -> gray, 4 px per thread with dword accesses
+// ------------------------------------------------------------------ cvtColor -> gray, 16 px per thread: three unaligned
+// 16-byte loads (48 bytes = 16 pixels x 3 channels) and one 16-byte store; rows of 1241 pixels are never aligned, the
+// hardware takes unaligned dwordx4 accesses.
+typedef uint32_t sd_u4v __attribute__((ext_vector_type(4)));
+typedef sd_u4v sd_u128_unaligned __attribute__((aligned(1)));
+__device__ __forceinline__ uint32_t sd_gray4(uint32_t a, uint32_t b, uint32_t c, int cr, int cb)
+{
+    // 12 bytes = 4 pixels x 3 channels; pixel k: bytes 3k, 3k+1, 3k+2
+    const uint32_t p0 = ((a & 255) * cr + ((a >> 8) & 255) * 9617 + ((a >> 16) & 255) * cb + 8192) >> 14;
+    const uint32_t p1 = ((a >> 24) * cr + (b & 255) * 9617 + ((b >> 8) & 255) * cb + 8192) >> 14;
+    const uint32_t p2 = (((b >> 16) & 255) * cr + (b >> 24) * 9617 + (c & 255) * cb + 8192) >> 14;
+    const uint32_t p3 = (((c >> 8) & 255) * cr + ((c >> 16) & 255) * 9617 + (c >> 24) * cb + 8192) >> 14;
+    return p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
+}
 __global__ void __launch_bounds__(256) k_cvt_gray3_wide(const uint8_t* __restrict__ src, int W, int H, size_t sstride,
                                                         size_t spitch, int rgbOrder, uint8_t* __restrict__ dst,
                                                         size_t dstride, size_t dpitch)
 {
     const int img = blockIdx.z;
-    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 16;
     const int y = blockIdx.y * 4 + threadIdx.y;
-    if (y >= H || x0 + 3 >= W) {
-        if (y < H && x0 < W) {      // ragged tail of the row: byte path
-            const uint8_t* s = src + (size_t)img * spitch + (size_t)y * sstride + (size_t)x0 * 3;
-            uint8_t* d = dst + (size_t)img * dpitch + (size_t)y * dstride + x0;
-            for (int k = 0; k < W - x0; k++) {
-                const uint8_t* p = s + 3 * k;
-                const int r = rgbOrder ? p[0] : p[2], gg = p[1], b = rgbOrder ? p[2] : p[0];
-                d[k] = (uint8_t)((r * 4899 + gg * 9617 + b * 1868 + (1 << 13)) >> 14);
-            }
-        }
+    if (y >= H || x0 >= W) return;
+    const uint8_t* srow = src + (size_t)img * spitch + (size_t)y * sstride + (size_t)x0 * 3;
+    uint8_t* drow = dst + (size_t)img * dpitch + (size_t)y * dstride + x0;
+    const int cr = rgbOrder ? 4899 : 1868, cb = rgbOrder ? 1868 : 4899;
+    if (x0 + 15 < W) {
+        const sd_u128_unaligned* s = (const sd_u128_unaligned*)srow;
+        const sd_u4v a = s[0], b = s[1], c = s[2];
+        sd_u4v o;
+        o.x = sd_gray4(a.x, a.y, a.z, cr, cb); o.y = sd_gray4(a.w, b.x, b.y, cr, cb);
+        o.z = sd_gray4(b.z, b.w, c.x, cr, cb); o.w = sd_gray4(c.y, c.z, c.w, cr, cb);
+        *(sd_u128_unaligned*)drow = o;
         return;
     }
-    const sd_u32_unaligned* s = (const sd_u32_unaligned*)(src + (size_t)img * spitch + (size_t)y * sstride + (size_t)x0 * 3);
-    const uint32_t a = s[0], b = s[1], c = s[2];     // 12 bytes = 4 pixels x 3 channels
-    const int cr = rgbOrder ? 4899 : 1868, cb = rgbOrder ? 1868 : 4899;
-    // pixel k: bytes 3k, 3k+1, 3k+2
-    const uint32_t p0 = ((a & 255) * cr + ((a >> 8) & 255) * 9617 + ((a >> 16) & 255) * cb + 8192) >> 14;
-    const uint32_t p1 = ((a >> 24) * cr + (b & 255) * 9617 + ((b >> 8) & 255) * cb + 8192) >> 14;
-    const uint32_t p2 = (((b >> 16) & 255) * cr + (b >> 24) * 9617 + (c & 255) * cb + 8192) >> 14;
-    const uint32_t p3 = (((c >> 8) & 255) * cr + ((c >> 16) & 255) * 9617 + (c >> 24) * cb + 8192) >> 14;
-    *(sd_u32_unaligned*)(dst + (size_t)img * dpitch + (size_t)y * dstride + x0) = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
+    for (int k = 0; k < W - x0; k++) {      // ragged tail of the row: byte path
+        const uint8_t* p = srow + 3 * k;
+        const int r = rgbOrder ? p[0] : p[2], gg = p[1], b = rgbOrder ? p[2] : p[0];
+        drow[k] = (uint8_t)((r * 4899 + gg * 9617 + b * 1868 + (1 << 13)) >> 14);
+    }
 }

@@ -729,7 +729,7 @@ int sd_cvt_gray_device(const uint8_t* d_src, int width, int height, size_t src_s
     if (n_images == 0) return SD_OK;
     dim3 blk(64, 4), grd(((width + 3) / 4 + 63) / 64, (height + 3) / 4, n_images);
     if (channels == 3)
-        hipLaunchKernelGGL(k_cvt_gray3_wide, grd, blk, 0, (hipStream_t)stream, d_src, width, height, src_stride, src_pitch,
+        hipLaunchKernelGGL(k_cvt_gray3_wide, dim3(((width + 15) / 16 + 63) / 64, (height + 3) / 4, n_images), blk, 0, (hipStream_t)stream, d_src, width, height, src_stride, src_pitch,
                            rgb_order, d_dst, dst_stride, dst_pitch);
     else
         hipLaunchKernelGGL(k_cvt_gray, grd, blk, 0, (hipStream_t)stream, d_src, width, height, src_stride, src_pitch, channels,
