@@ -23,8 +23,11 @@ import re
 
 def clean(name):
     name = name.split("(")[0].replace("void ", "")
-    m_ = re.match(r"_Z\d+(k_[a-z0-9_]+?)(PK|P[a-zA-Z]|i|f|$)", name)      # rocprofv3 leaves some names mangled
-    return m_.group(1) if m_ else name
+    m_ = re.match(r"_Z(\d+)", name)                  # rocprofv3 leaves some names mangled: _Z<len><name>...
+    if m_:
+        n_ = int(m_.group(1)); st = m_.end()
+        return name[st:st + n_]
+    return name
 
 
 def load(d):
