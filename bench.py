@@ -452,7 +452,7 @@ def main():
             if os.path.exists(pmc):
                 try:
                     j = json.load(open(pmc))
-                    e = j.get(dom)
+                    e = j.get(dom) or j.get({"k_fast_cells": "k_fast_cells_staged", "k_blur": "k_blur_wide"}.get(dom, dom))      # in-library ids vs kernel symbols
                     if e and e.get("batch_images") == n_img:
                         traffic = e.get("hbm_bytes_per_launch")
                 except Exception:
