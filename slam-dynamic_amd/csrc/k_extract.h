@@ -46,6 +46,19 @@ __device__ __forceinline__ int sd_reflect101(int p, int len)
 // ------------------------------------------------------------------ pyramid, level 0
 // Padded copy of the gray input with BORDER_REFLECT_101 (ORBextractor.cc:1127-1128).
 // Thread = 4 consecutive padded pixels (one aligned u32 store); block 64x4.  Groups that lie inside the
+// XCD-aware work order for per-image kernels.  Workgroups are dispatched round-robin over the 8 XCDs (id % 8) and every
+// XCD has its own L2, so a 1-D grid is decoded as (image group, item, XCD): XCD x processes images x, x + 8, ... and the
+// items of one image (neighbouring tiles / cells / keypoints, which share cache lines and halos) meet in ONE L2 instead of
+// being fetched by up to eight.  Grid size = items_per_image * round_up(n_images, 8).
+__device__ __forceinline__ bool sd_xcd_image_item(unsigned id, int perImage, int nImages, int& img, int& item)
+{
+    const int xcd = (int)(id & 7u);
+    const unsigned k = id >> 3;
+    item = (int)(k % (unsigned)perImage);
+    img = (int)(k / (unsigned)perImage) * 8 + xcd;
+    return img < nImages;
+}
+
 // interior columns are one (unaligned) dword load; only the 19-px frame takes the per-byte reflect path.
 typedef uint32_t __attribute__((aligned(1))) sd_u32_una;
 typedef unsigned long long __attribute__((aligned(1))) sd_u64_una;
@@ -619,11 +632,13 @@ __device__ __forceinline__ float sd_fast_atan2(float y, float x)
 
 __global__ void __launch_bounds__(256) k_orient(const uint8_t* __restrict__ pyr, const uint32_t* __restrict__ lvlKp,
                                                 const int* __restrict__ lvlCount, sd_keypoint* __restrict__ kpOut,
-                                                float2* __restrict__ rot, int* __restrict__ count, const SdDevPlan* __restrict__ PP)
+                                                float2* __restrict__ rot, int* __restrict__ count, const SdDevPlan* __restrict__ PP,
+                                                int nImages, int groupsPerImage)
 {
     const SdDevPlan& P = *PP;
-    const int img = blockIdx.y;
-    const int slot = blockIdx.x * 8 + (threadIdx.x >> 5);
+    int img, grp;
+    if (!sd_xcd_image_item(blockIdx.x, groupsPerImage, nImages, img, grp)) return;
+    const int slot = grp * 8 + (threadIdx.x >> 5);
     const int l32 = threadIdx.x & 31;
     if (slot >= P.kpCapLevels) return;
     int level = 0;
@@ -733,13 +748,15 @@ __global__ void __launch_bounds__(256) k_blur(const uint8_t* __restrict__ pyr, u
 typedef uint32_t __attribute__((aligned(1))) sd_u32_ua;
 __global__ void __launch_bounds__(256) k_describe(const uint8_t* __restrict__ blur, const uint32_t* __restrict__ lvlKp,
                                                   const int* __restrict__ lvlCount, const float2* __restrict__ rot,
-                                                  uint8_t* __restrict__ descOut, const SdDevPlan* __restrict__ PP)
+                                                  uint8_t* __restrict__ descOut, const SdDevPlan* __restrict__ PP, int nImages,
+                                                  int groupsPerImage)
 {
     const SdDevPlan& P = *PP;
     __shared__ __align__(16) uint8_t patch[4][37 * SD_DP_W];
-    const int img = blockIdx.y;
+    int img, grp;
+    if (!sd_xcd_image_item(blockIdx.x, groupsPerImage, nImages, img, grp)) return;
     const int wv = threadIdx.x >> 6;
-    const int slot = blockIdx.x * 4 + wv;
+    const int slot = grp * 4 + wv;
     const int lane = threadIdx.x & 63;
     if (slot >= P.kpCapLevels) return;
     int level = 0;

@@ -41,9 +41,10 @@ template <int NT>
 __global__ void __launch_bounds__(NT) k_fast_cells_staged(const uint8_t* __restrict__ pyr,
                                                           const SdCell* __restrict__ cells,
                                                           uint32_t* __restrict__ cellList, int* __restrict__ cellCount,
-                                                          const SdDevPlan* __restrict__ PP, int listCap)
+                                                          const SdDevPlan* __restrict__ PP, int listCapArg)
 {
     const SdDevPlan& P = *PP;
+    const int listCap = listCapArg & 0xFFFF, nImages = listCapArg >> 16;
     __shared__ __align__(16) uint8_t tile[SD_FS_MAXWIN * SD_FS_TW];
     __shared__ __align__(16) uint8_t score[SD_FS_SW * SD_FS_SW];
     extern __shared__ __align__(16) unsigned char dyn_smem[];
@@ -58,13 +59,14 @@ __global__ void __launch_bounds__(NT) k_fast_cells_staged(const uint8_t* __restr
     uint32_t* tileW = (uint32_t*)tile;
     uint32_t* scoreW = (uint32_t*)score;
     {
-        // Cell order = dispatch order.  An XCD-aware order (workgroup b -> cell (b % 8) * chunk + b / 8, one contiguous
-        // run of cells per XCD L2) was measured: FETCH_SIZE per launch fell 5x (475 -> 94 MiB, i.e. to the algorithmic
-        // bytes) but the kernel got 35 % slower (0.50 -> 0.67 ms per 128 images): it is bound by latency / occupancy,
-        // not by bytes, and the over-fetch is absorbed by L2 / Infinity Cache.  The faster order is kept.
-        const int img = blockIdx.y;
-        const int ci = blockIdx.x;
-        if (ci >= cellTotal) return;
+        // XCD-aware order: workgroup id -> XCD id % 8 (round-robin dispatch), so XCD x walks the cells of images x, x + 8, ...
+        // in cell order and neighbouring cells (which share 128-byte lines and a 6-px halo) meet in ONE L2.  Measured at 256
+        // images: FETCH_SIZE per launch 928 -> 173 MiB (x2 = the algorithmic bytes), same 1.0 ms.  (Splitting the cells
+        // of ONE image over the XCDs instead cut the fetch as much but was 35 % slower.)
+        const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+        const int ci = kq % cellTotal;
+        const int img = (kq / cellTotal) * 8 + xcd;
+        if (img >= nImages) return;
         const SdCell c = cells[ci];
         const SdLevel& g = P.lv[c.level];
         const int ww = c.x1 - c.x0, wh = c.y1 - c.y0;
@@ -246,6 +248,8 @@ __global__ void __launch_bounds__(256) k_blur_wide(const uint8_t* __restrict__ p
 {
     const SdDevPlan& P = *PP;
     __shared__ uint2 hbuf[22][32];
+    // (The XCD-aware image order of sd_xcd_image_item was measured here too: FETCH_SIZE 514 -> 203 MiB per 256 images, but
+    // the kernel went from 0.47 to 0.56 ms; the dispatch order is kept.)
     const int zi = blockIdx.z;
     const int img = zi / P.nlevels, level = zi - img * P.nlevels;
     const SdLevel& g = P.lv[level];

@@ -456,8 +456,10 @@ int sd_batch_extract_device(sd_batch* b, const uint8_t* d_gray, size_t stride, s
             listCap = (listCap + 7) & ~7;
             const size_t lds = (size_t)listCap * 4 + ((size_t)listCap / 4 + 4) * 4;
             // 128-thread workgroups: measured best (64: 0.66 ms, 128: 0.49 ms, 256: 0.65 ms per 128-image launch)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_cells_staged<128>), grd, dim3(128), lds, s, b->d_pyr, b->d_cells, b->d_cellList,
-                               b->d_cellCount, b->d_plan, listCap);
+            // 1-D grid: workgroup id = (image group, cell, XCD) -- see the kernel
+            const unsigned nwg = (unsigned)P.cells.size() * (unsigned)((n_images + 7) / 8 * 8);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_cells_staged<128>), dim3(nwg), dim3(128), lds, s, b->d_pyr, b->d_cells, b->d_cellList,
+                               b->d_cellCount, b->d_plan, listCap | (n_images << 16));
         }
         else
             hipLaunchKernelGGL(k_fast_cells, grd, dim3(256), 0, s, b->d_pyr, b->d_cells, b->d_cellList, b->d_cellCount, b->d_plan);
@@ -472,15 +474,16 @@ int sd_batch_extract_device(sd_batch* b, const uint8_t* d_gray, size_t stride, s
     LAUNCH_CHECK("k_quadtree");
     {
         ProfScope ps(b, s, K_ORIENT);
-        dim3 grd((P.kpCapLevels + 7) / 8, n_images);
-        hipLaunchKernelGGL(k_orient, grd, dim3(256), 0, s, b->d_pyr, b->d_lvlKp, b->d_lvlCount, b->d_kp, b->d_rot, b->d_count,
-                           b->d_plan);
+        const int gpi = (P.kpCapLevels + 7) / 8, n8 = (n_images + 7) / 8 * 8;
+        hipLaunchKernelGGL(k_orient, dim3((unsigned)gpi * n8), dim3(256), 0, s, b->d_pyr, b->d_lvlKp, b->d_lvlCount, b->d_kp, b->d_rot, b->d_count,
+                           b->d_plan, n_images, gpi);
     }
     LAUNCH_CHECK("k_orient");
     {
         ProfScope ps(b, s, K_DESC);
-        dim3 grd((P.kpCapLevels + 3) / 4, n_images);
-        hipLaunchKernelGGL(k_describe, grd, dim3(256), 0, s, b->d_blur, b->d_lvlKp, b->d_lvlCount, b->d_rot, b->d_desc, b->d_plan);
+        const int gpi = (P.kpCapLevels + 3) / 4, n8 = (n_images + 7) / 8 * 8;
+        hipLaunchKernelGGL(k_describe, dim3((unsigned)gpi * n8), dim3(256), 0, s, b->d_blur, b->d_lvlKp, b->d_lvlCount, b->d_rot, b->d_desc, b->d_plan,
+                           n_images, gpi);
     }
     LAUNCH_CHECK("k_describe");
     b->nExtracted = n_images;
