@@ -228,6 +228,16 @@ int sd_batch_estimate_motion(sd_batch* b, void* stream);
 int sd_batch_download_motion(sd_batch* b, int pair, double* H, double* F, uint8_t* mask_h, uint8_t* mask_f, int cap,
                              int* n_points, int* n_h, int* n_f, float* HorF, int* flag);
 
+/* Frame::UndistortKeyPoints (src/Frame.cc:812-842) and Frame::ComputeImageBounds (:844-872) for cameras whose
+ * Camera.k1 is not zero (TUM1 / TUM2 / EuRoC settings): cv::undistortPoints(pts, mK, mDistCoef, Mat(), mK).  K4 = fx, fy,
+ * cx, cy; dist5 = k1, k2, p1, p2, k3 (Tracking.cc:76-90).  sd_batch_undistort_keypoints writes the mvKeysUn records of the
+ * first n_images slots to d_keys_un ([n_images][cap] sd_keypoint; a plain copy when k1 == 0, as the reference does).
+ * The matchers of this library read the batch's own keypoints, i.e. they implement the k1 == 0 case of every shipped
+ * KITTI / TUM3 setting; sd_image_bounds gives mnMinX, mnMaxX, mnMinY, mnMaxY for sd_camera. */
+int sd_undistort_points_device(const float* d_pts, int n, const float* K4, const float* dist5, float* d_out, void* stream);
+int sd_batch_undistort_keypoints(sd_batch* b, int n_images, const float* K4, const float* dist5, sd_keypoint* d_keys_un, void* stream);
+int sd_image_bounds(int cols, int rows, const float* K4, const float* dist5, float* bounds4);
+
 /* Frame copy constructor (src/Frame.cc:39-63), as in `mLastFrame = Frame(mCurrentFrame)`: copies the frame
  * results of slot src (keypoints, descriptors, mvuRight/mvDepth, grid cells, map-point table) to slot dst. */
 int sd_batch_copy_frame(sd_batch* b, int src, int dst, void* stream);

@@ -393,3 +393,17 @@ def estimate_motion(points_last, points_current):
     f.restype = C.c_int
     flag = f(_p(p1), _p(p2), N, _p(H), _p(F), _p(mh), _p(mf), C.byref(nh), C.byref(nf), _p(hf))
     return dict(H=H.reshape(3, 3), F=F.reshape(3, 3), mask_h=mh[:N], mask_f=mf[:N], n_h=nh.value, n_f=nf.value, HorF=hf.reshape(3, 3), flag=flag)
+
+
+def undistort_points(pts, K4, dist5):
+    """cv::undistortPoints(pts, mK, mDistCoef, Mat(), mK) of Frame::UndistortKeyPoints -> (N, 2) f32."""
+    p = np.ascontiguousarray(pts, np.float32).reshape(-1, 2); out = np.zeros_like(p)
+    k = np.ascontiguousarray(K4, np.float32); d = np.ascontiguousarray(dist5, np.float32)
+    lib().orc_undistort_points(_p(p), len(p), _p(k), _p(d), _p(out))
+    return out
+
+
+def image_bounds(cols, rows, K4, dist5):
+    k = np.ascontiguousarray(K4, np.float32); d = np.ascontiguousarray(dist5, np.float32); b = np.zeros(4, np.float32)
+    lib().orc_image_bounds(int(cols), int(rows), _p(k), _p(d), _p(b))
+    return b

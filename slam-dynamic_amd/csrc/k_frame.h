@@ -965,3 +965,45 @@ __global__ void __launch_bounds__(64) k_local_resolve(
     for (int i = lane; i < N; i += 64) kpMatch[(size_t)f * cap + i] = s_match[i];
     if (lane == 0) nmatchOut[f] = nm;
 }
+
+
+// =====================================================================================
+// Frame::UndistortKeyPoints (Frame.cc:812-842) for a camera with distortion: cv::undistortPoints(pts, mK, mDistCoef, Mat(), mK)
+// [OpenCV-recall: five fixed-point iterations in double, see oracle/frame_oracle.inc].  One thread per keypoint; writes the
+// mvKeysUn records (the keypoint with pt replaced).
+// =====================================================================================
+struct SdDistortion { double fx, fy, cx, cy, k1, k2, p1, p2, k3; };
+__device__ __forceinline__ void sd_undistort_pt(const SdDistortion& D, float u, float v, float& uo, float& vo)
+{
+    const double ifx = 1. / D.fx, ify = 1. / D.fy;
+    double x = u, y = v;
+    x = (x - D.cx) * ifx; y = (y - D.cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((0. * r2 + 0.) * r2 + 0.) * r2) / (1 + ((D.k3 * r2 + D.k2) * r2 + D.k1) * r2);
+        const double deltaX = 2 * D.p1 * x * y + D.p2 * (r2 + 2 * x * x);
+        const double deltaY = D.p1 * (r2 + 2 * y * y) + 2 * D.p2 * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    uo = (float)(x * D.fx + D.cx);
+    vo = (float)(y * D.fy + D.cy);
+}
+__global__ void __launch_bounds__(256) k_undistort_points(const float* __restrict__ pts, int n, SdDistortion D, float* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float uo, vo;
+    sd_undistort_pt(D, pts[2 * i], pts[2 * i + 1], uo, vo);
+    out[2 * i] = uo; out[2 * i + 1] = vo;
+}
+__global__ void __launch_bounds__(256) k_undistort_keypoints(const sd_keypoint* __restrict__ kp, const int* __restrict__ count, int cap,
+                                                             SdDistortion D, int identity, sd_keypoint* __restrict__ kpUn)
+{
+    const int img = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count[img]) return;
+    sd_keypoint k = kp[(size_t)img * cap + i];
+    if (!identity) { float uo, vo; sd_undistort_pt(D, k.x, k.y, uo, vo); k.x = uo; k.y = vo; }
+    kpUn[(size_t)img * cap + i] = k;
+}

@@ -1289,6 +1289,68 @@ int sd_batch_download_motion(sd_batch* b, int pair, double* H, double* F, uint8_
     return SD_OK;
 }
 
+// Frame::UndistortKeyPoints / ComputeImageBounds (src/Frame.cc:812-872) for cameras with distortion.
+static SdDistortion to_distortion(const float* K4, const float* dist5)
+{
+    SdDistortion D;
+    D.fx = K4[0]; D.fy = K4[1]; D.cx = K4[2]; D.cy = K4[3];
+    D.k1 = dist5[0]; D.k2 = dist5[1]; D.p1 = dist5[2]; D.p2 = dist5[3]; D.k3 = dist5[4];
+    return D;
+}
+
+int sd_undistort_points_device(const float* d_pts, int n, const float* K4, const float* dist5, float* d_out, void* stream)
+{
+    if (n < 0 || !K4 || !dist5 || (n > 0 && (!d_pts || !d_out))) return set_err(SD_ERR_INVALID, "bad undistort arguments");
+    if (n == 0) return SD_OK;
+    hipLaunchKernelGGL(k_undistort_points, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_pts, n, to_distortion(K4, dist5), d_out);
+    LAUNCH_CHECK("k_undistort_points");
+    return SD_OK;
+}
+
+int sd_batch_undistort_keypoints(sd_batch* b, int n_images, const float* K4, const float* dist5, sd_keypoint* d_keys_un, void* stream_)
+{
+    if (!b || n_images < 0 || n_images > b->nExtracted || !K4 || !dist5 || !d_keys_un) return set_err(SD_ERR_INVALID, "bad undistort_keypoints arguments");
+    if (n_images == 0) return SD_OK;
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
+    b->lastStream = s;
+    const int cap = b->plan.kpCap;
+    hipLaunchKernelGGL(k_undistort_keypoints, dim3((cap + 255) / 256, n_images), dim3(256), 0, s, b->d_kp, b->d_count, cap, to_distortion(K4, dist5),
+                       dist5[0] == 0.0f ? 1 : 0, d_keys_un);                      // mDistCoef.at<float>(0) == 0.0 -> mvKeysUn = mvKeys
+    LAUNCH_CHECK("k_undistort_keypoints");
+    return SD_OK;
+}
+
+// Four corner points, once per camera: host arithmetic (double, the same expression order as the kernel).
+int sd_image_bounds(int cols, int rows, const float* K4, const float* dist5, float* bounds4)
+{
+    if (!K4 || !dist5 || !bounds4 || cols < 1 || rows < 1) return SD_ERR_INVALID;
+    if (dist5[0] != 0.0f) {
+        const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3], k1 = dist5[0], k2 = dist5[1], p1 = dist5[2], p2 = dist5[3], k3 = dist5[4];
+        const float corners[8] = {0.f, 0.f, (float)cols, 0.f, 0.f, (float)rows, (float)cols, (float)rows};
+        float u[8];
+        const double ifx = 1. / fx, ify = 1. / fy;
+        for (int i = 0; i < 4; i++) {
+            double x = corners[2 * i], y = corners[2 * i + 1];
+            x = (x - cx) * ifx; y = (y - cy) * ify;
+            const double x0 = x, y0 = y;
+            for (int j = 0; j < 5; j++) {
+                const double r2 = x * x + y * y;
+                const double icdist = (1 + ((0. * r2 + 0.) * r2 + 0.) * r2) / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+                const double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+                const double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+                x = (x0 - deltaX) * icdist;
+                y = (y0 - deltaY) * icdist;
+            }
+            u[2 * i] = (float)(x * fx + cx); u[2 * i + 1] = (float)(y * fy + cy);
+        }
+        bounds4[0] = std::min(u[0], u[4]); bounds4[1] = std::max(u[2], u[6]);
+        bounds4[2] = std::min(u[1], u[3]); bounds4[3] = std::max(u[5], u[7]);
+    } else {
+        bounds4[0] = 0.0f; bounds4[1] = (float)cols; bounds4[2] = 0.0f; bounds4[3] = (float)rows;
+    }
+    return SD_OK;
+}
+
 // Frame copy (mLastFrame = Frame(mCurrentFrame), Tracking.cc; Frame.cc:39-63): keypoints, descriptors,
 // stereo coordinates, grid cells and the map-point table of slot `src` into slot `dst`.
 int sd_batch_copy_frame(sd_batch* b, int src, int dst, void* stream_)

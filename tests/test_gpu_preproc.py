@@ -49,3 +49,49 @@ def test_hamming_matrix(gpu, fe, orc):
     assert np.array_equal(got, ref)
     assert got[3, 5] == 0 and got[4, 6] == 256
     assert fe.DescriptorDistance(a[0], b[0]) == ref[0, 0] == orc.descriptor_distance(a[0], b[0])
+
+
+def test_undistort_points_and_bounds(gpu, fe, orc):
+    """Frame::UndistortKeyPoints / ComputeImageBounds with TUM1.yaml's distortion (Examples/RGB-D/TUM1.yaml): bit-exact vs the oracle."""
+    import ctypes as C
+    import torch
+    K = np.array([517.306408, 516.469215, 318.643040, 255.313989], np.float32)
+    D = np.array([0.262383, -0.953104, -0.005358, 0.002628, 1.163314], np.float32)
+    rng = np.random.default_rng(2)
+    pts = np.stack([rng.uniform(0, 640, 5000), rng.uniform(0, 480, 5000)], 1).astype(np.float32)
+    d_in = torch.from_numpy(pts).cuda(); d_out = torch.zeros_like(d_in)
+    fe.check(fe.lib().sd_undistort_points_device(C.c_void_p(d_in.data_ptr()), len(pts), fe._p(K), fe._p(D), C.c_void_p(d_out.data_ptr()), None))
+    torch.cuda.synchronize()
+    exp = orc.undistort_points(pts, K, D)
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    assert np.abs(exp - pts).max() > 5.0            # the distortion is not a no-op
+    b = np.zeros(4, np.float32)
+    fe.check(fe.lib().sd_image_bounds(640, 480, fe._p(K), fe._p(D), fe._p(b)))
+    assert np.array_equal(b, orc.image_bounds(640, 480, K, D)) and b[0] > 5 and b[1] < 635
+    Z = np.zeros(5, np.float32)
+    fe.check(fe.lib().sd_image_bounds(640, 480, fe._p(K), fe._p(Z), fe._p(b)))
+    assert b.tolist() == [0.0, 640.0, 0.0, 480.0]
+
+
+def test_undistort_keypoints_of_a_batch(gpu, fe, orc, synth):
+    import ctypes as C
+    import torch
+    cfg = synth.TUM3
+    img = synth.random_image(cfg["width"], cfg["height"], 5)
+    ex = fe.ORBextractor(1000, 1.2, 8, 20, 7)
+    b = fe.Batch(ex, cfg["width"], cfg["height"], 1)
+    b.extract_host(img[None])
+    kp, _, _ = b.download(0)
+    K = np.array([517.306408, 516.469215, 318.643040, 255.313989], np.float32)
+    D = np.array([0.262383, -0.953104, -0.005358, 0.002628, 1.163314], np.float32)
+    d_un = torch.zeros(b.cap * 28, dtype=torch.uint8, device="cuda")
+    for dist in (D, np.zeros(5, np.float32)):
+        fe.check(fe.lib().sd_batch_undistort_keypoints(b.h, 1, fe._p(K), fe._p(dist), C.c_void_p(d_un.data_ptr()), None))
+        b.sync()
+        un = d_un.cpu().numpy().view(fe.KP_DTYPE)[:len(kp)]
+        exp = kp.copy()
+        if dist[0] != 0:
+            u = orc.undistort_points(np.stack([kp["x"], kp["y"]], 1), K, dist)
+            exp["x"] = u[:, 0]; exp["y"] = u[:, 1]
+        assert un.tobytes() == exp.tobytes()
+    b.close()
