@@ -337,6 +337,11 @@ int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int heig
  * (only after a forward with n == 1). */
 int sd_yolo_download_layer(sd_yolo* y, int layer, int image, uint16_t* f16_nhwc_out);
 int sd_yolo_download_region(sd_yolo* y, float* rows, int* total_rows);
+/* Host-image forms for a per-frame caller (`yolo->Segmentation_(imLeft)`, stereo_kitti.cc:107): upload + forward of one
+ * 8-bit BGR image, and yolov3Segment::Segmentation's mask in host memory (image 0 of the last forward). */
+int sd_yolo_forward_host(sd_yolo* y, const uint8_t* bgr, int width, int height, size_t stride, float conf_threshold);
+int sd_yolo_mask_host(sd_yolo* y, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold, uint8_t* mask,
+                      size_t stride, int* no_target);
 /* yolov3Segment::Segmentation_ result for one image (yolo.cc:151-206): NMSBoxes(conf, nms), class filter
  * {person, car, bicycle, bus, truck}, box width -20 % / height +60 % about the centre.  boxes: [cap][4] x,y,w,h. */
 /* yolov3Segment::Segmentation (yolo.cc:34-58, postprocess :80-137): d_mask (frame_rows x frame_cols u8 in HBM) = 1 except

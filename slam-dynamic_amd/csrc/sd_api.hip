@@ -1734,6 +1734,8 @@ static void yolo_free(sd_yolo* y)
 {
     if (!y) return;
     for (void* p : y->owned) if (p) (void)hipFree(p);
+    if (y->d_hostImg) (void)hipFree(y->d_hostImg);
+    if (y->d_hostMask) (void)hipFree(y->d_hostMask);
     if (y->stream) (void)hipStreamDestroy(y->stream);
     delete y;
 }
@@ -2136,6 +2138,39 @@ int sd_yolo_boxes(sd_yolo* y, int image, int frame_cols, int frame_rows, float c
         *n_out = n;
         return SD_OK;
     }
+}
+
+// Host-image forms for a per-frame caller (yolo->Segmentation_(imLeft) in the example drivers): upload + forward for one image,
+// and the Segmentation mask downloaded to host memory.
+int sd_yolo_forward_host(sd_yolo* y, const uint8_t* bgr, int width, int height, size_t stride, float conf_threshold)
+{
+    if (!y || !bgr || width < 1 || height < 1 || stride < (size_t)width * 3) return set_err(SD_ERR_INVALID, "bad yolo_forward_host arguments");
+    const size_t bytes = stride * (size_t)height;
+    if (bytes > y->hostImgCap) {
+        if (y->d_hostImg) (void)hipFree(y->d_hostImg);
+        y->d_hostImg = nullptr; y->hostImgCap = 0;
+        HIPCHK(hipMalloc((void**)&y->d_hostImg, bytes));
+        y->hostImgCap = bytes;
+    }
+    HIPCHK(hipMemcpyAsync(y->d_hostImg, bgr, bytes, hipMemcpyHostToDevice, y->stream));
+    return sd_yolo_forward_device(y, y->d_hostImg, width, height, stride, bytes, 1, conf_threshold, y->stream);
+}
+
+int sd_yolo_mask_host(sd_yolo* y, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold, uint8_t* mask, size_t stride,
+                      int* no_target)
+{
+    if (!y || !mask || frame_cols < 1 || frame_rows < 1 || stride < (size_t)frame_cols) return set_err(SD_ERR_INVALID, "bad yolo_mask_host arguments");
+    const size_t bytes = (size_t)frame_cols * frame_rows;
+    if (bytes > y->hostMaskCap) {
+        if (y->d_hostMask) (void)hipFree(y->d_hostMask);
+        y->d_hostMask = nullptr; y->hostMaskCap = 0;
+        HIPCHK(hipMalloc((void**)&y->d_hostMask, bytes));
+        y->hostMaskCap = bytes;
+    }
+    int rc = sd_yolo_mask_device(y, 0, frame_cols, frame_rows, conf_threshold, nms_threshold, y->d_hostMask, (size_t)frame_cols, no_target, nullptr);
+    if (rc != SD_OK) return rc;
+    HIPCHK(hipMemcpy2D(mask, stride, y->d_hostMask, (size_t)frame_cols, (size_t)frame_cols, (size_t)frame_rows, hipMemcpyDeviceToHost));
+    return SD_OK;
 }
 
 // postprocess_ for the first n_images of the last forward pass, entirely on the device (k_yolo_nms): one launch, and

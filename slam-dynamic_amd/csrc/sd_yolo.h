@@ -19,6 +19,7 @@ struct sd_yolo {
     _Float16* d_wgt = nullptr; float* d_bias = nullptr; _Float16* d_zero = nullptr;
     short4* d_ct = nullptr; short4* d_rt = nullptr;
     SdDet* d_dets = nullptr; int* d_ndet = nullptr; float* d_raw = nullptr;
+    uint8_t* d_hostImg = nullptr; size_t hostImgCap = 0; uint8_t* d_hostMask = nullptr; size_t hostMaskCap = 0;      // sd_yolo_forward_host / mask_host
     double* d_nmsBoxes = nullptr; int* d_nmsCls = nullptr; float* d_nmsConf = nullptr; int* d_nmsN = nullptr;      // sd_yolo_boxes_batch
     int detCap = 0, totalRows = 0;
     int tabW = 0, tabH = 0;

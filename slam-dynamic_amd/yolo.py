@@ -51,6 +51,36 @@ def parse_cfg(path):
     return layers, anchors, classes
 
 
+def write_cfg(path, layers, anchors, classes=80, net_w=640, net_h=480):
+    """A Darknet .cfg with the sections of src/yolo/yolov3.cfg for the given layer list (what parse_cfg / host/yolo.h read)."""
+    with open(path, "w") as f:
+        f.write("[net]\n# Testing\nbatch=1\nsubdivisions=1\nwidth=%d\nheight=%d\nchannels=3\n\n" % (net_w, net_h))
+        for L in layers:
+            t = int(L["type"])
+            if t == CONV:
+                f.write("[convolutional]\n")
+                if L["batch_normalize"]:
+                    f.write("batch_normalize=1\n")
+                f.write("filters=%d\nsize=%d\nstride=%d\npad=1\nactivation=%s\n\n" % (L["filters"], L["size"], L["stride"], "leaky" if L["leaky"] else "linear"))
+            elif t == SHORTCUT:
+                f.write("[shortcut]\nfrom=%d\nactivation=linear\n\n" % L["from"][0])
+            elif t == ROUTE:
+                f.write("[route]\nlayers = %s\n\n" % ", ".join(str(int(v)) for v in L["from"][:L["nfrom"]]))
+            elif t == UPSAMPLE:
+                f.write("[upsample]\nstride=%d\n\n" % L["stride"])
+            elif t == YOLO:
+                f.write("[yolo]\nmask = %s\nanchors = %s\nclasses=%d\nnum=9\njitter=.3\nignore_thresh = .7\ntruth_thresh = 1\nrandom=1\n\n"
+                        % (",".join(str(int(v)) for v in L["mask"]), ",  ".join("%d,%d" % (anchors[2 * k], anchors[2 * k + 1]) for k in range(9)), classes))
+
+
+def write_darknet_weights(path, payload, major=0, minor=2, revision=0, seen=32013312):
+    """yolov3.weights layout: int32 major, minor, revision, int64 seen (major*10 + minor >= 2), then the floats."""
+    with open(path, "wb") as f:
+        f.write(np.array([major, minor, revision], np.int32).tobytes())
+        f.write(np.array([seen], np.int64 if major * 10 + minor >= 2 else np.int32).tobytes())
+        f.write(np.ascontiguousarray(payload, np.float32).tobytes())
+
+
 def v3_layers():
     """The built-in YOLOv3 layer list of the C ABI (sd_yolo_v3_layers)."""
     L = fe.lib()

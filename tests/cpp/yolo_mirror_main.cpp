@@ -1,0 +1,38 @@
+// Exercises slam-dynamic_amd/host/yolo.h (the mirror of yolov3::yolov3Segment):
+//   yolo_mirror_main <cfg> <weights> <w> <h> <bgr.raw> <out.bin>
+// writes: int32 n, n x 4 doubles (Segmentation_), int32 noTarget, w*h mask bytes (Segmentation).
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "yolo.h"
+
+int main(int argc, char** argv)
+{
+    if (argc < 7) return 2;
+    const int w = atoi(argv[3]), h = atoi(argv[4]);
+    std::vector<uint8_t> img((size_t)w * h * 3);
+    FILE* f = fopen(argv[5], "rb");
+    if (!f || fread(img.data(), 1, img.size(), f) != img.size()) return 3;
+    fclose(f);
+    bool threw = false;
+    try { yolov3::yolov3Segment missing; } catch (const std::exception&) { threw = true; }      // the reference's hard-coded paths do not exist here
+    if (!threw) return 4;
+    try {
+        yolov3::yolov3Segment yolo(argv[1], argv[2]);
+        sdfe::ImageView v; v.data = img.data(); v.cols = w; v.rows = h; v.step = (size_t)w * 3;
+        const std::vector<yolov3::Rect2d> boxes = yolo.Segmentation_(v);
+        const std::vector<uint8_t> mask = yolo.Segmentation(v);
+        FILE* o = fopen(argv[6], "wb");
+        const int32_t n = (int32_t)boxes.size();
+        fwrite(&n, 4, 1, o);
+        for (const yolov3::Rect2d& r : boxes) fwrite(&r, sizeof(double), 4, o);
+        const int32_t nt = yolo.noTarget ? 1 : 0;
+        fwrite(&nt, 4, 1, o);
+        fwrite(mask.data(), 1, mask.size(), o);
+        fclose(o);
+    } catch (const std::exception& e) {
+        fprintf(stderr, "%s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
