@@ -674,9 +674,10 @@ __global__ void __launch_bounds__(256) k_orient(const uint8_t* __restrict__ pyr,
         for (int r = 0; r < 31; r++) {
             const int vv = r - SD_HALF_PATCH;
             const int val = au <= kUmax[vv < 0 ? -vv : vv] ? vals[r] : 0;
-            m10 += u * val;
-            m01 += vv * val;
+            m10 += val;                              // u is the same for every row of this lane: one multiply after the loop
+            m01 += __mul24(vv, val);                 // |vv| <= 15, val <= 255: full-rate 24-bit multiply
         }
+        m10 = __mul24(u, m10);
     }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }

@@ -283,9 +283,9 @@ __global__ void __launch_bounds__(256) k_blur_wide(const uint8_t* __restrict__ p
 #pragma unroll
             for (int k = 0; k < 7; k++) {
                 const uint2 v = hbuf[r + k][gq];
-                const uint32_t t = (uint32_t)P.taps[k];
-                s0 += t * (v.x & 0xFFFFu); s1 += t * (v.x >> 16);
-                s2 += t * (v.y & 0xFFFFu); s3 += t * (v.y >> 16);
+                const uint32_t t = (uint32_t)P.taps[k];         // < 2^8, sums < 2^16: full-rate 24-bit multiplies (v_mul_lo_u32 is quarter rate)
+                s0 += __umul24(t, v.x & 0xFFFFu); s1 += __umul24(t, v.x >> 16);
+                s2 += __umul24(t, v.y & 0xFFFFu); s3 += __umul24(t, v.y >> 16);
             }
             const uint32_t o0 = min((s0 + 0x8000u) >> 16, 255u), o1 = min((s1 + 0x8000u) >> 16, 255u);
             const uint32_t o2 = min((s2 + 0x8000u) >> 16, 255u), o3 = min((s3 + 0x8000u) >> 16, 255u);
@@ -302,10 +302,10 @@ typedef sd_u4v sd_u128_unaligned __attribute__((aligned(1)));
 __device__ __forceinline__ uint32_t sd_gray4(uint32_t a, uint32_t b, uint32_t c, int cr, int cb)
 {
     // 12 bytes = 4 pixels x 3 channels; pixel k: bytes 3k, 3k+1, 3k+2
-    const uint32_t p0 = ((a & 255) * cr + ((a >> 8) & 255) * 9617 + ((a >> 16) & 255) * cb + 8192) >> 14;
-    const uint32_t p1 = ((a >> 24) * cr + (b & 255) * 9617 + ((b >> 8) & 255) * cb + 8192) >> 14;
-    const uint32_t p2 = (((b >> 16) & 255) * cr + (b >> 24) * 9617 + (c & 255) * cb + 8192) >> 14;
-    const uint32_t p3 = (((c >> 8) & 255) * cr + ((c >> 16) & 255) * 9617 + (c >> 24) * cb + 8192) >> 14;
+    const uint32_t p0 = (__umul24(a & 255, cr) + __umul24((a >> 8) & 255, 9617) + __umul24((a >> 16) & 255, cb) + 8192) >> 14;
+    const uint32_t p1 = (__umul24(a >> 24, cr) + __umul24(b & 255, 9617) + __umul24((b >> 8) & 255, cb) + 8192) >> 14;
+    const uint32_t p2 = (__umul24((b >> 16) & 255, cr) + __umul24(b >> 24, 9617) + __umul24(c & 255, cb) + 8192) >> 14;
+    const uint32_t p3 = (__umul24((c >> 8) & 255, cr) + __umul24((c >> 16) & 255, 9617) + __umul24(c >> 24, cb) + 8192) >> 14;
     return p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
 }
 __global__ void __launch_bounds__(256) k_cvt_gray3_wide(const uint8_t* __restrict__ src, int W, int H, size_t sstride,
