@@ -239,27 +239,30 @@ __global__ void __launch_bounds__(NT) k_fast_cells_staged(const uint8_t* __restr
 }
 
 // ------------------------------------------------------------------ Gaussian blur 7x7, wide-access version
-// Tile = 128 x 16 output pixels per 256-thread workgroup.  Horizontal pass straight from HBM with aligned
+// Tile = 128 x SD_BLUR_TR output pixels per 256-thread workgroup.  Horizontal pass straight from HBM with aligned
 // dword loads (the pyramid's own REFLECT_101 frame supplies the halo): per output pixel two
 // v_dot4_u32_u8 against the packed taps; exact 8.8 sums go to LDS as packed u16.  Vertical pass from
 // LDS (ds_read_b64), 7 mads per pixel, (sum + 0x8000) >> 16, one dword store per 4 pixels.
+#ifndef SD_BLUR_TR
+#define SD_BLUR_TR 64        // output rows per tile: (TR + 6) / TR rows are filtered horizontally (16: 1.375x, 0.42 ms per 256 images; 32: 0.36; 64: 0.345)
+#endif
 __global__ void __launch_bounds__(256) k_blur_wide(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
                                                    const SdDevPlan* __restrict__ PP)
 {
     const SdDevPlan& P = *PP;
-    __shared__ uint2 hbuf[22][32];
+    __shared__ uint2 hbuf[SD_BLUR_TR + 6][32];
     // (The XCD-aware image order of sd_xcd_image_item was measured here too: FETCH_SIZE 514 -> 203 MiB per 256 images, but
     // the kernel went from 0.47 to 0.56 ms; the dispatch order is kept.)
     const int zi = blockIdx.z;
     const int img = zi / P.nlevels, level = zi - img * P.nlevels;
     const SdLevel& g = P.lv[level];
-    const int x0 = blockIdx.x * 128, y0 = blockIdx.y * 16;
+    const int x0 = blockIdx.x * 128, y0 = blockIdx.y * SD_BLUR_TR;
     if (x0 >= g.W || y0 >= g.H) return;
     const int tid = threadIdx.x;
     const uint32_t tapsLo = (uint32_t)P.taps[0] | ((uint32_t)P.taps[1] << 8) | ((uint32_t)P.taps[2] << 16) | ((uint32_t)P.taps[3] << 24);
     const uint32_t tapsHi = (uint32_t)P.taps[4] | ((uint32_t)P.taps[5] << 8) | ((uint32_t)P.taps[6] << 16);
     const uint8_t* src = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)SD_EDGE * g.stride + SD_XOFF;
-    for (int it = tid; it < 22 * 32; it += 256) {
+    for (int it = tid; it < (SD_BLUR_TR + 6) * 32; it += 256) {
         const int r = it >> 5, gq = it & 31;
         const int y = min(y0 + r - 3, g.H + 2);
         const uint32_t* rowp = (const uint32_t*)(src + (ptrdiff_t)y * g.stride + x0 + 4 * gq - 4);
@@ -275,7 +278,7 @@ __global__ void __launch_bounds__(256) k_blur_wide(const uint8_t* __restrict__ p
     }
     __syncthreads();
     uint8_t* dst = blur + (size_t)img * P.blurImageBytes + g.blurOffset;
-    for (int it = tid; it < 16 * 32; it += 256) {
+    for (int it = tid; it < SD_BLUR_TR * 32; it += 256) {
         const int r = it >> 5, gq = it & 31;
         const int x = x0 + 4 * gq, y = y0 + r;
         if (x < g.W && y < g.H) {

@@ -442,7 +442,7 @@ int sd_batch_extract_device(sd_batch* b, const uint8_t* d_gray, size_t stride, s
         // (Running the blur on a side stream beside FAST -> quadtree -> orient was measured: no gain, the kernels
         // just stretch — the CUs are already occupied — so everything stays on one stream.)
         ProfScope ps(b, s, K_BLUR);
-        dim3 grd((P.lv[0].W + 127) / 128, (P.lv[0].H + 15) / 16, n_images * nl);
+        dim3 grd((P.lv[0].W + 127) / 128, (P.lv[0].H + SD_BLUR_TR - 1) / SD_BLUR_TR, n_images * nl);
         hipLaunchKernelGGL(k_blur_wide, grd, dim3(256), 0, s, b->d_pyr, b->d_blur, b->d_plan);
     }
     LAUNCH_CHECK("k_blur");
