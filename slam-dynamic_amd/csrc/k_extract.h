@@ -122,6 +122,7 @@ __global__ void __launch_bounds__(256) k_pyr_level(uint8_t* __restrict__ pyr, co
     const short4* rt = ct + g.W;
     const uint8_t* sbase = pyr + (size_t)img * P.pyrImageBytes + s.pyrOffset + (size_t)SD_EDGE * s.stride + SD_XOFF;
     uint8_t* dbase = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + SD_XOFF + X0;
+    const int sstride = (int)s.stride, gstride = (int)g.stride;
     short4 re[SD_PYR_ROWS];
 #pragma unroll
     for (int r = 0; r < SD_PYR_ROWS; r++) re[r] = rt[sd_reflect101(min(Yb + 4 * r, HP - 1) - SD_EDGE, g.H)];
@@ -135,8 +136,8 @@ __global__ void __launch_bounds__(256) k_pyr_level(uint8_t* __restrict__ pyr, co
             const int sy0 = re[r].x;
             const int r0 = min(max(sy0, 0), s.H - 1), r1 = min(max(sy0 + 1, 0), s.H - 1);
             // a column at the right edge has a1 == 0, so reading the byte after it (the frame) is harmless
-            w0[r] = *(const sd_u64_una*)(sbase + (size_t)r0 * s.stride + sx0);
-            w1[r] = *(const sd_u64_una*)(sbase + (size_t)r1 * s.stride + sx0);
+            w0[r] = *(const sd_u64_una*)(sbase + __mul24(r0, sstride) + sx0);     // rows < 2^12, strides < 2^12: 24-bit multiply
+            w1[r] = *(const sd_u64_una*)(sbase + __mul24(r1, sstride) + sx0);
         }
 #pragma unroll
         for (int r = 0; r < SD_PYR_ROWS; r++) {
@@ -148,7 +149,7 @@ __global__ void __launch_bounds__(256) k_pyr_level(uint8_t* __restrict__ pyr, co
                 const uint32_t p1 = sd_lerp_px((int)((a >> o1) & 255), (int)((a >> (o1 + 8)) & 255), (int)((b >> o1) & 255), (int)((b >> (o1 + 8)) & 255), c1.y, c1.z, b0, b1);
                 const uint32_t p2 = sd_lerp_px((int)((a >> o2) & 255), (int)((a >> (o2 + 8)) & 255), (int)((b >> o2) & 255), (int)((b >> (o2 + 8)) & 255), c2.y, c2.z, b0, b1);
                 const uint32_t p3 = sd_lerp_px((int)((a >> o3) & 255), (int)((a >> (o3 + 8)) & 255), (int)((b >> o3) & 255), (int)((b >> (o3 + 8)) & 255), c3.y, c3.z, b0, b1);
-                *(uint32_t*)(dbase + (size_t)Yp * g.stride) = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
+                *(uint32_t*)(dbase + __mul24(Yp, gstride)) = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
             }
         }
     } else {
@@ -165,15 +166,15 @@ __global__ void __launch_bounds__(256) k_pyr_level(uint8_t* __restrict__ pyr, co
             if (Yp < HP) {
                 const int sy0 = re[r].x, b0 = re[r].y, b1 = re[r].z;
                 const int r0 = min(max(sy0, 0), s.H - 1), r1 = min(max(sy0 + 1, 0), s.H - 1);
-                const uint8_t* S0 = sbase + (size_t)r0 * s.stride;
-                const uint8_t* S1 = sbase + (size_t)r1 * s.stride;
+                const uint8_t* S0 = sbase + __mul24(r0, sstride);
+                const uint8_t* S1 = sbase + __mul24(r1, sstride);
                 uint32_t pack = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int sx = ce[k].x, sx1 = min(sx + 1, s.W - 1);
                     pack |= (uint32_t)sd_lerp_px(S0[sx], S0[sx1], S1[sx], S1[sx1], ce[k].y, ce[k].z, b0, b1) << (8 * k);
                 }
-                *(uint32_t*)(dbase + (size_t)Yp * g.stride) = pack;
+                *(uint32_t*)(dbase + __mul24(Yp, gstride)) = pack;
             }
         }
     }
