@@ -535,11 +535,13 @@ __global__ void __launch_bounds__(256) k_proj_candidates(
         }
     }
     if (n > SD_PROJ_K) { if (lane == 0) atomicOr(errFlag, 4); n = SD_PROJ_K; }
-    // wave-wide bitonic sort of <= 64 keys (one per lane), ascending
+    // wave-wide bitonic sort of <= 64 keys (one per lane), ascending.  The keys sit in lanes 0 .. n-1 (the rest hold the
+    // maximum), so a network over the first m = 2^ceil(log2 n) lanes is enough: windows hold ~5-15 candidates, which
+    // makes this 6-10 compare-exchange stages instead of 21.
     unsigned long long key = lane < n ? s_keys[wv][lane] : ~0ull;
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1)
-#pragma unroll
+    int m = 2;
+    while (m < n) m <<= 1;
+    for (int k = 2; k <= m && n > 1; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)key, j, 64);
             const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(key >> 32), j, 64);
