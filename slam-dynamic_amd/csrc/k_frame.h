@@ -704,11 +704,12 @@ struct SdTrack { float projX, projY, projXR, viewCos; int level; int inView; }; 
 __device__ __forceinline__ float sd_logf_cr(float x) { return (float)log((double)x); }
 
 // wave-wide ascending bitonic sort of one 64-bit key per lane
-__device__ __forceinline__ unsigned long long sd_wave_sort64(unsigned long long key, int lane)
+// (keys occupy lanes 0 .. n-1, the other lanes hold the maximum: a network over the first 2^ceil(log2 n) lanes suffices)
+__device__ __forceinline__ unsigned long long sd_wave_sort64(unsigned long long key, int lane, int n = 64)
 {
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1)
-#pragma unroll
+    int m = 2;
+    while (m < n) m <<= 1;
+    for (int k = 2; k <= m && n > 1; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)key, j, 64);
             const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(key >> 32), j, 64);
@@ -862,7 +863,7 @@ __global__ void __launch_bounds__(256) k_local_candidates(
                 const int h = __popcll(hm);
                 if (nbuf + h > SD_PROJ_K) {        // flush the waiting keys into the running best-64
                     unsigned long long kb = lane < nbuf ? s_keys[wv][lane] : ~0ull;
-                    kb = sd_wave_sort64(kb, lane);
+                    kb = sd_wave_sort64(kb, lane, nbuf);
                     best = sd_wave_merge_low64(best, kb, lane);
                     nbuf = 0;
                 }
@@ -871,7 +872,7 @@ __global__ void __launch_bounds__(256) k_local_candidates(
                 total_hits += h;
             }
             unsigned long long kb = lane < nbuf ? s_keys[wv][lane] : ~0ull;
-            kb = sd_wave_sort64(kb, lane);
+            kb = sd_wave_sort64(kb, lane, nbuf);
             best = sd_wave_merge_low64(best, kb, lane);
         }
     }
