@@ -439,8 +439,9 @@ int sd_batch_extract_device(sd_batch* b, const uint8_t* d_gray, size_t stride, s
     }
     LAUNCH_CHECK("k_pyr_level");
     {
-        // (Running the blur on a side stream beside FAST -> quadtree -> orient was measured: no gain, the kernels
-        // just stretch — the CUs are already occupied — so everything stays on one stream.)
+        // (Running the blur on a side stream was measured twice: forked after the pyramid (beside FAST) no gain; forked after
+        // FAST so that it runs beside the quadtree both kernels stretch (0.45 + 0.35 ms -> 0.73 ms together): +0.8 % frames/s,
+        // not worth a second stream and overlapped per-kernel timings — everything stays on one stream.)
         ProfScope ps(b, s, K_BLUR);
         dim3 grd((P.lv[0].W + 127) / 128, (P.lv[0].H + SD_BLUR_TR - 1) / SD_BLUR_TR, n_images * nl);
         hipLaunchKernelGGL(k_blur_wide, grd, dim3(256), 0, s, b->d_pyr, b->d_blur, b->d_plan);
