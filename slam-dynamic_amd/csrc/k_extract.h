@@ -62,6 +62,8 @@ __device__ __forceinline__ bool sd_xcd_image_item(unsigned id, int perImage, int
 // interior columns are one (unaligned) dword load; only the 19-px frame takes the per-byte reflect path.
 typedef uint32_t __attribute__((aligned(1))) sd_u32_una;
 typedef unsigned long long __attribute__((aligned(1))) sd_u64_una;
+typedef uint32_t sd_u4v __attribute__((ext_vector_type(4)));
+typedef sd_u4v sd_u128_unaligned __attribute__((aligned(1)));       // the hardware takes unaligned dwordx4 accesses
 
 __global__ void __launch_bounds__(256) k_pyr_level0(const uint8_t* __restrict__ gray, size_t gstride, size_t gpitch,
                                                     uint8_t* __restrict__ pyr, const SdDevPlan* __restrict__ PP)
@@ -176,6 +178,106 @@ __global__ void __launch_bounds__(256) k_pyr_level(uint8_t* __restrict__ pyr, co
                 }
                 *(uint32_t*)(dbase + __mul24(Yp, gstride)) = pack;
             }
+        }
+    }
+}
+
+// A pyramid level through LDS, frame included: a 256-thread workgroup produces TW x TH pixels of the PADDED plane (padded
+// coordinate (Xp, Yp) <-> interior pixel (reflect101(Xp - 19), reflect101(Yp - 19)), i.e. resize followed by
+// copyMakeBorder(BORDER_REFLECT_101) in one pass, as k_pyr_level does).
+//   A  the source rows / columns the tile needs are staged with unaligned 16-byte loads (coalesced);
+//   B  horizontal pass once per SOURCE row (each is used by ~1.7 destination rows): h = S[sx]*a0 + S[sx+1]*a1, kept as
+//      h >> 4 (< 2^15) in a u16 plane; a thread keeps its four column-table entries for all its rows; groups whose four
+//      columns ascend within 6 source bytes (all but the ones on the reflected frame) extract from one 64-bit window;
+//   C  vertical pass from the u16 plane, 8 pixels per thread, one 8-byte store.
+// Same integer arithmetic as sd_lerp_px.  ~4x fewer memory instructions per pixel than k_pyr_level (no per-thread table
+// loads, 16-byte source loads, 8-byte stores) and no latency-bound frame strips.
+#define SD_PT_XSHIFT 5
+template <int TW, int TH>
+__global__ void __launch_bounds__(256) k_pyr_level_tiles(uint8_t* __restrict__ pyr, const short4* __restrict__ tabs,
+                                                         const SdDevPlan* __restrict__ PP, int level, int srcRowBytes, int srcRowsMax,
+                                                         const int* __restrict__ ext)
+{
+    const SdDevPlan& P = *PP;
+    const SdLevel& g = P.lv[level];
+    const SdLevel& s = P.lv[level - 1];
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint8_t* sS = smem;                                                        // [srcRowsMax][srcRowBytes]
+    unsigned short* sH = (unsigned short*)(smem + (size_t)srcRowsMax * srcRowBytes);      // [srcRowsMax][TW]
+    const int img = blockIdx.z, tid = threadIdx.x;
+    // tile origin: padded column -SD_PT_XSHIFT + bx*TW, so that the 8-byte stores of phase C fall on 8-byte addresses (the
+    // padded plane starts SD_XOFF - 19 = 13 bytes into the row; columns < 0 land in the unused left margin)
+    const int Xp0 = (int)blockIdx.x * TW - SD_PT_XSHIFT, Yp0 = blockIdx.y * TH;
+    const int PW = g.W + 2 * SD_EDGE, HP = g.H + 2 * SD_EDGE;
+    const short4* ct = tabs + g.tabOffset;
+    const short4* rt = ct + g.W;
+    const int sstride = s.stride, gstride = g.stride;
+    const uint8_t* sbase = pyr + (size_t)img * P.pyrImageBytes + s.pyrOffset + (size_t)SD_EDGE * s.stride + SD_XOFF;
+    // extents of the source region, precomputed on the host (the reflection makes them non-monotone on the frame)
+    const int sxA = ext[blockIdx.x], syA = ext[gridDim.x + 2 * blockIdx.y], nrows = ext[gridDim.x + 2 * blockIdx.y + 1];
+    // ---- A
+    const int cpr = srcRowBytes >> 4;
+    for (int c = tid; c < nrows * cpr; c += 256) {
+        const int r = c / cpr, q = c - r * cpr;
+        *(sd_u4v*)(sS + r * srcRowBytes + 16 * q) = *(const sd_u128_unaligned*)(sbase + __mul24(syA + r, sstride) + sxA + 16 * q);
+    }
+    __syncthreads();
+    // ---- B
+    {
+        constexpr int NG = TW / 4, STEP = 256 / NG;
+        const int gq = tid % NG;
+        short4 c[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) c[k] = ct[sd_reflect101(min(max(Xp0 + 4 * gq + k, 0), PW - 1) - SD_EDGE, g.W)];
+        const int o0 = c[0].x - sxA;
+        const int d1 = c[1].x - c[0].x, d2 = c[2].x - c[0].x, d3 = c[3].x - c[0].x;
+        const bool window = d1 >= 0 && d2 >= d1 && d3 >= d2 && d3 <= 6;          // per lane; false only on the reflected frame
+        const int sh = o0 & 3;
+        for (int r = tid / NG; r < nrows; r += STEP) {
+            const uint8_t* row = sS + r * srcRowBytes;
+            int h[4];
+            if (window) {
+                const uint32_t* p = (const uint32_t*)(row + (o0 & ~3));
+                const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+                const unsigned long long a = ((unsigned long long)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32) | __builtin_amdgcn_alignbyte(w1, w0, sh);
+                h[0] = __mul24((int)(a & 255), c[0].y) + __mul24((int)((a >> 8) & 255), c[0].z);
+                h[1] = __mul24((int)((a >> (8 * d1)) & 255), c[1].y) + __mul24((int)((a >> (8 * d1 + 8)) & 255), c[1].z);
+                h[2] = __mul24((int)((a >> (8 * d2)) & 255), c[2].y) + __mul24((int)((a >> (8 * d2 + 8)) & 255), c[2].z);
+                h[3] = __mul24((int)((a >> (8 * d3)) & 255), c[3].y) + __mul24((int)((a >> (8 * d3 + 8)) & 255), c[3].z);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int o = c[k].x - sxA;           // the byte after the last source column has weight a1 == 0
+                    h[k] = __mul24((int)row[o], c[k].y) + __mul24((int)row[o + 1], c[k].z);
+                }
+            }
+            *(uint2*)(sH + r * TW + 4 * gq) = make_uint2((uint32_t)(h[0] >> 4) | ((uint32_t)(h[1] >> 4) << 16), (uint32_t)(h[2] >> 4) | ((uint32_t)(h[3] >> 4) << 16));
+        }
+    }
+    __syncthreads();
+    // ---- C
+    {
+        constexpr int NG = TW / 8, STEP = 256 / NG;
+        const int gq = tid % NG;
+        if (Xp0 + 8 * gq >= PW) return;                                            // no barrier below
+        uint8_t* dbase = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (SD_XOFF - SD_EDGE) + Xp0 + 8 * gq;
+        for (int Y = tid / NG; Y < TH; Y += STEP) {
+            const int Yp = Yp0 + Y;
+            if (Yp >= HP) break;
+            const short4 re = rt[sd_reflect101(Yp - SD_EDGE, g.H)];
+            const int r0 = min(max((int)re.x, 0), s.H - 1) - syA, r1 = min(max((int)re.x + 1, 0), s.H - 1) - syA;
+            const int b0 = re.y, b1 = re.z;
+            const uint4 u0 = *(const uint4*)(sH + r0 * TW + 8 * gq), u1 = *(const uint4*)(sH + r1 * TW + 8 * gq);
+            const uint32_t hh0[4] = {u0.x, u0.y, u0.z, u0.w}, hh1[4] = {u1.x, u1.y, u1.z, u1.w};
+            uint32_t out[2] = {0u, 0u};
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int a0 = (int)((hh0[k >> 1] >> (16 * (k & 1))) & 0xFFFFu), a1 = (int)((hh1[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+                const uint32_t v = (uint32_t)((((__mul24(b0, a0) >> 16) + (__mul24(b1, a1) >> 16) + 2) >> 2) & 255);
+                out[k >> 2] |= v << (8 * (k & 3));
+            }
+            // a group that runs past the padded width spills into the row's slack / the next row's unused left margin
+            *(uint2*)(dbase + __mul24(Yp, gstride)) = make_uint2(out[0], out[1]);
         }
     }
 }

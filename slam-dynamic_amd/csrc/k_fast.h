@@ -300,8 +300,6 @@ __global__ void __launch_bounds__(256) k_blur_wide(const uint8_t* __restrict__ p
 // ------------------------------------------------------------------ cvtColor -> gray, 16 px per thread: three unaligned
 // 16-byte loads (48 bytes = 16 pixels x 3 channels) and one 16-byte store; rows of 1241 pixels are never aligned, the
 // hardware takes unaligned dwordx4 accesses.
-typedef uint32_t sd_u4v __attribute__((ext_vector_type(4)));
-typedef sd_u4v sd_u128_unaligned __attribute__((aligned(1)));
 __device__ __forceinline__ uint32_t sd_gray4(uint32_t a, uint32_t b, uint32_t c, int cr, int cb)
 {
     // 12 bytes = 4 pixels x 3 channels; pixel k: bytes 3k, 3k+1, 3k+2

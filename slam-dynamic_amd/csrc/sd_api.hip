@@ -36,7 +36,13 @@ static const char* kKernelNames[K_COUNT] = {"k_pyr_level0", "k_pyr_level", "k_fa
                                             "k_grid_cells", "k_unproject", "k_proj_candidates", "k_proj_resolve",
                                             "k_box_separate", "k_separate", "k_update_frame", "k_local_candidates", "k_local_resolve", "k_bow_transform", "k_bow_finalize", "k_search_by_bow", "k_motion_prepare", "k_motion_hyp", "k_motion_select"};
 
+#define SD_PT_TW 256
+#define SD_PT_TH 16
+struct SdPyrTiles { int tilesX = 0, tilesY = 0, srcRowBytes = 0, srcRowsMax = 0, extOff = 0; size_t lds = 0; bool use = false; };
+
 struct sd_batch {
+    std::vector<SdPyrTiles> pyrTiles;      // per level: tile grid of k_pyr_level_tiles
+    int* d_pyrExt = nullptr;
     sd_extractor* ex = nullptr;
     SdPlan plan;
     SdDevPlan hplan;
@@ -217,7 +223,7 @@ static void batch_free(sd_batch* b)
                     b->d_sepPairs, b->d_kpD, b->d_descD, b->d_urD, b->d_depD, b->d_rowIdx, b->d_rowStart,
                     b->d_lmCand, b->d_lmN, b->d_lmOvf, b->d_lmIdx, b->d_bowWordF, b->d_bowWF, b->d_bowNidF, b->d_fvNode, b->d_fvFeat,
                     b->d_fvRunStart, b->d_fvRunNode, b->d_bowWord, b->d_bowVal, b->d_bowMeta, b->d_bowImg,
-                    b->d_moPts, b->d_moNorm, b->d_moCounts, b->d_moMaskH, b->d_moMaskF, b->d_moRes};
+                    b->d_moPts, b->d_moNorm, b->d_moCounts, b->d_moMaskH, b->d_moMaskF, b->d_moRes, b->d_pyrExt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& r : b->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : b->pool) (void)hipEventDestroy(e);
@@ -431,11 +437,58 @@ int sd_batch_extract_device(sd_batch* b, const uint8_t* d_gray, size_t stride, s
         hipLaunchKernelGGL(k_pyr_level0, grd, blk, 0, s, d_gray, stride, image_pitch, b->d_pyr, b->d_plan);
     }
     LAUNCH_CHECK("k_pyr_level0");
+    if (b->pyrTiles.empty()) {          // once per batch: LDS extents of k_pyr_level_tiles per level, or the per-thread kernel as a fallback
+        b->pyrTiles.assign(nl, SdPyrTiles());
+        auto refl = [](int p, int len) { if (p < 0) p = -p; if (p >= len) p = 2 * (len - 1) - p; return p; };
+        std::vector<int> ext;             // per level: source column origin of every tile column, (row origin, rows) of every tile row
+        for (int l = 1; l < nl; l++) {
+            const SdLevel& g = P.lv[l];
+            const int16_t* ct = &P.tabs[4 * (size_t)g.tabOffset];
+            const int16_t* rt = ct + 4 * (size_t)g.W;
+            const int PW = g.W + 2 * SD_EDGE, HPl = g.H + 2 * SD_EDGE, sH = P.lv[l - 1].H;
+            SdPyrTiles t;
+            t.tilesX = (PW + SD_PT_XSHIFT + SD_PT_TW - 1) / SD_PT_TW; t.tilesY = (HPl + SD_PT_TH - 1) / SD_PT_TH;
+            t.extOff = (int)ext.size();
+            int spanX = 0, spanY = 0;
+            for (int tx = 0; tx < t.tilesX; tx++) {
+                int lo = 1 << 30, hi = -1;
+                for (int k = 0; k < SD_PT_TW; k++) {
+                    const int sx = ct[4 * refl(std::min(std::max(tx * SD_PT_TW - SD_PT_XSHIFT + k, 0), PW - 1) - SD_EDGE, g.W)];
+                    lo = std::min(lo, sx); hi = std::max(hi, sx);
+                }
+                spanX = std::max(spanX, hi - lo + 2);
+                ext.push_back(lo);
+            }
+            for (int ty = 0; ty < t.tilesY; ty++) {
+                int lo = 1 << 30, hi = -1;
+                for (int k = 0; k < SD_PT_TH; k++) {
+                    const int sy = rt[4 * refl(std::min(ty * SD_PT_TH + k, HPl - 1) - SD_EDGE, g.H)];
+                    lo = std::min(lo, std::min(std::max(sy, 0), sH - 1)); hi = std::max(hi, std::min(std::max(sy + 1, 0), sH - 1));
+                }
+                spanY = std::max(spanY, hi - lo + 1);
+                ext.push_back(lo); ext.push_back(hi - lo + 1);
+            }
+            t.srcRowBytes = (spanX + 16 + 15) & ~15; t.srcRowsMax = spanY;
+            t.lds = (size_t)t.srcRowsMax * t.srcRowBytes + (size_t)t.srcRowsMax * SD_PT_TW * 2;
+            t.use = t.lds <= 48 * 1024 && g.W >= 40 && g.H >= 40;
+            b->pyrTiles[l] = t;
+        }
+        if (!ext.empty()) {
+            HIPCHK(hipMalloc((void**)&b->d_pyrExt, ext.size() * 4));
+            HIPCHK(hipMemcpy(b->d_pyrExt, ext.data(), ext.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
     for (int l = 1; l < nl; l++) {
         ProfScope ps(b, s, K_PYR);
         const SdLevel& g = P.lv[l];
-        dim3 blk(64, 4), grd(((g.W + 39 + 3) / 4 + 63) / 64, (g.H + 2 * SD_EDGE + 4 * SD_PYR_ROWS - 1) / (4 * SD_PYR_ROWS), n_images);
-        hipLaunchKernelGGL(k_pyr_level, grd, blk, 0, s, b->d_pyr, (const short4*)b->d_tabs, b->d_plan, l);
+        const SdPyrTiles& t = b->pyrTiles[l];
+        if (t.use) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pyr_level_tiles<SD_PT_TW, SD_PT_TH>), dim3(t.tilesX, t.tilesY, n_images), dim3(256), t.lds, s, b->d_pyr,
+                               (const short4*)b->d_tabs, b->d_plan, l, t.srcRowBytes, t.srcRowsMax, b->d_pyrExt + t.extOff);
+        } else {                         // resize ratios too large for the LDS tile: one thread per 4 pixels x 4 rows
+            dim3 blk(64, 4), grd(((g.W + 39 + 3) / 4 + 63) / 64, (g.H + 2 * SD_EDGE + 4 * SD_PYR_ROWS - 1) / (4 * SD_PYR_ROWS), n_images);
+            hipLaunchKernelGGL(k_pyr_level, grd, blk, 0, s, b->d_pyr, (const short4*)b->d_tabs, b->d_plan, l);
+        }
     }
     LAUNCH_CHECK("k_pyr_level");
     {
