@@ -76,3 +76,23 @@ def test_batch_slots_are_independent(gpu, fe, synth):
     k0b, d0b, _ = b.download(0)
     assert k0.tobytes() == k0b.tobytes() and d0.tobytes() == d0b.tobytes()
     b.close()
+
+
+@pytest.mark.parametrize("scale,levels", [(1.5, 5), (2.0, 3), (1.1, 6), (2.5, 3)])
+def test_other_scale_factors(gpu, fe, orc, synth, scale, levels):
+    """Settings files may choose any ORBextractor.scaleFactor / nLevels: the LDS pyramid tiles (wide source windows, the
+    non-window extraction path above a ratio of 2) and the per-thread fallback must stay bit-exact."""
+    w, h, nf = 752, 480, 800
+    img = synth.random_image(w, h, 91, "texture")
+    ex = fe.ORBextractor(nf, scale, levels, 20, 7)
+    b = fe.Batch(ex, w, h, 1)
+    b.extract_host(img[None])
+    o = orc.Extractor(nf, scale, levels, 20, 7)
+    rk, rd = o(img)
+    for l in range(levels):
+        assert np.array_equal(b.pyramid(0, l), o.pyramid(l)), "pyramid level %d" % l
+    kp, desc, per_level = b.download(0)
+    assert np.array_equal(per_level, o.per_level)
+    assert_kp_equal(kp, rk, "scale %.1f" % scale)
+    assert np.array_equal(desc, rd)
+    b.close()
