@@ -242,9 +242,11 @@ def main():
         fr = [synth.rgbd_frame(seq + 100 * (t // 128), t % 128, cfg) for t in range(B)]      # a synthetic sequence is valid for ~128 frames (zoom 1.01^t)
         d_rgb = torch.from_numpy(np.stack([f[0] for f in fr])).to(dev)
         d_depth = torch.from_numpy(np.stack([f[1] for f in fr]).view(np.int16)).to(dev)
-        d_gray = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+        Wg = (W + 63) // 64 * 64                        # the gray plane is this pipeline's own intermediate: 64-byte aligned rows
+        d_gray = torch.empty((B, H, Wg), dtype=torch.uint8, device=dev)
     else:
         fr = [synth.stereo_frame(seq + 100 * (t // 128), t % 128, cfg) for t in range(B)]
+        Wg = W                                           # stereo inputs arrive as tight 8-bit images
         d_gray = torch.from_numpy(np.stack([im for f in fr for im in (f[0], f[1])])).to(dev)
     del fr
 
@@ -358,8 +360,8 @@ def main():
         f0 = k * Bs
         g0 = d_gray[f0 * imgs_per_frame:]
         if args.workload == "rgbd":
-            fe.cvt_gray_device(d_rgb[f0:].data_ptr(), W, H, W * 3, W * H * 3, 3, 1, g0.data_ptr(), W, W * H, Bs, st)
-        bt.extract_device(g0.data_ptr(), W, W * H, n_img, st)
+            fe.cvt_gray_device(d_rgb[f0:].data_ptr(), W, H, W * 3, W * H * 3, 3, 1, g0.data_ptr(), Wg, Wg * H, Bs, st)
+        bt.extract_device(g0.data_ptr(), Wg, Wg * H, n_img, st)
         if args.workload == "rgbd":
             bt.rgbd_from_u16(d_depth[f0:].data_ptr(), W, W * H, Bs, depth_factor, cfg["bf"], st)
         else:

@@ -43,9 +43,6 @@ __device__ __forceinline__ int sd_reflect101(int p, int len)
     return p;
 }
 
-// ------------------------------------------------------------------ pyramid, level 0
-// Padded copy of the gray input with BORDER_REFLECT_101 (ORBextractor.cc:1127-1128).
-// Thread = 4 consecutive padded pixels (one aligned u32 store); block 64x4.  Groups that lie inside the
 // XCD-aware work order for per-image kernels.  Workgroups are dispatched round-robin over the 8 XCDs (id % 8) and every
 // XCD has its own L2, so a 1-D grid is decoded as (image group, item, XCD): XCD x processes images x, x + 8, ... and the
 // items of one image (neighbouring tiles / cells / keypoints, which share cache lines and halos) meet in ONE L2 instead of
@@ -59,12 +56,16 @@ __device__ __forceinline__ bool sd_xcd_image_item(unsigned id, int perImage, int
     return img < nImages;
 }
 
-// interior columns are one (unaligned) dword load; only the 19-px frame takes the per-byte reflect path.
 typedef uint32_t __attribute__((aligned(1))) sd_u32_una;
 typedef unsigned long long __attribute__((aligned(1))) sd_u64_una;
 typedef uint32_t sd_u4v __attribute__((ext_vector_type(4)));
 typedef sd_u4v sd_u128_unaligned __attribute__((aligned(1)));       // the hardware takes unaligned dwordx4 accesses
 
+// ------------------------------------------------------------------ pyramid, level 0
+// Padded copy of the gray input with BORDER_REFLECT_101 (ORBextractor.cc:1127-1128).
+// Thread = 16 consecutive bytes of a padded row (one ALIGNED 16-byte store: the interior starts SD_XOFF = 32 bytes into the
+// row); block 64x4.  Groups inside the interior are one 16-byte load (aligned too when the caller's gray rows are 16-byte
+// multiples); only the groups on the 19-px frame take the per-byte reflect path.
 __global__ void __launch_bounds__(256) k_pyr_level0(const uint8_t* __restrict__ gray, size_t gstride, size_t gpitch,
                                                     uint8_t* __restrict__ pyr, const SdDevPlan* __restrict__ PP)
 {
@@ -74,23 +75,25 @@ __global__ void __launch_bounds__(256) k_pyr_level0(const uint8_t* __restrict__ 
     const int gx = blockIdx.x * 64 + threadIdx.x;
     const int Yp = blockIdx.y * 4 + threadIdx.y;          // padded row 0 .. H+37
     if (Yp >= g.H + 2 * SD_EDGE) return;
-    const int X0 = -20 + 4 * gx;                           // first interior-relative column of this u32
+    const int X0 = -SD_XOFF + 16 * gx;                     // first interior-relative column of this 16-byte group
     if (X0 > g.W + SD_EDGE - 1) return;
     const int sy = sd_reflect101(Yp - SD_EDGE, g.H);
     const uint8_t* srow = gray + (size_t)img * gpitch + (size_t)sy * gstride;
-    uint32_t pack = 0;
-    if (X0 >= 0 && X0 + 3 < g.W) {
-        pack = *(const sd_u32_una*)(srow + X0);
+    sd_u4v pack;
+    if (X0 >= 0 && X0 + 15 < g.W) {
+        pack = *(const sd_u128_unaligned*)(srow + X0);
     } else {
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 16; k++) {
             int X = X0 + k;
-            X = X < -SD_EDGE ? -SD_EDGE : (X > g.W + SD_EDGE - 1 ? g.W + SD_EDGE - 1 : X);
-            pack |= (uint32_t)srow[sd_reflect101(X, g.W)] << (8 * k);
+            X = X < -SD_EDGE ? -SD_EDGE : (X > g.W + SD_EDGE - 1 ? g.W + SD_EDGE - 1 : X);     // margin bytes: any value
+            w[k >> 2] |= (uint32_t)srow[sd_reflect101(X, g.W)] << (8 * (k & 3));
         }
+        pack.x = w[0]; pack.y = w[1]; pack.z = w[2]; pack.w = w[3];
     }
     uint8_t* drow = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)Yp * g.stride;
-    *(uint32_t*)(drow + SD_XOFF + X0) = pack;
+    *(sd_u4v*)(drow + SD_XOFF + X0) = pack;
 }
 
 // ------------------------------------------------------------------ pyramid, level >= 1

@@ -433,7 +433,7 @@ int sd_batch_extract_device(sd_batch* b, const uint8_t* d_gray, size_t stride, s
     {
         ProfScope ps(b, s, K_PYR0);
         const SdLevel& g = P.lv[0];
-        dim3 blk(64, 4), grd(((g.W + 39 + 3) / 4 + 63) / 64, (g.H + 2 * SD_EDGE + 3) / 4, n_images);
+        dim3 blk(64, 4), grd(((g.W + SD_XOFF + SD_EDGE + 15) / 16 + 63) / 64, (g.H + 2 * SD_EDGE + 3) / 4, n_images);
         hipLaunchKernelGGL(k_pyr_level0, grd, blk, 0, s, d_gray, stride, image_pitch, b->d_pyr, b->d_plan);
     }
     LAUNCH_CHECK("k_pyr_level0");
