@@ -31,7 +31,7 @@ struct SdDevPlan {               // lives in HBM; every kernel gets a pointer to
     int taps[7];
 };
 
-__constant__ signed char c_pattern[1024] = {
+__constant__ __attribute__((aligned(4))) signed char c_pattern[1024] = {
 #include "orb_pattern.inc"
 };
 
@@ -898,8 +898,9 @@ __global__ void __launch_bounds__(256) k_describe(const uint8_t* __restrict__ bl
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int pi = 4 * (lane + 64 * r);
-        const float x0 = (float)c_pattern[pi], y0 = (float)c_pattern[pi + 1];
-        const float x1 = (float)c_pattern[pi + 2], y1 = (float)c_pattern[pi + 3];
+        const uint32_t pq = *(const uint32_t*)(c_pattern + pi);            // one dword = (x0, y0, x1, y1) as int8
+        const float x0 = (float)(signed char)(pq & 255u), y0 = (float)(signed char)((pq >> 8) & 255u);
+        const float x1 = (float)(signed char)((pq >> 16) & 255u), y1 = (float)(signed char)(pq >> 24);
         const int iy0 = __float2int_rn(x0 * b + y0 * a), ix0 = __float2int_rn(x0 * a - y0 * b);
         const int iy1 = __float2int_rn(x1 * b + y1 * a), ix1 = __float2int_rn(x1 * a - y1 * b);
         const int t0 = center[iy0 * SD_DP_W + ix0];
