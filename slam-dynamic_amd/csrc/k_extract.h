@@ -661,7 +661,9 @@ __global__ void __launch_bounds__(256, 4) k_quadtree(const uint32_t* __restrict_
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int s_wsum[8];
     __shared__ int s_scal[4];
-    const int level = blockIdx.x, img = blockIdx.y;
+    // longest work first: all images' level 0 (the most candidates), then level 1, ... so that the short high levels fill
+    // the slots the level-0 workgroups leave, instead of every image's level 0 heading a round of its own
+    const int level = blockIdx.y, img = blockIdx.x;
     const SdLevel& g = P.lv[level];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     SdQtLds S;

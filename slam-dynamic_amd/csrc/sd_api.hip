@@ -521,7 +521,7 @@ int sd_batch_extract_device(sd_batch* b, const uint8_t* d_gray, size_t stride, s
     LAUNCH_CHECK("k_fast_cells");
     {
         ProfScope ps(b, s, K_QTREE);
-        dim3 grd(nl, n_images);
+        dim3 grd(n_images, nl);
         hipLaunchKernelGGL(k_quadtree, grd, dim3(256), b->qtLds, s, b->d_cellList, b->d_cellCount, b->d_cells, b->d_cand,
                            b->d_nodeOf, b->d_lvlCount, b->d_candCount, b->d_lvlKp, b->d_err, b->d_plan, b->qtMN, b->qtSortP);
     }
