@@ -41,7 +41,7 @@ __device__ __forceinline__ int sd_wave_append(bool pred, int* counter)
 // 1.02 ms per 256 images here vs 1.48 ms (128 threads x 2 cells), 1.15 ms (256 x 2), 1.61 ms (256 x 4): the LDS footprint
 // halves the cells in flight per CU and the phases do not shrink.)
 template <int NT>
-__global__ void __launch_bounds__(NT) k_fast_cells_staged(const uint8_t* __restrict__ pyr,
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) k_fast_cells_staged(const uint8_t* __restrict__ pyr,
                                                           const SdCell* __restrict__ cells,
                                                           uint32_t* __restrict__ cellList, int* __restrict__ cellCount,
                                                           const SdDevPlan* __restrict__ PP, int listCapArg)
