@@ -126,21 +126,21 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 const int nvalid = sw - 4 * gq;                               // pixels of this group inside the scan
                 if (nvalid < 4) pmask &= (1u << nvalid) - 1u;
             }
-            // one slot reservation per wave: exclusive scan of the per-lane counts, then up to 4 writes
-            const int cnt = __popc(pmask);
-            int incl = cnt;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-            const int wtot = __shfl(incl, 63, 64);
-            int base = 0;
+            // one slot reservation per wave: the four candidate bits of a lane go out bit plane by bit plane (ballot + mbcnt,
+            // ~5 VALU each) instead of through a six-step prefix scan of the per-lane counts; list order is free
+            const unsigned long long b0 = __ballot(pmask & 1u), b1 = __ballot(pmask & 2u), b2 = __ballot(pmask & 4u), b3 = __ballot(pmask & 8u);
+            const int c0 = __popcll(b0), c1 = __popcll(b1), c2 = __popcll(b2), c3 = __popcll(b3);
+            const int wtot = c0 + c1 + c2 + c3;
             if (wtot) {
-                if (lane == 63) base = atomicAdd(&s_cnt1, wtot);
-                base = __shfl(base, 63, 64);
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_cnt1, wtot);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const unsigned short e0 = (unsigned short)((sy << 8) | (4 * gq));
+                if (pmask & 1u) list1[base + __builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, 0u))] = e0;
+                if (pmask & 2u) list1[base + c0 + __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0u))] = e0 + 1;
+                if (pmask & 4u) list1[base + c0 + c1 + __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b2, 0u))] = e0 + 2;
+                if (pmask & 8u) list1[base + c0 + c1 + c2 + __builtin_amdgcn_mbcnt_hi((unsigned)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b3, 0u))] = e0 + 3;
             }
-            int slot = base + incl - cnt;
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (pmask & (1u << j)) list1[slot++] = (unsigned short)((sy << 8) | (4 * gq + j));
         }
         __syncthreads();
         // ---- phase 2: exact ring test on the survivors
