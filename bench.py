@@ -311,7 +311,8 @@ def main():
         det = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=B)
         det.load_weights(pkg.yolo.synth_weights(layers, seed=3)[0])
         d_bgr = d_gray.view(B, 2, H, W)[:, 0].unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()      # the left image as 3 channels
-        yolo_state = dict(last=None, n_boxes=0)
+        yolo_state = dict(last=None, n_boxes=0, in_flight=False)
+        det_stream = torch.cuda.Stream(device=dev)
     recs, gatherer = None, None
     if dist is not None:
         recs = []
@@ -323,10 +324,16 @@ def main():
     def run_yolo_step(first):
         """BASELINE configs[2], one batch of B consecutive stereo frames (frame i's reference frame is frame i-2, 0.2 s back)."""
         bt, st = batch, main_stream.cuda_stream
-        det.forward_device(d_bgr.data_ptr(), W, H, W * 3, W * H * 3, B, 0.5, st)            # yolo->Segmentation_(imLeft)
+        # The detector (MFMA-bound) runs on its own stream, one batch AHEAD of the front end (VALU / latency-bound kernels + the
+        # host's boxTrack recurrence): the boxes of this batch were requested during the previous step, the next batch's
+        # forward pass is launched as soon as they are downloaded, and everything below overlaps with it.
+        if not yolo_state["in_flight"]:
+            det.forward_device(d_bgr.data_ptr(), W, H, W * 3, W * H * 3, B, 0.5, det_stream.cuda_stream)  # yolo->Segmentation_(imLeft)
+        dets = det.boxes_batch(B, W, H, stream=det_stream.cuda_stream)                      # one synchronisation per batch
+        det.forward_device(d_bgr.data_ptr(), W, H, W * 3, W * H * 3, B, 0.5, det_stream.cuda_stream)      # the next batch
+        yolo_state["in_flight"] = True
         bt.extract_device(d_gray.data_ptr(), W, W * H, n_img, st)
         bt.stereo_match(B, cfg["bf"], cfg["fx"], st)
-        dets = det.boxes_batch(B, W, H, stream=st)                                          # one synchronisation per batch
         # Frame::boxTrack is a host recurrence over the sequence (f64, a handful of boxes)
         bl, il = [], []
         lo, li_, lm, lv = np.zeros((0, 4)), np.zeros(0, np.int32), np.zeros(0, np.uint8), np.zeros((0, 2))
