@@ -6,10 +6,10 @@
 //   phase 1  ALL scanned pixels, 4 per thread from packed words: compass test.  Any 9-arc of the
 //            16-ring holds two ADJACENT compass points (ring 0,4,8,12), so a corner needs an adjacent
 //            compass pair both darker than v-T or both brighter than v+T (T = minTh).  ~25 ops/px.
-//   phase 2  survivors (wave-ballot compacted): exact 16-bit dark/bright ring masks, 9-contiguous test
-//   phase 3  corners (compacted again): cornerScore (sliding 9-window min/max) -> score tile
-//   phase 4  3x3 strict-maximum NMS on the corner list; cell threshold = iniTh if any survivor >= iniTh
-//   phase 5  row-major ordered emission (prefix sum over the score tile)
+//   phase 2  survivors (wave-ballot compacted): cornerScore (9-arc min / max as three 3-arcs) -> score tile; score >= T
+//            IS the FAST-9 test at T, so the corners fall out of the score (compacted again)
+//   phase 3  3x3 strict-maximum NMS on the corner list -> row bit masks; cell threshold = iniTh if any survivor >= iniTh
+//   phase 4  row-major ordered emission (wave prefix sum over the row masks + popcount inside the row)
 // Same results as k_fast_cells (kept as the generic path for windows > 52 px); see that kernel's header
 // comment for why the threshold-free score map reproduces OpenCV's two-threshold behaviour.
 #pragma once
@@ -34,57 +34,79 @@ __device__ __forceinline__ int sd_wave_append(bool pred, int* counter)
     return pred ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
 }
 
-// One workgroup of NT threads per cell.  The cost of a cell is dominated by latencies (window fetch, LDS
-// round trips between the short phases), so small workgroups with a small LDS footprint (lists sized by the
-// plan's largest scan area) are used to keep many independent cells in flight per CU.
+// Per-cell descriptor of the staged kernel: everything the window fetch needs in ONE scalar load (the generic SdCell needs the
+// level table behind it, a second dependent load before the first pixel can be requested).
+struct SdFastCell {
+    uint32_t srcOff;        // byte offset of tile column 0 / window row 0 inside one image's pyramid block
+    int stride;             // level row stride
+    short ww, wh;           // window size
+    short jw, ih;           // ORBextractor.cc:822-823 shift
+    int listOffset, cap;
+};
+struct SdFastArgs {
+    unsigned long long pyrImageBytes;
+    int cellTotal, nImages, listCap, minTh, iniTh, cellListCap;
+};
+#define SD_FS_ROWS 48              // row-mask slots (scan height <= 46)
+
+// One workgroup of NT threads per cell.  The cost of a cell is VALU work plus the latency of its window fetch, so small
+// workgroups with a small LDS footprint (lists sized by the plan's largest scan area) keep many independent cells in flight
+// per CU.
 // (Measured: giving a workgroup 2 or 4 consecutive cells — same barriers, fuller lanes in the short phases — is SLOWER:
 // 1.02 ms per 256 images here vs 1.48 ms (128 threads x 2 cells), 1.15 ms (256 x 2), 1.61 ms (256 x 4): the LDS footprint
 // halves the cells in flight per CU and the phases do not shrink.)
 template <int NT>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) k_fast_cells_staged(const uint8_t* __restrict__ pyr,
-                                                          const SdCell* __restrict__ cells,
+                                                          const SdFastCell* __restrict__ cells,
                                                           uint32_t* __restrict__ cellList, int* __restrict__ cellCount,
-                                                          const SdDevPlan* __restrict__ PP, int listCapArg)
+                                                          const SdFastArgs A)
 {
-    const SdDevPlan& P = *PP;
-    const int listCap = listCapArg & 0xFFFF, nImages = listCapArg >> 16;
     __shared__ __align__(16) uint8_t tile[SD_FS_MAXWIN * SD_FS_TW];
     __shared__ __align__(16) uint8_t score[SD_FS_SW * SD_FS_SW];
+    __shared__ unsigned long long rowAll[SD_FS_ROWS], rowIni[SD_FS_ROWS];   // NMS survivors per scan row: all / those >= iniTh
     extern __shared__ __align__(16) unsigned char dyn_smem[];
-    unsigned short* list1 = (unsigned short*)dyn_smem;              // [listCap]
-    unsigned short* list2 = list1 + listCap;                        // [listCap]
-    unsigned* kept = (unsigned*)(list2 + listCap);                  // [listCap / 4 + 4] NMS maxima: (sy<<16)|(sx<<8)|score
+    unsigned short* list1 = (unsigned short*)dyn_smem;              // [listCap] pixels that pass the compass test
+    unsigned short* list2 = list1 + A.listCap;                      // [listCap] corners at minTh
+    unsigned* kept = (unsigned*)(list2 + A.listCap);                // [listCap / 4 + 4] NMS maxima: (sy<<16)|(sx<<8)|score
     __shared__ int s_cnt1, s_cnt2, s_cnt3, s_any;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int cellTotal = P.cellTotal;
-    const int T = P.minTh;
+    const int T = A.minTh;
     const uint32_t T2 = (uint32_t)T | ((uint32_t)T << 16);
     uint32_t* tileW = (uint32_t*)tile;
     uint32_t* scoreW = (uint32_t*)score;
+    // XCD-aware order: grid = (8 * cells, image groups); the linear workgroup id % 8 = blockIdx.x % 8 picks the XCD
+    // (round-robin dispatch), so XCD x walks the cells of images x, x + 8, ... in cell order and neighbouring cells (which
+    // share 128-byte lines and a 6-px halo) meet in ONE L2.  Measured at 256 images: FETCH_SIZE per launch 928 -> 173 MiB
+    // (x2 = the algorithmic bytes).  (Splitting the cells of ONE image over the XCDs cut the fetch as much but was 35 % slower.)
+    const int ci = blockIdx.x >> 3;
+    const int img = blockIdx.y * 8 + (blockIdx.x & 7);
+    if (img >= A.nImages) return;
+    const SdFastCell c = cells[ci];
+    const int ww = c.ww, wh = c.wh;
+    const int sw = ww - 6, sh = wh - 6;
+    if (sw <= 0 || sh <= 0) { if (tid == 0) cellCount[(size_t)img * A.cellTotal + ci] = 0; return; }
     {
-        // XCD-aware order: workgroup id -> XCD id % 8 (round-robin dispatch), so XCD x walks the cells of images x, x + 8, ...
-        // in cell order and neighbouring cells (which share 128-byte lines and a 6-px halo) meet in ONE L2.  Measured at 256
-        // images: FETCH_SIZE per launch 928 -> 173 MiB (x2 = the algorithmic bytes), same 1.0 ms.  (Splitting the cells
-        // of ONE image over the XCDs instead cut the fetch as much but was 35 % slower.)
-        const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
-        const int ci = kq % cellTotal;
-        const int img = (kq / cellTotal) * 8 + xcd;
-        if (img >= nImages) return;
-        const SdCell c = cells[ci];
-        const SdLevel& g = P.lv[c.level];
-        const int ww = c.x1 - c.x0, wh = c.y1 - c.y0;
-        const int sw = ww - 6, sh = wh - 6;
-        if (sw <= 0 || sh <= 0) { if (tid == 0) cellCount[(size_t)img * cellTotal + ci] = 0; return; }
-        {
-            const uint8_t* src = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)(SD_EDGE + c.y0) * g.stride +
-                                 SD_XOFF + c.x0 - 1;
-            const int wd = tid & 15;
-            for (int y = tid >> 4; y < wh; y += NT / 16)
-                if (wd < 14) tileW[y * 14 + wd] = *(const sd_u32_unaligned*)(src + (size_t)y * g.stride + 4 * wd);
+        // ---- phase 0: window -> LDS.  All row requests of a thread are issued before the first one is consumed (one memory
+        // round trip per cell instead of one per 8 rows); the LDS clears run underneath.
+        const uint8_t* src = pyr + (size_t)img * A.pyrImageBytes + c.srcOff;
+        const int wd = tid & 15, y0 = tid >> 4;
+        constexpr int NR = (SD_FS_MAXWIN + NT / 16 - 1) / (NT / 16);
+        uint32_t px[NR];
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const int y = y0 + k * (NT / 16);
+            px[k] = 0;
+            if (wd < 14 && y < wh) px[k] = *(const sd_u32_unaligned*)(src + (unsigned)__mul24(y, c.stride) + 4 * wd);
         }
         // only the frame and the scanned rows of the score tile are ever read: rows 0 .. sh+1
         for (int i = tid; i < (sh + 2) * (SD_FS_SW / 4); i += NT) scoreW[i] = 0;
+        if (tid < SD_FS_ROWS) { rowAll[tid] = 0; rowIni[tid] = 0; }
         if (tid == 0) { s_cnt1 = 0; s_cnt2 = 0; s_cnt3 = 0; s_any = 0; }
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const int y = y0 + k * (NT / 16);
+            if (wd < 14 && y < wh) tileW[y * 14 + wd] = px[k];
+        }
         __syncthreads();
         // ---- phase 1: compass quick test, 4 px per thread, packed 2 x i16 arithmetic.
         // With sign words dX = (X - lo) [sign set <=> X darker than v-T] the adjacent-pair test over the cycle
@@ -143,7 +165,8 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
             }
         }
         __syncthreads();
-        // ---- phase 2: exact ring test on the survivors
+        // ---- phase 2: cornerScore of every survivor.  score = (largest t for which the pixel is still a FAST-9 corner), so
+        // "corner at T" <=> score >= T and no separate ring test is needed.  A 9-arc is three 3-arcs: min3 / max3 twice.
         const int n1 = s_cnt1;
         for (int i0 = 0; i0 < n1; i0 += NT) {
             const int i = i0 + tid;
@@ -153,91 +176,85 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 ent = list1[i];
                 const int sx = ent & 255, sy = ent >> 8;
                 const uint8_t* p = tile + (sy + 3) * SD_FS_TW + sx + 4;
-                const int v = p[0];
-                const int a = T - v, b = v + T;      // sign(r + a) -> darker ; sign(b - r) -> brighter
-                unsigned dark = 0, bright = 0;
                 const int S = SD_FS_TW;
-#define SD_RING(off) { const int r = p[off]; dark = __builtin_amdgcn_alignbit(dark, (unsigned)(r + a), 31); \
-                       bright = __builtin_amdgcn_alignbit(bright, (unsigned)(b - r), 31); }
-                SD_RING(3 * S) SD_RING(3 * S + 1) SD_RING(2 * S + 2) SD_RING(S + 3) SD_RING(3) SD_RING(-S + 3)
-                SD_RING(-2 * S + 2) SD_RING(-3 * S + 1) SD_RING(-3 * S) SD_RING(-3 * S - 1) SD_RING(-2 * S - 2)
-                SD_RING(-S - 3) SD_RING(-3) SD_RING(S - 3) SD_RING(2 * S - 2) SD_RING(3 * S - 1)
-#undef SD_RING
-                corner = sd_has9(dark & 0xFFFFu) || sd_has9(bright & 0xFFFFu);
+                const int v = p[0];
+                int d[16];
+                d[0] = v - p[3 * S];       d[1] = v - p[3 * S + 1];   d[2] = v - p[2 * S + 2];   d[3] = v - p[S + 3];
+                d[4] = v - p[3];           d[5] = v - p[-S + 3];      d[6] = v - p[-2 * S + 2];  d[7] = v - p[-3 * S + 1];
+                d[8] = v - p[-3 * S];      d[9] = v - p[-3 * S - 1];  d[10] = v - p[-2 * S - 2]; d[11] = v - p[-S - 3];
+                d[12] = v - p[-3];         d[13] = v - p[S - 3];      d[14] = v - p[2 * S - 2];  d[15] = v - p[3 * S - 1];
+                int mn3[16], mx3[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    mn3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+                    mx3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+                }
+                int a9[16], b9[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    a9[k] = min(min(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]);
+                    b9[k] = max(max(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]);
+                }
+#pragma unroll
+                for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+                    for (int k = 0; k < w; k++) { a9[k] = max(a9[k], a9[k + w]); b9[k] = min(b9[k], b9[k + w]); }
+                const int sc = max(a9[0], -b9[0]) - 1;
+                corner = sc >= T;
+                if (corner) score[(sy + 1) * SD_FS_SW + sx + 1] = (uint8_t)sc;
             }
             const int slot = sd_wave_append(corner, &s_cnt2);
             if (corner) list2[slot] = ent;
         }
         __syncthreads();
-        // ---- phase 3: corner score into the score tile
+        // ---- phase 3: 3x3 strict-maximum NMS over the corner list (zero frame = outside the scanned area); survivors go to a
+        //      compact list and set their bit in the row masks; the cell threshold is iniTh iff one of them reaches it
         const int n2 = s_cnt2;
-        for (int i = tid; i < n2; i += NT) {
-            const unsigned short ent = list2[i];
-            const int sx = ent & 255, sy = ent >> 8;
-            const uint8_t* p = tile + (sy + 3) * SD_FS_TW + sx + 4;
-            const int S = SD_FS_TW;
-            const int v = p[0];
-            int d[16];
-            d[0] = v - p[3 * S];       d[1] = v - p[3 * S + 1];   d[2] = v - p[2 * S + 2];   d[3] = v - p[S + 3];
-            d[4] = v - p[3];           d[5] = v - p[-S + 3];      d[6] = v - p[-2 * S + 2];  d[7] = v - p[-3 * S + 1];
-            d[8] = v - p[-3 * S];      d[9] = v - p[-3 * S - 1];  d[10] = v - p[-2 * S - 2]; d[11] = v - p[-S - 3];
-            d[12] = v - p[-3];         d[13] = v - p[S - 3];      d[14] = v - p[2 * S - 2];  d[15] = v - p[3 * S - 1];
-            int mn2[16], mx2[16], mn4[16], mx4[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-            for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
-            int A = -1000, B = 1000;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                A = max(A, min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]));
-                B = min(B, max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]));
-            }
-            score[(sy + 1) * SD_FS_SW + sx + 1] = (uint8_t)(max(A, -B) - 1);      // >= T for a corner at T
-        }
-        __syncthreads();
-        // ---- phase 4: 3x3 strict-maximum NMS over the corner list (zero frame = outside the scanned area);
-        //      survivors go to a compact list; the cell threshold is iniTh iff one of them reaches it
         for (int i0 = 0; i0 < n2; i0 += NT) {
             const int i = i0 + tid;
             bool ok = false;
             unsigned key = 0;
             if (i < n2) {
                 const unsigned short ent = list2[i];
-                const uint8_t* q = score + ((ent >> 8) + 1) * SD_FS_SW + (ent & 255) + 1;
+                const int sx = ent & 255, sy = ent >> 8;
+                const uint8_t* q = score + (sy + 1) * SD_FS_SW + sx + 1;
                 const int s = q[0];
                 ok = s > q[-SD_FS_SW - 1] && s > q[-SD_FS_SW] && s > q[-SD_FS_SW + 1] && s > q[-1] && s > q[1] &&
                      s > q[SD_FS_SW - 1] && s > q[SD_FS_SW] && s > q[SD_FS_SW + 1];
                 key = ((unsigned)ent << 8) | (unsigned)s;
-                if (ok && s >= P.iniTh) s_any = 1;
+                if (ok) {
+                    atomicOr(&rowAll[sy], 1ull << sx);
+                    if (s >= A.iniTh) { atomicOr(&rowIni[sy], 1ull << sx); s_any = 1; }
+                }
             }
             const int slot = sd_wave_append(ok, &s_cnt3);
             if (ok) kept[slot] = key;
         }
         __syncthreads();
-        // ---- phase 5: row-major emission: rank of a survivor = number of survivors (>= threshold) before it
+        // ---- phase 4: row-major emission.  rank of a survivor = survivors in the rows above (wave prefix sum over the row
+        //      masks, one row per lane) + survivors to its left in its own row (popcount of the masked row word)
         const int n3 = s_cnt3;
-        const int Tc = s_any ? P.iniTh : P.minTh;
-        uint32_t* out = cellList + (size_t)img * P.cellListCap + c.listOffset;
-        int total = 0;
-        for (int i = tid; i < n3; i += NT) {
-            const unsigned key = kept[i];
-            if ((int)(key & 255u) >= Tc) {
-                int rank = 0;
-                for (int j = 0; j < n3; j++) { const unsigned kj = kept[j]; rank += ((int)(kj & 255u) >= Tc) && ((kj >> 8) < (key >> 8)); }
-                const int sx = (key >> 8) & 255, sy = key >> 16;
+        const bool any = s_any != 0;
+        const int Tc = any ? A.iniTh : A.minTh;
+        const unsigned long long* rows = any ? rowIni : rowAll;
+        const int rowPop = lane < SD_FS_ROWS ? __popcll(rows[lane]) : 0;
+        int incl = rowPop;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        const int excl = incl - rowPop;
+        uint32_t* out = cellList + (size_t)img * A.cellListCap + c.listOffset;
+        for (int i0 = 0; i0 < n3; i0 += NT) {
+            const int i = i0 + tid;
+            const unsigned key = i < n3 ? kept[i] : 0u;
+            const int sx = (key >> 8) & 255, sy = key >> 16;
+            const int base = __shfl(excl, sy, 64);
+            if (i < n3 && (int)(key & 255u) >= Tc) {
+                const int rank = base + __popcll(rows[sy] & ((1ull << sx) - 1ull));
                 const uint32_t px = (uint32_t)(sx + 3 + c.jw), py = (uint32_t)(sy + 3 + c.ih);
                 if (rank < c.cap) out[rank] = px | (py << 12) | ((key & 255u) << 24);
             }
         }
-        if (tid < 64) {                                     // count of emitted keypoints (first wave)
-            int cnt = 0;
-            for (int j = lane; j < n3; j += 64) cnt += (int)(kept[j] & 255u) >= Tc;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-            total = cnt;
-            if (tid == 0) cellCount[(size_t)img * cellTotal + ci] = min(total, c.cap);
-        }
+        if (tid == 63) cellCount[(size_t)img * A.cellTotal + ci] = min(incl, c.cap);
     }
 }
 

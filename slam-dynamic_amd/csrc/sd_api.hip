@@ -56,6 +56,7 @@ struct sd_batch {
     // device buffers
     SdDevPlan* d_plan = nullptr;
     SdCell* d_cells = nullptr;
+    SdFastCell* d_fcells = nullptr; int fastListCap = 0, fastMaxCap = 0;   // k_fast_cells_staged: per-cell descriptors, list sizes
     int16_t* d_tabs = nullptr;
     uint8_t* d_pyr = nullptr;
     uint8_t* d_blur = nullptr;
@@ -214,7 +215,7 @@ int sd_extractor_level_size(const sd_extractor* ex, int width, int height, int l
 static void batch_free(sd_batch* b)
 {
     if (!b) return;
-    void* ptrs[] = {b->d_plan, b->d_cells, b->d_tabs, b->d_pyr, b->d_blur, b->d_cellList, b->d_cellCount, b->d_cand,
+    void* ptrs[] = {b->d_plan, b->d_cells, b->d_fcells, b->d_tabs, b->d_pyr, b->d_blur, b->d_cellList, b->d_cellCount, b->d_cand,
                     b->d_nodeOf, b->d_lvlCount, b->d_candCount, b->d_lvlKp, b->d_rot, b->d_kp, b->d_desc, b->d_count,
                     b->d_err, b->d_uright, b->d_depth, b->d_sad, b->d_stage, b->d_cellOf, b->d_xw, b->d_flags,
                     b->d_pcand, b->d_pncand, b->d_match, b->d_pairs, b->d_npairs, b->d_nmatch, b->d_pose, b->d_pairIdx, b->d_sortedIdx, b->d_cellStart,
@@ -283,6 +284,7 @@ int sd_batch_create(sd_batch** out, sd_extractor* ex, int width, int height, int
     const size_t nI = (size_t)max_images;
     ALLOC(b->d_plan, sizeof(SdDevPlan));
     ALLOC(b->d_cells, sizeof(SdCell) * P.cells.size());
+    ALLOC(b->d_fcells, sizeof(SdFastCell) * P.cells.size());
     ALLOC(b->d_tabs, sizeof(int16_t) * P.tabs.size());
     ALLOC(b->d_pyr, nI * P.pyrImageBytes + 4096);
     ALLOC(b->d_blur, nI * P.blurImageBytes + 4096);
@@ -344,6 +346,21 @@ int sd_batch_create(sd_batch** out, sd_extractor* ex, int width, int height, int
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMemcpy(b->d_plan, &D, sizeof(D), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(b->d_cells, P.cells.data(), sizeof(SdCell) * P.cells.size(), hipMemcpyHostToDevice);
+    {
+        std::vector<SdFastCell> fc(P.cells.size());
+        for (size_t i = 0; i < P.cells.size(); i++) {
+            const SdCell& c = P.cells[i];
+            const SdLevel& g = P.lv[c.level];
+            fc[i].srcOff = (uint32_t)(g.pyrOffset + (SD_EDGE + c.y0) * g.stride + SD_XOFF + c.x0 - 1);
+            fc[i].stride = g.stride;
+            fc[i].ww = (short)(c.x1 - c.x0); fc[i].wh = (short)(c.y1 - c.y0);
+            fc[i].jw = c.jw; fc[i].ih = c.ih; fc[i].listOffset = c.listOffset; fc[i].cap = c.cap;
+            b->fastListCap = std::max(b->fastListCap, (c.x1 - c.x0 - 6) * (c.y1 - c.y0 - 6));      // largest scanned area of a cell
+            b->fastMaxCap = std::max(b->fastMaxCap, c.cap);
+        }
+        b->fastListCap = (b->fastListCap + 7) & ~7;
+        if (e == hipSuccess) e = hipMemcpy(b->d_fcells, fc.data(), sizeof(SdFastCell) * fc.size(), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMemcpy(b->d_tabs, P.tabs.data(), sizeof(int16_t) * P.tabs.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(b->d_err, 0, 4);
     if (e == hipSuccess) e = hipMemset(b->d_fb, 0, nI * sizeof(SdFrameBoxes));
@@ -505,15 +522,15 @@ int sd_batch_extract_device(sd_batch* b, const uint8_t* d_gray, size_t stride, s
         dim3 grd((unsigned)P.cells.size(), n_images);
         if (P.maxWin <= SD_FS_MAXWIN)
         {
-            int listCap = 0;                                           // largest scanned area of a cell, rounded up
-            for (const SdCell& c : P.cells) { const int a_ = (c.x1 - c.x0 - 6) * (c.y1 - c.y0 - 6); if (a_ > listCap) listCap = a_; }
-            listCap = (listCap + 7) & ~7;
-            const size_t lds = (size_t)listCap * 4 + ((size_t)listCap / 4 + 4) * 4;
+            const int listCap = b->fastListCap;
+            const size_t lds = (size_t)listCap * 4 + ((size_t)b->fastMaxCap + 4) * 4;
             // 128-thread workgroups: measured best (64: 0.66 ms, 128: 0.49 ms, 256: 0.65 ms per 128-image launch)
-            // 1-D grid: workgroup id = (image group, cell, XCD) -- see the kernel
-            const unsigned nwg = (unsigned)P.cells.size() * (unsigned)((n_images + 7) / 8 * 8);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_cells_staged<128>), dim3(nwg), dim3(128), lds, s, b->d_pyr, b->d_cells, b->d_cellList,
-                               b->d_cellCount, b->d_plan, listCap | (n_images << 16));
+            // grid = (8 x cells, image groups): workgroup -> (cell, XCD, image group) -- see the kernel
+            SdFastArgs fa;
+            fa.pyrImageBytes = P.pyrImageBytes; fa.cellTotal = (int)P.cells.size(); fa.nImages = n_images; fa.listCap = listCap;
+            fa.minTh = b->hplan.minTh; fa.iniTh = b->hplan.iniTh; fa.cellListCap = P.cellListCap;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_cells_staged<128>), dim3((unsigned)P.cells.size() * 8u, (unsigned)((n_images + 7) / 8)), dim3(128),
+                               lds, s, b->d_pyr, b->d_fcells, b->d_cellList, b->d_cellCount, fa);
         }
         else
             hipLaunchKernelGGL(k_fast_cells, grd, dim3(256), 0, s, b->d_pyr, b->d_cells, b->d_cellList, b->d_cellCount, b->d_plan);
