@@ -5,7 +5,7 @@
 //            the scanned pixels start on a word boundary
 //   phase 1  ALL scanned pixels, 4 per thread from packed words: compass test.  Any 9-arc of the
 //            16-ring holds two ADJACENT compass points (ring 0,4,8,12), so a corner needs an adjacent
-//            compass pair both darker than v-T or both brighter than v+T (T = minTh).  ~25 ops/px.
+//            compass pair both darker than v-T or both brighter than v+T (T = minTh); done on halved pixels, 4 px per 32-bit op.
 //   phase 2  survivors (wave-ballot compacted): cornerScore (9-arc min / max as three 3-arcs) -> score tile; score >= T
 //            IS the FAST-9 test at T, so the corners fall out of the score (compacted again)
 //   phase 3  3x3 strict-maximum NMS on the corner list -> row bit masks; cell threshold = iniTh if any survivor >= iniTh
@@ -71,7 +71,6 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     __shared__ int s_cnt1, s_cnt2, s_cnt3, s_any;
     const int tid = threadIdx.x, lane = tid & 63;
     const int T = A.minTh;
-    const uint32_t T2 = (uint32_t)T | ((uint32_t)T << 16);
     uint32_t* tileW = (uint32_t*)tile;
     uint32_t* scoreW = (uint32_t*)score;
     // XCD-aware order: grid = (8 * cells, image groups); the linear workgroup id % 8 = blockIdx.x % 8 picks the XCD
@@ -108,9 +107,13 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
             if (wd < 14 && y < wh) tileW[y * 14 + wd] = px[k];
         }
         __syncthreads();
-        // ---- phase 1: compass quick test, 4 px per thread, packed 2 x i16 arithmetic.
-        // With sign words dX = (X - lo) [sign set <=> X darker than v-T] the adjacent-pair test over the cycle
-        // S-E-N-W collapses to (dS|dN) & (dE|dW); same for the brighter side with (hi - X).
+        // ---- phase 1: compass quick test, 4 px per thread, four pixels per 32-bit operation on HALVED pixel values (7 bits per
+        // byte, bit 7 of every byte is the borrow guard of a byte-wise subtraction):  X < v - T  implies
+        // (X >> 1) <= (v >> 1) - k  and  X > v + T  implies  (X >> 1) >= (v >> 1) + k  with k = (T + 1) / 2, so the halved test never
+        // loses a corner; the few extra survivors (+6 % measured) are rejected by the exact score of phase 2.
+        // The adjacent-pair test over the cycle S-E-N-W collapses to (dS|dN) & (dE|dW); same for the brighter side.
+        const uint32_t M7 = 0x7f7f7f7fu, G7 = 0x80808080u;
+        const uint32_t KG = G7 - (uint32_t)((T + 1) >> 1) * 0x01010101u;
         const int ng = (sw + 3) >> 2;
         const int shift = ng <= 8 ? 3 : 4;                 // items per scan row = 1 << shift (no division)
         const int nitems = sh << shift;
@@ -122,35 +125,25 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
             if (live) {
                 const uint32_t* row = tileW + (sy + 3) * 14 + gq;
                 const uint32_t w0 = row[0], w1 = row[1], w2 = row[2];
-                const uint32_t C = w1;
-                const uint32_t E = __builtin_amdgcn_alignbyte(w2, w1, 3);
-                const uint32_t Wst = __builtin_amdgcn_alignbyte(w1, w0, 1);
                 const uint32_t N = tileW[sy * 14 + gq + 1];
                 const uint32_t S = tileW[(sy + 6) * 14 + gq + 1];
-#pragma unroll
-                for (int half = 0; half < 2; half++) {
-                    const uint32_t sel = half ? 0x0C030C02u : 0x0C010C00u;   // bytes (0,1) or (2,3) -> 2 x u16
-                    const uint32_t c2 = __builtin_amdgcn_perm(0u, C, sel), e2 = __builtin_amdgcn_perm(0u, E, sel);
-                    const uint32_t w2_ = __builtin_amdgcn_perm(0u, Wst, sel), n2 = __builtin_amdgcn_perm(0u, N, sel);
-                    const uint32_t s2 = __builtin_amdgcn_perm(0u, S, sel);
-                    typedef short v2s __attribute__((ext_vector_type(2)));
-                    const v2s lo = __builtin_bit_cast(v2s, c2) - __builtin_bit_cast(v2s, T2);
-                    const v2s hi = __builtin_bit_cast(v2s, c2) + __builtin_bit_cast(v2s, T2);
-                    const v2s vs = __builtin_bit_cast(v2s, s2), vn = __builtin_bit_cast(v2s, n2);
-                    const v2s ve = __builtin_bit_cast(v2s, e2), vw = __builtin_bit_cast(v2s, w2_);
-                    const uint32_t dV = __builtin_bit_cast(uint32_t, vs - lo) | __builtin_bit_cast(uint32_t, vn - lo);
-                    const uint32_t dH = __builtin_bit_cast(uint32_t, ve - lo) | __builtin_bit_cast(uint32_t, vw - lo);
-                    const uint32_t bV = __builtin_bit_cast(uint32_t, hi - vs) | __builtin_bit_cast(uint32_t, hi - vn);
-                    const uint32_t bH = __builtin_bit_cast(uint32_t, hi - ve) | __builtin_bit_cast(uint32_t, hi - vw);
-                    const uint32_t ps = (dV & dH) | (bV & bH);               // sign bits 15 / 31
-                    pmask |= (((ps >> 15) & 1u) | ((ps >> 30) & 2u)) << (2 * half);
-                }
+                // halved pixels, 7 bits per byte (the alignbit forms shift the E / W neighbours into place on the way)
+                const uint32_t C7 = (w1 >> 1) & M7, N7 = (N >> 1) & M7, S7 = (S >> 1) & M7;
+                const uint32_t E7 = __builtin_amdgcn_alignbit(w2, w1, 25) & M7;
+                const uint32_t W7 = __builtin_amdgcn_alignbit(w1, w0, 9) & M7;
+                const uint32_t loD = C7 + KG;                       // byte = 128 + (v7 - k): bit 7 = "v7 >= k", low bits = v7 - k
+                const uint32_t gD = loD | G7;
+                const uint32_t loB = (C7 ^ M7) + KG;                // the same in the complemented (127 - x) domain
+                const uint32_t hB = (loB | G7) - M7;
+                const uint32_t dV = (gD - S7) | (gD - N7), dH = (gD - E7) | (gD - W7);   // bit 7: X7 <= v7 - k
+                const uint32_t bV = (S7 + hB) | (N7 + hB), bH = (E7 + hB) | (W7 + hB);   // bit 7: X7 >= v7 + k
+                pmask = ((dV & dH & loD) | (bV & bH & loB)) & G7;
                 const int nvalid = sw - 4 * gq;                               // pixels of this group inside the scan
-                if (nvalid < 4) pmask &= (1u << nvalid) - 1u;
+                if (nvalid < 4) pmask &= (1u << (8 * nvalid)) - 1u;
             }
             // one slot reservation per wave: the four candidate bits of a lane go out bit plane by bit plane (ballot + mbcnt,
             // ~5 VALU each) instead of through a six-step prefix scan of the per-lane counts; list order is free
-            const unsigned long long b0 = __ballot(pmask & 1u), b1 = __ballot(pmask & 2u), b2 = __ballot(pmask & 4u), b3 = __ballot(pmask & 8u);
+            const unsigned long long b0 = __ballot(pmask & 0x80u), b1 = __ballot(pmask & 0x8000u), b2 = __ballot(pmask & 0x800000u), b3 = __ballot(pmask & 0x80000000u);
             const int c0 = __popcll(b0), c1 = __popcll(b1), c2 = __popcll(b2), c3 = __popcll(b3);
             const int wtot = c0 + c1 + c2 + c3;
             if (wtot) {
@@ -158,10 +151,10 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 if (lane == 0) base = atomicAdd(&s_cnt1, wtot);
                 base = __builtin_amdgcn_readfirstlane(base);
                 const unsigned short e0 = (unsigned short)((sy << 8) | (4 * gq));
-                if (pmask & 1u) list1[base + __builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, 0u))] = e0;
-                if (pmask & 2u) list1[base + c0 + __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0u))] = e0 + 1;
-                if (pmask & 4u) list1[base + c0 + c1 + __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b2, 0u))] = e0 + 2;
-                if (pmask & 8u) list1[base + c0 + c1 + c2 + __builtin_amdgcn_mbcnt_hi((unsigned)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b3, 0u))] = e0 + 3;
+                if (pmask & 0x80u) list1[base + __builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, 0u))] = e0;
+                if (pmask & 0x8000u) list1[base + c0 + __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0u))] = e0 + 1;
+                if (pmask & 0x800000u) list1[base + c0 + c1 + __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b2, 0u))] = e0 + 2;
+                if (pmask & 0x80000000u) list1[base + c0 + c1 + c2 + __builtin_amdgcn_mbcnt_hi((unsigned)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b3, 0u))] = e0 + 3;
             }
         }
         __syncthreads();
