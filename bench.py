@@ -187,9 +187,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("SD_BENCH_FORCE_DIST"):     # FORCE_DIST: one-rank RCCL group, rehearses the collective calls on a 1-GPU box
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         backend = os.environ.get("SD_BENCH_BACKEND", "nccl")            # "gloo" only for single-GPU rehearsal
         if backend == "nccl":
             dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
