@@ -259,6 +259,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #ifndef SD_BLUR_TR
 #define SD_BLUR_TR 64        // output rows per tile: (TR + 6) / TR rows are filtered horizontally (16: 1.375x, 0.42 ms per 256 images; 32: 0.36; 64: 0.345)
 #endif
+template <bool CLAMP>
 __global__ void __launch_bounds__(256) k_blur_wide(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
                                                    const SdDevPlan* __restrict__ PP)
 {
@@ -275,37 +276,73 @@ __global__ void __launch_bounds__(256) k_blur_wide(const uint8_t* __restrict__ p
     const uint32_t tapsLo = (uint32_t)P.taps[0] | ((uint32_t)P.taps[1] << 8) | ((uint32_t)P.taps[2] << 16) | ((uint32_t)P.taps[3] << 24);
     const uint32_t tapsHi = (uint32_t)P.taps[4] | ((uint32_t)P.taps[5] << 8) | ((uint32_t)P.taps[6] << 16);
     const uint8_t* src = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)SD_EDGE * g.stride + SD_XOFF;
-    for (int it = tid; it < (SD_BLUR_TR + 6) * 32; it += 256) {
-        const int r = it >> 5, gq = it & 31;
-        const int y = min(y0 + r - 3, g.H + 2);
-        const uint32_t* rowp = (const uint32_t*)(src + (ptrdiff_t)y * g.stride + x0 + 4 * gq - 4);
-        const uint32_t w0 = rowp[0], w1 = rowp[1], w2 = rowp[2];
-        uint32_t h[4];
+    {
+        // horizontal pass: all row requests of a thread go out before the first one is consumed
+        constexpr int NIT = (SD_BLUR_TR + 6 + 7) / 8;
+        const int gq = tid & 31, rb = tid >> 5;
+        const uint8_t* colp = src + x0 + 4 * gq - 4;
+        uint32_t w[NIT][3];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t A = j == 3 ? w1 : __builtin_amdgcn_alignbyte(w1, w0, j + 1);
-            const uint32_t B = j == 3 ? w2 : __builtin_amdgcn_alignbyte(w2, w1, j + 1);
-            h[j] = __builtin_amdgcn_udot4(A, tapsLo, __builtin_amdgcn_udot4(B, tapsHi, 0u, false), false);
+        for (int i = 0; i < NIT; i++) {
+            const int r = rb + 8 * i;
+            const int y = min(y0 + r - 3, g.H + 2);
+            const uint32_t* rowp = (const uint32_t*)(colp + (ptrdiff_t)__mul24(y, g.stride));
+            if (r < SD_BLUR_TR + 6) { w[i][0] = rowp[0]; w[i][1] = rowp[1]; w[i][2] = rowp[2]; }
         }
-        hbuf[r][gq] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+#pragma unroll
+        for (int i = 0; i < NIT; i++) {
+            const int r = rb + 8 * i;
+            if (r < SD_BLUR_TR + 6) {
+                uint32_t h[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t A = j == 3 ? w[i][1] : __builtin_amdgcn_alignbyte(w[i][1], w[i][0], j + 1);
+                    const uint32_t B = j == 3 ? w[i][2] : __builtin_amdgcn_alignbyte(w[i][2], w[i][1], j + 1);
+                    h[j] = __builtin_amdgcn_udot4(A, tapsLo, __builtin_amdgcn_udot4(B, tapsHi, 0u, false), false);
+                }
+                hbuf[r][gq] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            }
+        }
     }
     __syncthreads();
+    // Vertical pass: a thread owns one 4-px column group and SD_BLUR_TR / 8 consecutive output rows, and slides a 7-row window
+    // of unpacked 8.8 sums down them: one ds_read_b64 and four unpacks per output row instead of seven of each.  The
+    // accumulators start at the rounding constant; with taps summing to <= 256 the result is byte 2 of the sum (CLAMP covers
+    // the 257 case sd_extractor_set_blur_taps admits).
     uint8_t* dst = blur + (size_t)img * P.blurImageBytes + g.blurOffset;
-    for (int it = tid; it < SD_BLUR_TR * 32; it += 256) {
-        const int r = it >> 5, gq = it & 31;
-        const int x = x0 + 4 * gq, y = y0 + r;
-        if (x < g.W && y < g.H) {
-            uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    constexpr int RPT = SD_BLUR_TR / 8;                   // output rows per thread
+    const int gq = tid & 31, r0 = (tid >> 5) * RPT;
+    const int x = x0 + 4 * gq;
+    if (x >= g.W) return;
+    uint32_t t[7];
 #pragma unroll
-            for (int k = 0; k < 7; k++) {
-                const uint2 v = hbuf[r + k][gq];
-                const uint32_t t = (uint32_t)P.taps[k];         // < 2^8, sums < 2^16: full-rate 24-bit multiplies (v_mul_lo_u32 is quarter rate)
-                s0 += __umul24(t, v.x & 0xFFFFu); s1 += __umul24(t, v.x >> 16);
-                s2 += __umul24(t, v.y & 0xFFFFu); s3 += __umul24(t, v.y >> 16);
-            }
-            const uint32_t o0 = min((s0 + 0x8000u) >> 16, 255u), o1 = min((s1 + 0x8000u) >> 16, 255u);
-            const uint32_t o2 = min((s2 + 0x8000u) >> 16, 255u), o3 = min((s3 + 0x8000u) >> 16, 255u);
-            *(uint32_t*)(dst + (size_t)y * g.blurStride + x) = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+    for (int k = 0; k < 7; k++) t[k] = (uint32_t)P.taps[k];      // < 2^8, sums < 2^16: full-rate 24-bit multiplies (v_mul_lo_u32 is quarter rate)
+    uint32_t win[7][4];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const uint2 v = hbuf[r0 + k][gq];
+        win[k][0] = v.x & 0xFFFFu; win[k][1] = v.x >> 16; win[k][2] = v.y & 0xFFFFu; win[k][3] = v.y >> 16;
+    }
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+        const uint2 v = hbuf[r0 + r + 6][gq];
+        uint32_t* nw = win[(r + 6) % 7];
+        nw[0] = v.x & 0xFFFFu; nw[1] = v.x >> 16; nw[2] = v.y & 0xFFFFu; nw[3] = v.y >> 16;
+        uint32_t sum[4] = {0x8000u, 0x8000u, 0x8000u, 0x8000u};
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            const uint32_t* w = win[(r + k) % 7];
+#pragma unroll
+            for (int j = 0; j < 4; j++) sum[j] += __umul24(t[k], w[j]);
+        }
+        const int y = y0 + r0 + r;
+        if (y < g.H) {
+            uint32_t o;
+            if (CLAMP)
+                o = min(sum[0] >> 16, 255u) | (min(sum[1] >> 16, 255u) << 8) | (min(sum[2] >> 16, 255u) << 16) | (min(sum[3] >> 16, 255u) << 24);
+            else
+                o = __builtin_amdgcn_perm(__builtin_amdgcn_perm(sum[3], sum[2], 0x0C0C0602u), __builtin_amdgcn_perm(sum[1], sum[0], 0x0C0C0602u), 0x05040100u);
+            *(uint32_t*)(dst + (size_t)y * g.blurStride + x) = o;
         }
     }
 }

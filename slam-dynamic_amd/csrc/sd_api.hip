@@ -514,7 +514,10 @@ int sd_batch_extract_device(sd_batch* b, const uint8_t* d_gray, size_t stride, s
         // not worth a second stream and overlapped per-kernel timings — everything stays on one stream.)
         ProfScope ps(b, s, K_BLUR);
         dim3 grd((P.lv[0].W + 127) / 128, (P.lv[0].H + SD_BLUR_TR - 1) / SD_BLUR_TR, n_images * nl);
-        hipLaunchKernelGGL(k_blur_wide, grd, dim3(256), 0, s, b->d_pyr, b->d_blur, b->d_plan);
+        unsigned tapSum = 0;
+        for (int i = 0; i < 7; i++) tapSum += b->hplan.taps[i];
+        if (tapSum <= 256) hipLaunchKernelGGL(k_blur_wide<false>, grd, dim3(256), 0, s, b->d_pyr, b->d_blur, b->d_plan);
+        else hipLaunchKernelGGL(k_blur_wide<true>, grd, dim3(256), 0, s, b->d_pyr, b->d_blur, b->d_plan);
     }
     LAUNCH_CHECK("k_blur");
     {
