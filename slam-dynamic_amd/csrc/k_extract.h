@@ -218,20 +218,36 @@ __global__ void __launch_bounds__(256) k_pyr_level_tiles(uint8_t* __restrict__ p
     const uint8_t* sbase = pyr + (size_t)img * P.pyrImageBytes + s.pyrOffset + (size_t)SD_EDGE * s.stride + SD_XOFF;
     // extents of the source region, precomputed on the host (the reflection makes them non-monotone on the frame)
     const int sxA = ext[blockIdx.x], syA = ext[gridDim.x + 2 * blockIdx.y], nrows = ext[gridDim.x + 2 * blockIdx.y + 1];
-    // ---- A
+    // The column-table entries of phase B and the row-table entries of phase C are requested here, ahead of the source
+    // pixels, so that the workgroup pays ONE memory round trip instead of three (tables, pixels, tables).
+    constexpr int NGB = TW / 4, STEPB = 256 / NGB;
+    constexpr int NGC = TW / 8, STEPC = 256 / NGC, NYC = (TH + STEPC - 1) / STEPC;
+    const int gqB = tid % NGB;
+    short4 c[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) c[k] = ct[sd_reflect101(min(max(Xp0 + 4 * gqB + k, 0), PW - 1) - SD_EDGE, g.W)];
+    short4 reC[NYC];
+#pragma unroll
+    for (int i = 0; i < NYC; i++) reC[i] = rt[sd_reflect101(min(Yp0 + tid / NGC + STEPC * i, HP - 1) - SD_EDGE, g.H)];
+    // ---- A: 16-byte chunks, two requests in flight per thread
     const int cpr = srcRowBytes >> 4;
-    for (int c = tid; c < nrows * cpr; c += 256) {
-        const int r = c / cpr, q = c - r * cpr;
-        *(sd_u4v*)(sS + r * srcRowBytes + 16 * q) = *(const sd_u128_unaligned*)(sbase + __mul24(syA + r, sstride) + sxA + 16 * q);
+    const uint32_t cprInv = 0xFFFFFFFFu / (uint32_t)cpr + 1u;                  // c / cpr == umulhi(c, cprInv) for c * cpr < 2^32
+    const int nchunks = nrows * cpr;
+    for (int c0 = tid; c0 < nchunks; c0 += 512) {
+        const int c1 = c0 + 256;
+        const int ra = (int)__umulhi((uint32_t)c0, cprInv), qa = c0 - ra * cpr;
+        const int rb = (int)__umulhi((uint32_t)c1, cprInv), qb = c1 - rb * cpr;
+        const sd_u4v va = *(const sd_u128_unaligned*)(sbase + __mul24(syA + ra, sstride) + sxA + 16 * qa);
+        sd_u4v vb = va;
+        if (c1 < nchunks) vb = *(const sd_u128_unaligned*)(sbase + __mul24(syA + rb, sstride) + sxA + 16 * qb);
+        *(sd_u4v*)(sS + ra * srcRowBytes + 16 * qa) = va;
+        if (c1 < nchunks) *(sd_u4v*)(sS + rb * srcRowBytes + 16 * qb) = vb;
     }
     __syncthreads();
     // ---- B
     {
-        constexpr int NG = TW / 4, STEP = 256 / NG;
-        const int gq = tid % NG;
-        short4 c[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) c[k] = ct[sd_reflect101(min(max(Xp0 + 4 * gq + k, 0), PW - 1) - SD_EDGE, g.W)];
+        constexpr int NG = NGB, STEP = STEPB;
+        const int gq = gqB;
         const int o0 = c[0].x - sxA;
         const int d1 = c[1].x - c[0].x, d2 = c[2].x - c[0].x, d3 = c[3].x - c[0].x;
         const bool window = d1 >= 0 && d2 >= d1 && d3 >= d2 && d3 <= 6;          // per lane; false only on the reflected frame
@@ -264,10 +280,12 @@ __global__ void __launch_bounds__(256) k_pyr_level_tiles(uint8_t* __restrict__ p
         const int gq = tid % NG;
         if (Xp0 + 8 * gq >= PW) return;                                            // no barrier below
         uint8_t* dbase = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (SD_XOFF - SD_EDGE) + Xp0 + 8 * gq;
-        for (int Y = tid / NG; Y < TH; Y += STEP) {
+#pragma unroll
+        for (int i = 0; i < NYC; i++) {
+            const int Y = tid / NG + STEP * i;
             const int Yp = Yp0 + Y;
-            if (Yp >= HP) break;
-            const short4 re = rt[sd_reflect101(Yp - SD_EDGE, g.H)];
+            if (Y >= TH || Yp >= HP) break;
+            const short4 re = reC[i];
             const int r0 = min(max((int)re.x, 0), s.H - 1) - syA, r1 = min(max((int)re.x + 1, 0), s.H - 1) - syA;
             const int b0 = re.y, b1 = re.z;
             const uint4 u0 = *(const uint4*)(sH + r0 * TW + 8 * gq), u1 = *(const uint4*)(sH + r1 * TW + 8 * gq);
