@@ -56,6 +56,31 @@ __device__ __forceinline__ bool sd_xcd_image_item(unsigned id, int perImage, int
     return img < nImages;
 }
 
+// Keypoint slots are laid out level after level with every level's slice starting on a multiple of 8 (sd_plan.h), so the 8
+// (k_orient) or 4 (k_describe) slots of a workgroup share one level: level, level geometry and the per-level counts are
+// wave-uniform SCALAR loads issued together, not per-lane loads chained behind each other.
+__device__ __forceinline__ int sd_slot_level(const SdDevPlan& P, int slot0)
+{
+    int level = 0;
+#pragma unroll
+    for (int l = 1; l < SD_MAX_LEVELS; l++)
+        if (l < P.nlevels && slot0 >= P.lv[l].kpOffset) level = l;
+    return level;
+}
+// lc = this image's per-level counts; the array carries SD_MAX_LEVELS ints of padding so that all loads are unconditional
+__device__ __forceinline__ void sd_level_counts(const int* __restrict__ lc, int nlevels, int level, int& before, int& mine, int& total)
+{
+    before = 0; mine = 0; total = 0;
+#pragma unroll
+    for (int l = 0; l < SD_MAX_LEVELS; l++) {
+        const int ld = lc[l];
+        const int c = l < nlevels ? ld : 0;
+        total += c;
+        before += l < level ? c : 0;
+        mine = l == level ? c : mine;
+    }
+}
+
 typedef uint32_t __attribute__((aligned(1))) sd_u32_una;
 typedef unsigned long long __attribute__((aligned(1))) sd_u64_una;
 typedef uint32_t sd_u4v __attribute__((ext_vector_type(4)));
@@ -767,21 +792,13 @@ __global__ void __launch_bounds__(256) k_orient(const uint8_t* __restrict__ pyr,
     const int slot = grp * 8 + (threadIdx.x >> 5);
     const int l32 = threadIdx.x & 31;
     if (slot >= P.kpCapLevels) return;
-    int level = 0;
-#pragma unroll
-    for (int l = 1; l < SD_MAX_LEVELS; l++)
-        if (l < P.nlevels && slot >= P.lv[l].kpOffset) level = l;
+    const int level = sd_slot_level(P, grp * 8);
     const SdLevel& g = P.lv[level];
-    const int* lc = lvlCount + (size_t)img * P.nlevels;
     const int idx = slot - g.kpOffset;
-    int before = 0;
-    for (int l = 0; l < level; l++) before += lc[l];
-    if (slot == 0 && l32 == 0) {
-        int tot = 0;
-        for (int l = 0; l < P.nlevels; l++) tot += lc[l];
-        count[img] = tot;
-    }
-    if (idx >= lc[level]) return;
+    int before, mine, tot;
+    sd_level_counts(lvlCount + (size_t)img * P.nlevels, P.nlevels, level, before, mine, tot);
+    if (slot == 0 && l32 == 0) count[img] = tot;
+    if (idx >= mine) return;
     const uint32_t v = lvlKp[(size_t)img * P.kpCapLevels + slot];
     const int px = (int)(v & 0xFFF) + g.minBX, py = (int)((v >> 12) & 0xFFF) + g.minBY;
     const uint8_t* center = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)(SD_EDGE + py) * g.stride +
@@ -886,16 +903,12 @@ __global__ void __launch_bounds__(256) k_describe(const uint8_t* __restrict__ bl
     const int slot = grp * 4 + wv;
     const int lane = threadIdx.x & 63;
     if (slot >= P.kpCapLevels) return;
-    int level = 0;
-#pragma unroll
-    for (int l = 1; l < SD_MAX_LEVELS; l++)
-        if (l < P.nlevels && slot >= P.lv[l].kpOffset) level = l;
+    const int level = sd_slot_level(P, grp * 4);
     const SdLevel& g = P.lv[level];
-    const int* lc = lvlCount + (size_t)img * P.nlevels;
     const int idx = slot - g.kpOffset;
-    if (idx >= lc[level]) return;
-    int before = 0;
-    for (int l = 0; l < level; l++) before += lc[l];
+    int before, mine, tot;
+    sd_level_counts(lvlCount + (size_t)img * P.nlevels, P.nlevels, level, before, mine, tot);
+    if (idx >= mine) return;
     const uint32_t v = lvlKp[(size_t)img * P.kpCapLevels + slot];
     const int px = (int)(v & 0xFFF) + g.minBX, py = (int)((v >> 12) & 0xFFF) + g.minBY;
     const float2 ab = rot[(size_t)img * P.kpCapLevels + slot];
@@ -903,6 +916,9 @@ __global__ void __launch_bounds__(256) k_describe(const uint8_t* __restrict__ bl
     const int step = g.blurStride;
     const uint8_t* corner = blur + (size_t)img * P.blurImageBytes + g.blurOffset + (size_t)(py - SD_DP_R) * step + (px - SD_DP_R);
     uint32_t* pw = (uint32_t*)patch[wv];
+    uint32_t pqs[4];                                                       // requested before the patch: one round trip for both
+#pragma unroll
+    for (int r = 0; r < 4; r++) pqs[r] = *(const uint32_t*)(c_pattern + 4 * (lane + 64 * r));       // one dword = (x0, y0, x1, y1) as int8
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         const int i = lane + 64 * k;
@@ -917,8 +933,7 @@ __global__ void __launch_bounds__(256) k_describe(const uint8_t* __restrict__ bl
     unsigned long long words[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int pi = 4 * (lane + 64 * r);
-        const uint32_t pq = *(const uint32_t*)(c_pattern + pi);            // one dword = (x0, y0, x1, y1) as int8
+        const uint32_t pq = pqs[r];
         const float x0 = (float)(signed char)(pq & 255u), y0 = (float)(signed char)((pq >> 8) & 255u);
         const float x1 = (float)(signed char)((pq >> 16) & 255u), y1 = (float)(signed char)(pq >> 24);
         const int iy0 = __float2int_rn(x0 * b + y0 * a), ix0 = __float2int_rn(x0 * a - y0 * b);

@@ -292,7 +292,7 @@ int sd_batch_create(sd_batch** out, sd_extractor* ex, int width, int height, int
     ALLOC(b->d_cellCount, nI * P.cells.size() * 4);
     ALLOC(b->d_cand, nI * P.cellListCap * 4 + 64);
     ALLOC(b->d_nodeOf, nI * P.cellListCap * 2 + 64);
-    ALLOC(b->d_lvlCount, nI * P.nlevels * 4);
+    ALLOC(b->d_lvlCount, nI * P.nlevels * 4 + SD_MAX_LEVELS * 4);      // + padding: sd_level_counts loads SD_MAX_LEVELS entries
     ALLOC(b->d_candCount, nI * P.nlevels * 4);
     ALLOC(b->d_lvlKp, nI * P.kpCapLevels * 4);
     ALLOC(b->d_rot, nI * P.kpCapLevels * sizeof(float2));

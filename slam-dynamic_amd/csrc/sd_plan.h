@@ -180,7 +180,7 @@ static inline bool sd_plan_build(SdPlan& P, const SdParams& prm, int W, int H)
         g.maxNodes = 4 * bound + 16;
         g.kpCap = (g.quota + 3 > 4 * g.nIni ? g.quota + 3 : 4 * g.nIni) + 1;
         g.kpOffset = kpOff;
-        kpOff += g.kpCap;
+        kpOff += (g.kpCap + 7) & ~7;      // slices start on multiples of 8: the slots of one k_orient / k_describe workgroup share a level
         if (g.maxNodes > P.maxNodesAll) P.maxNodesAll = g.maxNodes;
         // resize coefficient tables (OpenCV resize INTER_LINEAR, 8u)
         g.tabOffset = tabOff;
