@@ -503,26 +503,27 @@ __global__ void __launch_bounds__(256) k_proj_candidates(
                 }
                 const int cS = __shfl(runS, col, 64), cE = __shfl(excl, col, 64);
                 if (t < total) {
+                    // everything a candidate needs is requested as soon as its index is known (one round trip, not one per test)
                     const int i2 = sorted[cS + (t - cE)];
-                    const sd_keypoint k = kC[i2];
+                    const sd_keypoint* kq = kC + i2;
+                    const float kx = kq->x, ky = kq->y;
+                    const int koct = kq->octave;
+                    const float r2 = urC[i2];
+                    const int cellKey = cellC[i2];
+                    const uint4* dr = (const uint4*)(dC + (size_t)i2 * 32);
+                    const uint4 d0 = dr[0], d1 = dr[1];
                     bool lv = true;
                     if (bCheckLevels) {
-                        if (k.octave < minLevel) lv = false;
-                        if (maxLevel >= 0 && k.octave > maxLevel) lv = false;
+                        if (koct < minLevel) lv = false;
+                        if (maxLevel >= 0 && koct > maxLevel) lv = false;
                     }
-                    const float distx = k.x - u, disty = k.y - v;
-                    if (lv && fabsf(distx) < radius && fabsf(disty) < radius) {
-                        bool rOk = true;
-                        const float r2 = urC[i2];
-                        if (r2 > 0) { const float er = fabsf(ur - r2); if (er > radius) rOk = false; }
-                        if (rOk) {
-                            const uint4* dr = (const uint4*)(dC + (size_t)i2 * 32);
-                            const int dist = sd_hamming256(l0, l1, dr[0], dr[1]);
-                            if (dist <= SD_TH_HIGH) {
-                                hit = true;
-                                key = ((unsigned long long)dist << 32) | ((unsigned long long)cellC[i2] << 16) | (unsigned)i2;
-                            }
-                        }
+                    const float distx = kx - u, disty = ky - v;
+                    bool rOk = true;
+                    if (r2 > 0) { const float er = fabsf(ur - r2); if (er > radius) rOk = false; }
+                    const int dist = sd_hamming256(l0, l1, d0, d1);
+                    if (lv && fabsf(distx) < radius && fabsf(disty) < radius && rOk && dist <= SD_TH_HIGH) {
+                        hit = true;
+                        key = ((unsigned long long)dist << 32) | ((unsigned long long)cellKey << 16) | (unsigned)i2;
                     }
                 }
                 const unsigned long long m = __ballot(hit);

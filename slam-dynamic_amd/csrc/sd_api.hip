@@ -1581,7 +1581,7 @@ int sd_batch_first_separate(sd_batch* b, int n_frames, const int32_t* slots, con
 {
     if (!b || n_frames < 0 || n_frames > b->maxImages || (n_frames > 0 && (!slots || !boxes || !n_boxes || !box_idx)))
         return set_err(SD_ERR_INVALID, "bad first_separate arguments");
-    if (b->plan.kpCap > 2048) return set_err(SD_ERR_UNSUPPORTED, "box separation supports up to 2048 keypoints per image");
+    if (b->plan.kpMax > 2048) return set_err(SD_ERR_UNSUPPORTED, "box separation supports up to 2048 keypoints per image");
     hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
     b->lastStream = s;
     if (n_frames == 0) return SD_OK;

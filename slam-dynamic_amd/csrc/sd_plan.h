@@ -100,6 +100,7 @@ struct SdPlan {
     int candCapTotal = 0;    // == cellListCap (compact candidates)
     int kpCapLevels = 0;     // sum of kpCap over levels
     int kpCap = 0;           // capacity of the final per-image keypoint array
+    int kpMax = 0;           // most keypoints an image can produce (sum of the per-level capacities, without the slice padding)
     int maxNodesAll = 0;
     int maxWin = 0;          // largest FAST window side over all cells
     std::string error;
@@ -180,6 +181,7 @@ static inline bool sd_plan_build(SdPlan& P, const SdParams& prm, int W, int H)
         g.maxNodes = 4 * bound + 16;
         g.kpCap = (g.quota + 3 > 4 * g.nIni ? g.quota + 3 : 4 * g.nIni) + 1;
         g.kpOffset = kpOff;
+        P.kpMax += g.kpCap;
         kpOff += (g.kpCap + 7) & ~7;      // slices start on multiples of 8: the slots of one k_orient / k_describe workgroup share a level
         if (g.maxNodes > P.maxNodesAll) P.maxNodesAll = g.maxNodes;
         // resize coefficient tables (OpenCV resize INTER_LINEAR, 8u)
