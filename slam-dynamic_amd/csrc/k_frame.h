@@ -405,37 +405,45 @@ __global__ void __launch_bounds__(256) k_unproject(const sd_keypoint* __restrict
     flags[o] = f;
 }
 
-// Phase A: one wave per Last-frame map point.  Projects it, scans the Current frame's keypoints for the
-// members of GetFeaturesInArea(u, v, radius, level range) and keeps the (<= 64) candidates with Hamming
-// distance <= TH_HIGH sorted by (distance, visiting order).  No assignment state is touched here.
-__global__ void __launch_bounds__(256) k_proj_candidates(
-    const sd_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc, const float* __restrict__ uRight,
-    const int* __restrict__ count, const short* __restrict__ cellOf, const unsigned short* __restrict__ sortedIdx,
-    const unsigned short* __restrict__ cellStart, const float* __restrict__ xw,
-    const uint8_t* __restrict__ flags, const uint8_t* __restrict__ dmp, const float* __restrict__ Tcw,
-    const float* __restrict__ Tlw, unsigned short* __restrict__ cand, uint8_t* __restrict__ ncand,
-    int* __restrict__ errFlag, const SdDevPlan* __restrict__ PP, SdCamera cam, float th, int bMono,
-    const int2* __restrict__ pairIdx)
+// Phase A.  Projects every Last-frame map point, scans the Current frame's keypoints for the members of
+// GetFeaturesInArea(u, v, radius, level range) and keeps the (<= 64) candidates with Hamming distance <= TH_HIGH sorted by
+// (distance, visiting order).  No assignment state is touched here.
+// A search window holds ~4-15 grid-cell members, so a point gets a GROUP of 16 lanes (four points per wave): the group
+// fetches its cell runs, tests 16 members per step, compacts the hits and sorts them in a 16-lane bitonic network.  A point
+// whose window spans more than 16 grid columns or yields more than 16 hits is redone by the whole wave (GW = 64).
+struct SdProjArgs {
+    const sd_keypoint* kp; const uint8_t* desc; const float* uRight; const int* count; const short* cellOf;
+    const unsigned short* sortedIdx; const unsigned short* cellStart; const float* xw; const uint8_t* flags; const uint8_t* dmp;
+    const float* Tcw; const float* Tlw; unsigned short* cand; uint8_t* ncand; int* errFlag; const SdDevPlan* P;
+    SdCamera cam; float th; int bMono; const int2* pairIdx;
+};
+
+// GW lanes (a group) work on point i of the pair; `live` = the group has a point.  Loop bounds are made wave-uniform with
+// __any() so that the cross-lane operations are executed by all lanes.  Returns the hit count (may exceed cap: overflow)
+// and leaves the sorted keys in `key` (lane gl of the group holds rank gl).
+template <int GW>
+__device__ __forceinline__ int sd_proj_point(const SdProjArgs& A, int pair, int i, bool live, int gl, int gshift,
+                                             unsigned long long* __restrict__ keys /* LDS, GW slots of this group */,
+                                             unsigned long long& keyOut, bool& tooWide)
 {
-    const SdDevPlan& P = *PP;
-    __shared__ unsigned long long s_keys[4][SD_PROJ_K];
-    const int pair = blockIdx.y;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + wv;
-    const int imgC = pairIdx[pair].x, imgL = pairIdx[pair].y;
+    const SdDevPlan& P = *A.P;
+    const SdCamera& cam = A.cam;
+    const int lane = threadIdx.x & 63;
+    const int imgC = A.pairIdx[pair].x, imgL = A.pairIdx[pair].y;
     const int cap = P.kpCap;
-    const int Nl = count[imgL], Nc = count[imgC];
-    if (i >= Nl) return;
-    const size_t oL = (size_t)imgL * cap + i;
-    const size_t oOut = (size_t)pair * cap + i;
+    const size_t oL = (size_t)imgL * cap + (live ? i : 0);
     int n = 0;
-    bool ok = (flags[oL] & 1) != 0;
+    tooWide = false;
+    bool ok = live && (A.flags[oL] & 1) != 0;
     float u = 0.f, v = 0.f, invzc = 0.f, radius = 0.f;
     int minLevel = -1, maxLevel = -1;
-    if (ok) {
-        const float* T = Tcw + (size_t)pair * 16;
+    const float* T = A.Tcw + (size_t)pair * 16;
+    const float* Tl = A.Tlw + (size_t)pair * 16;
+    {
+        const float X = A.xw[3 * oL], Y = A.xw[3 * oL + 1], Z = A.xw[3 * oL + 2];
+        const int nLastOctave = A.kp[oL].octave;
         float xc, yc, zc;
-        sd_mat3_mul_add(T, xw[3 * oL], xw[3 * oL + 1], xw[3 * oL + 2], xc, yc, zc);
+        sd_mat3_mul_add(T, X, Y, Z, xc, yc, zc);
         invzc = 1.0f / zc;
         if (invzc < 0) ok = false;
         u = cam.fx * xc * invzc + cam.cx;
@@ -443,117 +451,159 @@ __global__ void __launch_bounds__(256) k_proj_candidates(
         if (u < cam.mnMinX || u > cam.mnMaxX) ok = false;
         if (v < cam.mnMinY || v > cam.mnMaxY) ok = false;
         // bForward / bBackward (ORBmatcher.cc:1497-1510): tlc = Rlw*twc + tlw, twc = -Rcw^T * tcw
-        const float* Tl = Tlw + (size_t)pair * 16;
-        float twx, twy, twz, s;
-        s = (-T[0]) * T[3] + (-T[4]) * T[7]; twx = s + (-T[8]) * T[11];
-        s = (-T[1]) * T[3] + (-T[5]) * T[7]; twy = s + (-T[9]) * T[11];
-        s = (-T[2]) * T[3] + (-T[6]) * T[7]; twz = s + (-T[10]) * T[11];
+        float twx, twy, twz, s_;
+        s_ = (-T[0]) * T[3] + (-T[4]) * T[7]; twx = s_ + (-T[8]) * T[11];
+        s_ = (-T[1]) * T[3] + (-T[5]) * T[7]; twy = s_ + (-T[9]) * T[11];
+        s_ = (-T[2]) * T[3] + (-T[6]) * T[7]; twz = s_ + (-T[10]) * T[11];
         float lx, ly, lz;
         sd_mat3_mul_add(Tl, twx, twy, twz, lx, ly, lz);
-        const bool bForward = lz > cam.mb && !bMono, bBackward = -lz > cam.mb && !bMono;
-        const int nLastOctave = kp[oL].octave;
-        radius = th * P.lv[nLastOctave].scale;
+        const bool bForward = lz > cam.mb && !A.bMono, bBackward = -lz > cam.mb && !A.bMono;
+        radius = A.th * P.lv[nLastOctave].scale;
         if (bForward) { minLevel = nLastOctave; maxLevel = -1; }
         else if (bBackward) { minLevel = 0; maxLevel = nLastOctave; }
         else { minLevel = nLastOctave - 1; maxLevel = nLastOctave + 1; }
     }
-    if (ok) {
-        const float wInv = (float)SD_GRID_COLS / (cam.mnMaxX - cam.mnMinX);
-        const float hInv = (float)SD_GRID_ROWS / (cam.mnMaxY - cam.mnMinY);
-        const int nMinCellX = max(0, (int)floorf((u - cam.mnMinX - radius) * wInv));
-        const int nMaxCellX = min(SD_GRID_COLS - 1, (int)ceilf((u - cam.mnMinX + radius) * wInv));
-        const int nMinCellY = max(0, (int)floorf((v - cam.mnMinY - radius) * hInv));
-        const int nMaxCellY = min(SD_GRID_ROWS - 1, (int)ceilf((v - cam.mnMinY + radius) * hInv));
-        if (nMinCellX >= SD_GRID_COLS || nMaxCellX < 0 || nMinCellY >= SD_GRID_ROWS || nMaxCellY < 0) ok = false;
-        if (ok) {
-            const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
-            const uint4* dl = (const uint4*)(dmp + oL * 32);
-            const uint4 l0 = dl[0], l1 = dl[1];
-            const sd_keypoint* kC = kp + (size_t)imgC * cap;
-            const short* cellC = cellOf + (size_t)imgC * cap;
-            const float* urC = uRight + (size_t)imgC * cap;
-            const uint8_t* dC = desc + (size_t)imgC * cap * 32;
-            const float ur = u - cam.mbf * invzc;
-            const unsigned short* sorted = sortedIdx + (size_t)imgC * cap;
-            const unsigned short* cs = cellStart + (size_t)imgC * (SD_GRID_CELLS + 8);
-            // GetFeaturesInArea visits cells ix-major / iy-minor: cells (ix, minY..maxY) are one contiguous run of
-            // the sorted list.  Lane j < nCols fetches the run of column ix = nMinCellX + j; a wave prefix sum
-            // turns the <= 64 runs into one flat range so that 64 candidates are tested per step.
-            const int nColsA = nMaxCellX - nMinCellX + 1;
-            int runS = 0, runN = 0;
-            if (lane < nColsA) {
-                const int ix = nMinCellX + lane;
-                runS = cs[ix * SD_GRID_ROWS + nMinCellY];
-                runN = cs[ix * SD_GRID_ROWS + nMaxCellY + 1] - runS;
-            }
-            int incl = runN;
+    const float wInv = (float)SD_GRID_COLS / (cam.mnMaxX - cam.mnMinX);
+    const float hInv = (float)SD_GRID_ROWS / (cam.mnMaxY - cam.mnMinY);
+    const int nMinCellX = max(0, (int)floorf((u - cam.mnMinX - radius) * wInv));
+    const int nMaxCellX = min(SD_GRID_COLS - 1, (int)ceilf((u - cam.mnMinX + radius) * wInv));
+    const int nMinCellY = max(0, (int)floorf((v - cam.mnMinY - radius) * hInv));
+    const int nMaxCellY = min(SD_GRID_ROWS - 1, (int)ceilf((v - cam.mnMinY + radius) * hInv));
+    if (nMinCellX >= SD_GRID_COLS || nMaxCellX < 0 || nMinCellY >= SD_GRID_ROWS || nMaxCellY < 0) ok = false;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    const uint4* dl = (const uint4*)(A.dmp + oL * 32);
+    const uint4 l0 = dl[0], l1 = dl[1];
+    const sd_keypoint* kC = A.kp + (size_t)imgC * cap;
+    const short* cellC = A.cellOf + (size_t)imgC * cap;
+    const float* urC = A.uRight + (size_t)imgC * cap;
+    const uint8_t* dC = A.desc + (size_t)imgC * cap * 32;
+    const float ur = u - cam.mbf * invzc;
+    const unsigned short* sorted = A.sortedIdx + (size_t)imgC * cap;
+    const unsigned short* cs = A.cellStart + (size_t)imgC * (SD_GRID_CELLS + 8);
+    // GetFeaturesInArea visits cells ix-major / iy-minor: cells (ix, minY..maxY) are one contiguous run of the sorted list.
+    // Group lane j < nCols fetches the run of column ix = nMinCellX + j; a group prefix sum turns the runs into one flat range
+    // so that GW candidates are tested per step.
+    int nColsA = ok ? nMaxCellX - nMinCellX + 1 : 0;
+    if (nColsA > GW) { tooWide = true; nColsA = 0; }
+    int runS = 0, runN = 0;
+    if (gl < nColsA) {
+        const int ix = nMinCellX + gl;
+        runS = cs[ix * SD_GRID_ROWS + nMinCellY];
+        runN = cs[ix * SD_GRID_ROWS + nMaxCellY + 1] - runS;
+    }
+    int incl = runN;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-            const int total = __shfl(incl, 63, 64);
-            const int excl = incl - runN;
-            for (int base = 0; base < total; base += 64) {
-                const int t = base + lane;
-                bool hit = false;
-                unsigned long long key = 0;
-                // owner column of flat index t: the last lane whose exclusive prefix is <= t
-                int col = 0;
-                for (int j = 1; j < nColsA; j++) {            // nColsA is wave-uniform and small (window / cell width)
-                    const int ej = __shfl(excl, j, 64);
-                    if (ej <= t) col = j;
-                }
-                const int cS = __shfl(runS, col, 64), cE = __shfl(excl, col, 64);
-                if (t < total) {
-                    // everything a candidate needs is requested as soon as its index is known (one round trip, not one per test)
-                    const int i2 = sorted[cS + (t - cE)];
-                    const sd_keypoint* kq = kC + i2;
-                    const float kx = kq->x, ky = kq->y;
-                    const int koct = kq->octave;
-                    const float r2 = urC[i2];
-                    const int cellKey = cellC[i2];
-                    const uint4* dr = (const uint4*)(dC + (size_t)i2 * 32);
-                    const uint4 d0 = dr[0], d1 = dr[1];
-                    bool lv = true;
-                    if (bCheckLevels) {
-                        if (koct < minLevel) lv = false;
-                        if (maxLevel >= 0 && koct > maxLevel) lv = false;
-                    }
-                    const float distx = kx - u, disty = ky - v;
-                    bool rOk = true;
-                    if (r2 > 0) { const float er = fabsf(ur - r2); if (er > radius) rOk = false; }
-                    const int dist = sd_hamming256(l0, l1, d0, d1);
-                    if (lv && fabsf(distx) < radius && fabsf(disty) < radius && rOk && dist <= SD_TH_HIGH) {
-                        hit = true;
-                        key = ((unsigned long long)dist << 32) | ((unsigned long long)cellKey << 16) | (unsigned)i2;
-                    }
-                }
-                const unsigned long long m = __ballot(hit);
-                if (hit) {
-                    const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-                    if (pos < SD_PROJ_K) s_keys[wv][pos] = key;
-                }
-                n += __popcll(m);
+    for (int o = 1; o < GW; o <<= 1) { const int t = __shfl_up(incl, o, GW); if (gl >= o) incl += t; }
+    const int total = __shfl(incl, GW - 1, GW);
+    const int excl = incl - runN;
+    int colsU = nColsA;                                            // wave-uniform bounds
+#pragma unroll
+    for (int o = GW; o < 64; o <<= 1) colsU = max(colsU, __shfl_xor(colsU, o, 64));
+    colsU = __builtin_amdgcn_readfirstlane(colsU);
+    for (int base = 0; __any(base < total); base += GW) {
+        const int t = base + gl;
+        bool hit = false;
+        unsigned long long key = 0;
+        // owner column of flat index t: the last group lane whose exclusive prefix is <= t
+        int col = 0;
+        for (int j = 1; j < colsU; j++) {
+            const int ej = __shfl(excl, j, GW);
+            if (j < nColsA && ej <= t) col = j;
+        }
+        const int cS = __shfl(runS, col, GW), cE = __shfl(excl, col, GW);
+        if (t < total) {
+            // everything a candidate needs is requested as soon as its index is known (one round trip, not one per test)
+            const int i2 = sorted[cS + (t - cE)];
+            const sd_keypoint* kq = kC + i2;
+            const float kx = kq->x, ky = kq->y;
+            const int koct = kq->octave;
+            const float r2 = urC[i2];
+            const int cellKey = cellC[i2];
+            const uint4* dr = (const uint4*)(dC + (size_t)i2 * 32);
+            const uint4 d0 = dr[0], d1 = dr[1];
+            bool lv = true;
+            if (bCheckLevels) {
+                if (koct < minLevel) lv = false;
+                if (maxLevel >= 0 && koct > maxLevel) lv = false;
+            }
+            const float distx = kx - u, disty = ky - v;
+            bool rOk = true;
+            if (r2 > 0) { const float er = fabsf(ur - r2); if (er > radius) rOk = false; }
+            const int dist = sd_hamming256(l0, l1, d0, d1);
+            if (lv && fabsf(distx) < radius && fabsf(disty) < radius && rOk && dist <= SD_TH_HIGH) {
+                hit = true;
+                key = ((unsigned long long)dist << 32) | ((unsigned long long)cellKey << 16) | (unsigned)i2;
             }
         }
+        const unsigned long long mAll = __ballot(hit);
+        const unsigned long long m = GW == 64 ? mAll : (mAll >> gshift) & ((1ull << (GW & 63)) - 1ull);
+        if (hit) {
+            const int pos = n + __popcll(m & ((1ull << gl) - 1ull));
+            if (pos < GW) keys[pos] = key;
+        }
+        n += __popcll(m);
     }
-    if (n > SD_PROJ_K) { if (lane == 0) atomicOr(errFlag, 4); n = SD_PROJ_K; }
-    // wave-wide bitonic sort of <= 64 keys (one per lane), ascending.  The keys sit in lanes 0 .. n-1 (the rest hold the
-    // maximum), so a network over the first m = 2^ceil(log2 n) lanes is enough: windows hold ~5-15 candidates, which
-    // makes this 6-10 compare-exchange stages instead of 21.
-    unsigned long long key = lane < n ? s_keys[wv][lane] : ~0ull;
-    int m = 2;
-    while (m < n) m <<= 1;
-    for (int k = 2; k <= m && n > 1; k <<= 1)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave's LDS writes are done
+    // group-wide bitonic sort of <= GW keys (one per lane), ascending.  The keys sit in lanes 0 .. n-1 (the rest hold the
+    // maximum), so a network over the first m = 2^ceil(log2 n) lanes is enough: windows hold few candidates, which makes this
+    // 3-10 compare-exchange stages instead of 21.
+    const int nk = min(n, GW);
+    unsigned long long key = gl < nk ? keys[gl] : ~0ull;
+    int mU = nk;
+#pragma unroll
+    for (int o = GW; o < 64; o <<= 1) mU = max(mU, __shfl_xor(mU, o, 64));
+    mU = __builtin_amdgcn_readfirstlane(mU);
+    int m2 = 2;
+    while (m2 < mU) m2 <<= 1;
+    for (int k = 2; k <= m2 && mU > 1; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)key, j, 64);
             const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(key >> 32), j, 64);
             const unsigned long long other = ((unsigned long long)hi << 32) | lo;
-            const bool up = ((lane & k) == 0);
-            const bool lower = ((lane & j) == 0);
+            const bool up = ((gl & k) == 0);
+            const bool lower = ((gl & j) == 0);
             const bool takeMin = (up == lower);
             key = takeMin ? (key < other ? key : other) : (key > other ? key : other);
         }
-    if (lane < n) cand[oOut * SD_PROJ_K + lane] = (unsigned short)(key & 0xFFFFu);
-    if (lane == 0) ncand[oOut] = (uint8_t)n;
+    keyOut = key;
+    return n;
+}
+
+__global__ void __launch_bounds__(256) k_proj_candidates(const SdProjArgs A)
+{
+    __shared__ unsigned long long s_keys[4][SD_PROJ_K];
+    const int pair = blockIdx.y;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int Nl = A.count[A.pairIdx[pair].y];
+    const int cap = A.P->kpCap;
+    const int iw = (blockIdx.x * 4 + wv) * 4;                       // first of the wave's four points
+    if (iw >= Nl) return;
+    const int sub = lane >> 4, gl = lane & 15;
+    const int i = iw + sub;
+    const bool live = i < Nl;
+    unsigned long long key;
+    bool wide;
+    const int n = sd_proj_point<16>(A, pair, i, live, gl, lane & 48, s_keys[wv] + 16 * sub, key, wide);
+    const bool redo = live && (wide || n > 16);
+    const size_t oOut = (size_t)pair * cap + i;
+    if (live && !redo) {
+        if (gl < n) A.cand[oOut * SD_PROJ_K + gl] = (unsigned short)(key & 0xFFFFu);
+        if (gl == 0) A.ncand[oOut] = (uint8_t)n;
+    }
+    unsigned long long redoMask = __ballot(redo && gl == 0);
+    while (redoMask) {                                               // rare: the whole wave takes the point
+        const int s = (__ffsll((long long)redoMask) - 1) >> 4;
+        redoMask &= redoMask - 1;
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long key64;
+        bool wide64;
+        int n64 = sd_proj_point<64>(A, pair, iw + s, true, lane, 0, s_keys[wv], key64, wide64);
+        if (n64 > SD_PROJ_K) { if (lane == 0) atomicOr(A.errFlag, 4); n64 = SD_PROJ_K; }
+        const size_t o64 = (size_t)pair * cap + iw + s;
+        if (lane < n64) A.cand[o64 * SD_PROJ_K + lane] = (unsigned short)(key64 & 0xFFFFu);
+        if (lane == 0) A.ncand[o64] = (uint8_t)n64;
+    }
 }
 
 // Phase B: one wave per frame pair walks the Last-frame points in index order (the order that decides

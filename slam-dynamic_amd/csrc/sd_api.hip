@@ -990,11 +990,13 @@ int sd_batch_search_by_projection(sd_batch* b, int n_pairs, const int32_t* cur_i
     const int cap = b->plan.kpCap;
     {
         ProfScope ps(b, s, K_PROJ_A);
-        dim3 grd((cap + 3) / 4, n_pairs);
-        hipLaunchKernelGGL(k_proj_candidates, grd, dim3(256), 0, s, b->d_kp, b->d_desc, b->d_uright, b->d_count, b->d_cellOf, b->d_sortedIdx,
-                           b->d_cellStart, b->d_xw,
-                           b->d_flags, d_mp_desc ? d_mp_desc : b->d_desc, dTc, dTl, b->d_pcand, b->d_pncand, b->d_err, b->d_plan,
-                           to_cam(cam), th, bMono, b->d_pairIdx);
+        dim3 grd((cap + 15) / 16, n_pairs);                 // 16 points per workgroup: four per wave, 16 lanes each
+        SdProjArgs pa;
+        pa.kp = b->d_kp; pa.desc = b->d_desc; pa.uRight = b->d_uright; pa.count = b->d_count; pa.cellOf = b->d_cellOf;
+        pa.sortedIdx = b->d_sortedIdx; pa.cellStart = b->d_cellStart; pa.xw = b->d_xw; pa.flags = b->d_flags;
+        pa.dmp = d_mp_desc ? d_mp_desc : b->d_desc; pa.Tcw = dTc; pa.Tlw = dTl; pa.cand = b->d_pcand; pa.ncand = b->d_pncand;
+        pa.errFlag = b->d_err; pa.P = b->d_plan; pa.cam = to_cam(cam); pa.th = th; pa.bMono = bMono; pa.pairIdx = b->d_pairIdx;
+        hipLaunchKernelGGL(k_proj_candidates, grd, dim3(256), 0, s, pa);
     }
     LAUNCH_CHECK("k_proj_candidates");
     {

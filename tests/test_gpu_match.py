@@ -56,11 +56,13 @@ def test_unproject(seq, fe, orc):
         assert np.array_equal(xw[:n].view(np.uint32), oxw.view(np.uint32))
 
 
-@pytest.mark.parametrize("th,obs_frac,occ_frac", [(7.0, 0.0, 0.0), (15.0, 0.0, 0.0), (15.0, 0.6, 0.05), (40.0, 1.0, 0.1)])
+@pytest.mark.parametrize("th,obs_frac,occ_frac", [(7.0, 0.0, 0.0), (15.0, 0.0, 0.0), (15.0, 0.6, 0.05), (40.0, 1.0, 0.1),
+                                                     (60.0, 0.3, 0.05)])
 def test_search_by_projection(seq, fe, orc, th, obs_frac, occ_frac):
     """Frame t matched against frame t-1.  obs_frac > 0 marks Last-frame points as map points with
     observations (they lock the keypoint they take, ORBmatcher.cc:462-465); occ_frac marks Current
-    keypoints as already holding such a point.  th = 40 forces many contested keypoints."""
+    keypoints as already holding such a point.  th = 40 forces many contested keypoints; th = 60 makes the windows wider than
+    16 grid columns (the whole-wave path of k_proj_candidates)."""
     import torch
     b, T, cam = seq["b"], seq["T"], seq["cam"]
     cam10 = fe.camera_array(cam)
@@ -147,3 +149,44 @@ def test_reprojection_residuals_match_to_1e5(seq, fe, orc):
     assert rg.shape == ro.shape and len(rg) == len(pairs)
     assert np.max(np.abs(rg - ro)) <= 1e-5
     assert np.array_equal(rg, ro)            # in fact identical: the inputs are bit-identical
+
+
+def test_search_by_projection_crowded_windows(gpu, fe, orc, synth):
+    """Every descriptor zeroed: each window member is a hit at distance 0, so points collect more than 16 candidates (the
+    whole-wave path of k_proj_candidates) and every choice is decided by the visiting order of GetFeaturesInArea alone."""
+    cfg = synth.KITTI_STEREO
+    T = 2
+    frames = [synth.stereo_frame(seq=6, t=t) for t in range(T)]
+    ex = fe.ORBextractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+    b = fe.Batch(ex, cfg["width"], cfg["height"], 2 * T)
+    try:
+        b.extract_host(np.stack([im for (l, r, _) in frames for im in (l, r)]))
+        b.stereo_match(T, cfg["bf"], cfg["fx"])
+        cam = fe.make_camera(cfg)
+        cam10 = fe.camera_array(cam)
+        b.assign_grid(2 * T, cam)
+        I = np.eye(4, dtype=np.float32)
+        b.unproject(2, T, cam, np.tile(I, (T, 1, 1)))
+        ref = []
+        for t in range(T):
+            kp, desc, _ = b.download(2 * t)
+            n = len(kp)
+            ur, dep, _ = b.download_stereo(t)
+            xw, fl = b.download_mappoints(2 * t)
+            ref.append(dict(kp=kp[:n].copy(), ur=ur[:n].copy(), xw=xw[:n].copy(), fl=fl[:n].copy()))
+        _, d_desc, _, cap = b.results_device()
+        fe.as_torch_u8(d_desc, 2 * T * cap * 32).zero_()
+        b.sync()
+        th = 25.0
+        b.search_by_projection([2], [0], I[None], I[None], cam, th, False, True)
+        cur, last = ref[1], ref[0]
+        scale = orc.Extractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"]).scale.copy()
+        zc = np.zeros((len(cur["kp"]), 32), np.uint8); zl = np.zeros((len(last["kp"]), 32), np.uint8)
+        om, opairs, onm = orc.search_by_projection(cur["kp"], zc, cur["ur"], last["kp"], zl, last["xw"], last["fl"],
+                                                   I, I, cam10, scale, th, False, True)
+        m, pairs, nm = b.download_matches(0)
+        assert nm == onm and onm > 100
+        assert np.array_equal(pairs, opairs)
+        assert np.array_equal(m[:len(cur["kp"])], om)
+    finally:
+        b.close()
