@@ -367,9 +367,10 @@ def main():
         bt, st = batches[k], streams[k].cuda_stream
         f0 = k * Bs
         g0 = d_gray[f0 * imgs_per_frame:]
-        if args.workload == "rgbd":
-            fe.cvt_gray_device(d_rgb[f0:].data_ptr(), W, H, W * 3, W * H * 3, 3, 1, g0.data_ptr(), Wg, Wg * H, Bs, st)
-        bt.extract_device(g0.data_ptr(), Wg, Wg * H, n_img, st)
+        if args.workload == "rgbd":            # GrabImageRGBD's cvtColor runs inside the level-0 copy of the extractor (same results as the two calls)
+            bt.extract_color_device(d_rgb[f0:].data_ptr(), W * 3, W * H * 3, n_img, True, st)
+        else:
+            bt.extract_device(g0.data_ptr(), Wg, Wg * H, n_img, st)
         if args.workload == "rgbd":
             bt.rgbd_from_u16(d_depth[f0:].data_ptr(), W, W * H, Bs, depth_factor, cfg["bf"], st)
         else:

@@ -78,6 +78,12 @@ int sd_batch_kp_capacity(const sd_batch* b, int* cap); /* max keypoints one imag
  * `stream`; results stay on the device. */
 int sd_batch_extract_device(sd_batch* b, const uint8_t* d_gray, size_t stride, size_t image_pitch, int n_images,
                             void* stream);
+/* The same for 3-channel 8-bit input (BGR, or RGB when rgb_order != 0: Camera.RGB): Tracking::GrabImageRGBD / GrabImageStereo's
+ * cvtColor (src/Tracking.cc:179-198,259-268) fused into the extractor's level-0 copy (src/ORBextractor.cc:1127-1128), so the
+ * gray image is never stored; it is the interior of pyramid level 0 (sd_batch_pyramid_level).  Results are identical to
+ * sd_cvt_gray_device followed by sd_batch_extract_device.  `stride` in bytes (>= 3 * width). */
+int sd_batch_extract_color_device(sd_batch* b, const uint8_t* d_src, size_t stride, size_t image_pitch, int rgb_order, int n_images,
+                                  void* stream);
 /* Same, from host memory (upload + extract + stream sync).  Empty image (NULL / 0 size) => 0 keypoints,
  * as ORBextractor.cc:1046-1047. */
 int sd_batch_extract_host(sd_batch* b, const uint8_t* gray, size_t stride, size_t image_pitch, int n_images);

@@ -385,3 +385,63 @@ __global__ void __launch_bounds__(256) k_cvt_gray3_wide(const uint8_t* __restric
         drow[k] = (uint8_t)((r * 4899 + gg * 9617 + b * 1868 + (1 << 13)) >> 14);
     }
 }
+
+// ------------------------------------------------------------------ cvtColor + pyramid level 0 in one pass
+// GrabImageRGBD / GrabImageStereo convert to gray and hand the gray image to the extractor, whose first step copies it into
+// the padded level-0 plane (ORBextractor.cc:1127-1128).  For 3-channel input already in HBM the two steps are one pass: the
+// gray image is never written and re-read (it IS the interior of level 0).  The arithmetic is sd_gray4's.
+//   k_pyr_level0_rgb        all padded rows, the 16-byte groups that lie fully inside the interior: items flattened over
+//                           (row, group) so that every wave is full; three unaligned 16-byte loads, one aligned 16-byte store
+//   k_pyr_level0_rgb_frame  the four groups per row that touch the reflected frame (X < 0 or X >= W): per-byte path
+__global__ void __launch_bounds__(256) k_pyr_level0_rgb(const uint8_t* __restrict__ src, size_t sstride, size_t spitch, int rgbOrder,
+                                                        uint8_t* __restrict__ pyr, const SdDevPlan* __restrict__ PP, int groupsPerRow,
+                                                        uint32_t gprInv)
+{
+    const SdDevPlan& P = *PP;
+    const SdLevel& g = P.lv[0];
+    const int img = blockIdx.y;
+    const uint32_t item = blockIdx.x * 256u + threadIdx.x;
+    const int Yp = (int)__umulhi(item, gprInv);            // item / groupsPerRow
+    if (Yp >= g.H + 2 * SD_EDGE) return;
+    const int X0 = 16 * (int)(item - (uint32_t)Yp * (uint32_t)groupsPerRow);          // interior groups start at column 0
+    const int sy = sd_reflect101(Yp - SD_EDGE, g.H);
+    const uint8_t* srow = src + (size_t)img * spitch + (size_t)sy * sstride;
+    const int cr = rgbOrder ? 4899 : 1868, cb = rgbOrder ? 1868 : 4899;
+    const sd_u128_unaligned* s = (const sd_u128_unaligned*)(srow + 3 * X0);
+    const sd_u4v a = s[0], b = s[1], c = s[2];
+    sd_u4v o;
+    o.x = sd_gray4(a.x, a.y, a.z, cr, cb); o.y = sd_gray4(a.w, b.x, b.y, cr, cb);
+    o.z = sd_gray4(b.z, b.w, c.x, cr, cb); o.w = sd_gray4(c.y, c.z, c.w, cr, cb);
+    uint8_t* drow = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)Yp * g.stride;
+    *(sd_u4v*)(drow + SD_XOFF + X0) = o;
+}
+
+__global__ void __launch_bounds__(256) k_pyr_level0_rgb_frame(const uint8_t* __restrict__ src, size_t sstride, size_t spitch, int rgbOrder,
+                                                              uint8_t* __restrict__ pyr, const SdDevPlan* __restrict__ PP, int groupsPerRow,
+                                                              int tailGroups)
+{
+    const SdDevPlan& P = *PP;
+    const SdLevel& g = P.lv[0];
+    const int img = blockIdx.y;
+    const int per = 2 + tailGroups;                         // frame groups per row: two on the left (X0 = -32, -16), the rest on the right
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    const int Yp = item / per, q = item - Yp * per;
+    if (Yp >= g.H + 2 * SD_EDGE) return;
+    const int X0 = q < 2 ? -SD_XOFF + 16 * q : 16 * (groupsPerRow + q - 2);
+    const int sy = sd_reflect101(Yp - SD_EDGE, g.H);
+    const uint8_t* srow = src + (size_t)img * spitch + (size_t)sy * sstride;
+    const int cr = rgbOrder ? 4899 : 1868, cb = rgbOrder ? 1868 : 4899;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int X = X0 + k;
+        X = X < -SD_EDGE ? -SD_EDGE : (X > g.W + SD_EDGE - 1 ? g.W + SD_EDGE - 1 : X);     // margin bytes: any value
+        const uint8_t* p = srow + 3 * sd_reflect101(X, g.W);
+        const uint32_t v = (__umul24((uint32_t)p[0], (uint32_t)cr) + __umul24((uint32_t)p[1], 9617u) + __umul24((uint32_t)p[2], (uint32_t)cb) + 8192u) >> 14;
+        w[k >> 2] |= v << (8 * (k & 3));
+    }
+    sd_u4v o;
+    o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+    uint8_t* drow = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)Yp * g.stride;
+    *(sd_u4v*)(drow + SD_XOFF + X0) = o;
+}

@@ -434,8 +434,22 @@ static int check_launch(const char* name)
 }
 #define LAUNCH_CHECK(name) do { int rc_ = check_launch(name); if (rc_ != SD_OK) return rc_; } while (0)
 
+static int extract_impl(sd_batch* b, const uint8_t* d_gray, size_t stride, size_t image_pitch, int n_images, void* stream_, int colorMode);
+
 int sd_batch_extract_device(sd_batch* b, const uint8_t* d_gray, size_t stride, size_t image_pitch, int n_images,
                             void* stream_)
+{
+    return extract_impl(b, d_gray, stride, image_pitch, n_images, stream_, 0);
+}
+
+int sd_batch_extract_color_device(sd_batch* b, const uint8_t* d_src, size_t stride, size_t image_pitch, int rgb_order, int n_images,
+                                  void* stream_)
+{
+    return extract_impl(b, d_src, stride, image_pitch, n_images, stream_, rgb_order ? 2 : 1);
+}
+
+// colorMode 0: 8-bit gray input; 1 / 2: 3-channel BGR / RGB input converted on the way into level 0
+static int extract_impl(sd_batch* b, const uint8_t* d_gray, size_t stride, size_t image_pitch, int n_images, void* stream_, int colorMode)
 {
     if (!b || n_images < 0 || n_images > b->maxImages) return set_err(SD_ERR_INVALID, "bad extract arguments");
     hipStream_t s = stream_ ? (hipStream_t)stream_ : b->stream;
@@ -445,13 +459,23 @@ int sd_batch_extract_device(sd_batch* b, const uint8_t* d_gray, size_t stride, s
     if (n_images == 0) return SD_OK;
     if (!d_gray) return set_err(SD_ERR_INVALID, "null image pointer");
     const SdPlan& P = b->plan;
-    if (stride < (size_t)P.W) return set_err(SD_ERR_INVALID, "stride smaller than width");
+    if (stride < (size_t)P.W * (colorMode ? 3 : 1)) return set_err(SD_ERR_INVALID, "stride smaller than width");
     const int nl = P.nlevels;
     {
         ProfScope ps(b, s, K_PYR0);
         const SdLevel& g = P.lv[0];
         dim3 blk(64, 4), grd(((g.W + SD_XOFF + SD_EDGE + 15) / 16 + 63) / 64, (g.H + 2 * SD_EDGE + 3) / 4, n_images);
-        hipLaunchKernelGGL(k_pyr_level0, grd, blk, 0, s, d_gray, stride, image_pitch, b->d_pyr, b->d_plan);
+        if (colorMode) {
+            const int gpr = g.W / 16;                                                    // groups fully inside the interior
+            const int lastGroup = (g.W + SD_EDGE - 1) / 16;                              // group of the last frame column
+            const int tail = lastGroup - gpr + 1, rows = g.H + 2 * SD_EDGE;
+            const uint32_t gprInv = 0xFFFFFFFFu / (uint32_t)gpr + 1u;
+            hipLaunchKernelGGL(k_pyr_level0_rgb, dim3((unsigned)((size_t)rows * gpr + 255) / 256, n_images), dim3(256), 0, s, d_gray, stride, image_pitch,
+                               colorMode == 2 ? 1 : 0, b->d_pyr, b->d_plan, gpr, gprInv);
+            hipLaunchKernelGGL(k_pyr_level0_rgb_frame, dim3((unsigned)(rows * (2 + tail) + 255) / 256, n_images), dim3(256), 0, s, d_gray, stride,
+                               image_pitch, colorMode == 2 ? 1 : 0, b->d_pyr, b->d_plan, gpr, tail);
+        }
+        else hipLaunchKernelGGL(k_pyr_level0, grd, blk, 0, s, d_gray, stride, image_pitch, b->d_pyr, b->d_plan);
     }
     LAUNCH_CHECK("k_pyr_level0");
     if (b->pyrTiles.empty()) {          // once per batch: LDS extents of k_pyr_level_tiles per level, or the per-thread kernel as a fallback

@@ -55,6 +55,7 @@ def lib():
         L.sd_batch_destroy.argtypes = [vp]
         L.sd_batch_kp_capacity.argtypes = [vp, C.POINTER(i)]
         L.sd_batch_extract_device.argtypes = [vp, vp, sz, sz, i, vp]
+        L.sd_batch_extract_color_device.argtypes = [vp, vp, sz, sz, i, i, vp]
         L.sd_batch_extract_host.argtypes = [vp, vp, sz, sz, i]
         L.sd_batch_results_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i)]
         L.sd_batch_counts.argtypes = [vp, vp, i]
@@ -193,6 +194,11 @@ class Batch:
 
     def extract_device(self, d_ptr, stride, pitch, n, stream=None):
         check(lib().sd_batch_extract_device(self.h, C.c_void_p(d_ptr), stride, pitch, n, C.c_void_p(stream or 0)))
+
+    def extract_color_device(self, d_ptr, stride, pitch, n, rgb_order=True, stream=None):
+        """cvtColor + operator() for 3-channel images in HBM (GrabImageRGBD's conversion fused into pyramid level 0)."""
+        check(lib().sd_batch_extract_color_device(self.h, C.c_void_p(d_ptr), stride, pitch, int(bool(rgb_order)), n,
+                                                  C.c_void_p(stream or 0)))
 
     def sync(self):
         check(lib().sd_batch_sync(self.h))

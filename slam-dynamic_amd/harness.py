@@ -128,7 +128,6 @@ class DynamicFrontEnd:
         self.last = None
         W, H = cfg["width"], cfg["height"]
         self.d_rgb = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
-        self.d_gray = torch.empty((H, W), dtype=torch.uint8, device="cuda")
         self.d_depth = torch.empty((H, W), dtype=torch.int16, device="cuda")
         self.depth_factor = float(np.float32(1.0) / np.float32(cfg.get("depth_map_factor", 1.0)))
         self.I = np.eye(4, dtype=np.float32)[None]
@@ -145,8 +144,7 @@ class DynamicFrontEnd:
         # Tracking::GrabImageRGBD (Tracking.cc:256-272): cvtColor + depth scaling; Frame ctor (Frame.cc:297-323): extract + RGB-D stereo
         self.d_rgb.copy_(torch.from_numpy(np.ascontiguousarray(im_rgb)), non_blocking=False)
         self.d_depth.copy_(torch.from_numpy(np.ascontiguousarray(im_depth_u16).view(np.int16)))
-        fe.cvt_gray_device(self.d_rgb.data_ptr(), W, H, W * 3, W * H * 3, 3, int(self.rgb_order), self.d_gray.data_ptr(), W, W * H, 1, st)
-        b.extract_device(self.d_gray.data_ptr(), W, W * H, 1, st)
+        b.extract_color_device(self.d_rgb.data_ptr(), W * 3, W * H * 3, 1, bool(self.rgb_order), st)
         b.rgbd_from_u16(self.d_depth.data_ptr(), W, W * H, 1, self.depth_factor, cfg["bf"], st)
         # Frame::boxTrack (Frame.cc:324) on the host, then firstSeparate + the static/dynamic split (:329-367)
         boxes = np.asarray(boxes, np.float64).reshape(-1, 4)

@@ -95,3 +95,35 @@ def test_undistort_keypoints_of_a_batch(gpu, fe, orc, synth):
             exp["x"] = u[:, 0]; exp["y"] = u[:, 1]
         assert un.tobytes() == exp.tobytes()
     b.close()
+
+
+@pytest.mark.parametrize("rgb", [True, False])
+def test_extract_color_equals_cvt_then_extract(gpu, fe, orc, synth, rgb):
+    """sd_batch_extract_color_device (cvtColor inside the level-0 copy) == sd_cvt_gray_device + sd_batch_extract_device:
+    level 0 of the pyramid, keypoints and descriptors, bit for bit; and the gray values are the oracle's."""
+    import torch
+    cfg = synth.KITTI03_RGBD
+    W, H = cfg["width"], cfg["height"]
+    frames = [synth.rgbd_frame(3, t, cfg)[0] for t in range(2)]
+    rng = np.random.default_rng(5)
+    src = np.stack(frames).copy()
+    src[..., 1] = np.roll(src[..., 1], 3, axis=2)            # make the three channels differ
+    src[..., 2] = (src[..., 2].astype(np.int32) * 3 // 4 + rng.integers(0, 30, src[..., 2].shape)).astype(np.uint8)
+    d_src = torch.from_numpy(src).cuda()
+    d_gray = torch.empty((2, H, W), dtype=torch.uint8, device="cuda")
+    ex = fe.ORBextractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+    b1 = fe.Batch(ex, W, H, 2); b2 = fe.Batch(ex, W, H, 2)
+    try:
+        fe.cvt_gray_device(d_src.data_ptr(), W, H, W * 3, W * H * 3, 3, int(rgb), d_gray.data_ptr(), W, W * H, 2)
+        torch.cuda.synchronize()
+        b1.extract_device(d_gray.data_ptr(), W, W * H, 2); b1.sync()
+        b2.extract_color_device(d_src.data_ptr(), W * 3, W * H * 3, 2, rgb); b2.sync()
+        for i in range(2):
+            p1, p2 = b1.pyramid(i, 0), b2.pyramid(i, 0)
+            assert np.array_equal(p1, p2)
+            assert np.array_equal(p2[19:-19, 19:-19], orc.cvt_gray(src[i], rgb))
+            k1, d1, l1 = b1.download(i); k2, d2, l2 = b2.download(i)
+            assert len(k1) > 1500 and np.array_equal(l1, l2)
+            assert k1.tobytes() == k2.tobytes() and np.array_equal(d1, d2)
+    finally:
+        b1.close(); b2.close()
