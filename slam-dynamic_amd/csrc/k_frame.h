@@ -70,6 +70,7 @@ __global__ void __launch_bounds__(256) k_stereo_match(const sd_keypoint* __restr
                                                       const SdDevPlan* __restrict__ PP, float mbf, float fx)
 {
     const SdDevPlan& P = *PP;
+    __shared__ __align__(16) uint8_t s_win[4][11 * 12 + 11 * 24 + 4];       // per wave: left window + right strip
     const int f = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -90,25 +91,30 @@ __global__ void __launch_bounds__(256) k_stereo_match(const sd_keypoint* __restr
     unsigned bestKey = ((unsigned)SD_TH_HIGH << 16) | 0xFFFFu;
     const sd_keypoint* kR = kp + (size_t)imgR * P.kpCap;
     const uint8_t* dR = desc + (size_t)imgR * P.kpCap * 32;
+    // lane l holds scale[l]: the band radius of a right keypoint comes from a cross-lane read, not from a load chained behind its octave
+    const float scaleOfLane = lane < P.nlevels ? P.lv[lane].scale : 0.f;
     if (!(maxU < 0)) {
         // only right keypoints whose integer row lies within bandR (>= 2*scale_max + 1) rows can contain yi
         const int H0 = P.lv[0].H;
         const int* rs = rowStart + (size_t)f * (H0 + 8);
         const unsigned short* ridx = rowIdx + (size_t)f * P.kpCap;
         const int p0 = rs[max(yi - bandR, 0)], p1 = rs[min(yi + bandR, H0 - 1) + 1];
-        for (int p = p0 + lane; p < p1; p += 64) {
-            const int iR = ridx[p];
-            const sd_keypoint k = kR[iR];
-            const float r = 2.0f * P.lv[k.octave].scale;
-            const int maxr = (int)ceilf(k.y + r), minr = (int)floorf(k.y - r);
-            if (yi < minr || yi > maxr) continue;
-            if (k.octave < levelL - 1 || k.octave > levelL + 1) continue;
-            if (k.x >= minU && k.x <= maxU) {
-                const uint4* dr = (const uint4*)(dR + (size_t)iR * 32);
-                const unsigned dist = (unsigned)sd_hamming256(l0, l1, dr[0], dr[1]);
-                const unsigned key = (dist << 16) | (unsigned)iR;
-                bestKey = min(bestKey, key);
-            }
+        for (int pb = p0; pb < p1; pb += 64) {
+            const int p = pb + lane;
+            const bool in = p < p1;
+            // position, octave and descriptor of the candidate are requested together (one round trip after its index)
+            const int iR = in ? ridx[p] : 0;
+            const sd_keypoint* kq = kR + iR;
+            const float kx = kq->x, ky = kq->y;
+            const int koct = kq->octave;
+            const uint4* dr = (const uint4*)(dR + (size_t)iR * 32);
+            const uint4 d0 = dr[0], d1 = dr[1];
+            const float r = 2.0f * __shfl(scaleOfLane, koct, 64);
+            const int maxr = (int)ceilf(ky + r), minr = (int)floorf(ky - r);
+            const bool cand = in && !(yi < minr || yi > maxr) && !(koct < levelL - 1 || koct > levelL + 1) && kx >= minU && kx <= maxU;
+            const unsigned dist = (unsigned)sd_hamming256(l0, l1, d0, d1);
+            const unsigned key = (dist << 16) | (unsigned)iR;
+            if (cand) bestKey = min(bestKey, key);
         }
     }
 #pragma unroll
@@ -131,22 +137,43 @@ __global__ void __launch_bounds__(256) k_stereo_match(const sd_keypoint* __restr
             const int rowT = (int)(scaledvL - w);
             const uint8_t* IL = baseL + (ptrdiff_t)rowT * g.stride + (int)(scaleduL - w);
             const uint8_t* IR = baseR + (ptrdiff_t)rowT * g.stride + (int)(scaleduR0 - w);   // incR = 0 window
-            const int cL = IL[w * g.stride + w];
+            // The 11x11 left window and the 11x21 strip the right window slides over are staged in this wave's LDS with
+            // 99 unaligned dword requests (two per lane, one round trip); the 1331 absolute differences then read LDS bytes
+            // (the previous form issued 46 global byte-load instructions per keypoint and was bound by them).
+            uint8_t* sIL = s_win[threadIdx.x >> 6];              // [11][12]
+            uint8_t* sIR = sIL + 11 * 12;                        // [11][24]: columns -5 .. +18 of the incR = 0 window
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const int id = lane + 64 * it;
+                if (id < 33) {
+                    const int yy = id / 3, q = id - yy * 3;
+                    *(uint32_t*)(sIL + yy * 12 + 4 * q) = *(const sd_u32_una*)(IL + yy * g.stride + 4 * q);
+                } else if (id < 99) {
+                    const int j = id - 33, yy = j / 6, q = j - yy * 6;
+                    *(uint32_t*)(sIR + yy * 24 + 4 * q) = *(const sd_u32_una*)(IR + yy * g.stride - L + 4 * q);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): this wave's LDS writes are done
+            const int cL = sIL[w * 12 + w];
+            int cR[11];
+#pragma unroll
+            for (int k = 0; k < 11; k++) cR[k] = sIR[w * 24 + w + k];           // column (w + inc) + L, inc = k - L
             int sums[11];
 #pragma unroll
             for (int k = 0; k < 11; k++) sums[k] = 0;
             for (int p = lane; p < 121; p += 64) {
                 const int yy = p / 11, xx = p - yy * 11;
-                const int a = (int)IL[yy * g.stride + xx] - cL;
+                const int a = (int)sIL[yy * 12 + xx] - cL;
+                const uint8_t* rowR = sIR + yy * 24 + xx;
 #pragma unroll
                 for (int k = 0; k < 11; k++) {
-                    const int inc = k - L;
-                    const int cR = IR[w * g.stride + w + inc];
-                    const int b = (int)IR[yy * g.stride + xx + inc] - cR;
+                    const int b = (int)rowR[k] - cR[k];
                     const int d = a - b;
                     sums[k] += d < 0 ? -d : d;
                 }
             }
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int k = 0; k < 11; k++)
 #pragma unroll
