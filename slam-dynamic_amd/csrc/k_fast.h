@@ -5,10 +5,11 @@
 //            the scanned pixels start on a word boundary
 //   phase 1  ALL scanned pixels, 4 per thread from packed words: compass test.  Any 9-arc of the
 //            16-ring holds two ADJACENT compass points (ring 0,4,8,12), so a corner needs an adjacent
-//            compass pair both darker than v-T or both brighter than v+T (T = minTh); done on halved pixels, 4 px per 32-bit op.
+//            compass pair both darker than v-T or both brighter than v+T; done on halved pixels, 4 px per 32-bit op.
 //   phase 2  survivors (wave-ballot compacted): cornerScore (9-arc min / max as three 3-arcs) -> score tile; score >= T
 //            IS the FAST-9 test at T, so the corners fall out of the score (compacted again)
-//   phase 3  3x3 strict-maximum NMS on the corner list -> row bit masks; cell threshold = iniTh if any survivor >= iniTh
+//   phase 3  3x3 strict-maximum NMS on the corner list -> row bit masks
+//   phases 1-3 run at T = iniTh and, only for a cell without a survivor, again at T = minTh (the reference's retry)
 //   phase 4  row-major ordered emission (wave prefix sum over the row masks + popcount inside the row)
 // Same results as k_fast_cells (kept as the generic path for windows > 52 px); see that kernel's header
 // comment for why the threshold-free score map reproduces OpenCV's two-threshold behaviour.
@@ -63,14 +64,13 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
 {
     __shared__ __align__(16) uint8_t tile[SD_FS_MAXWIN * SD_FS_TW];
     __shared__ __align__(16) uint8_t score[SD_FS_SW * SD_FS_SW];
-    __shared__ unsigned long long rowAll[SD_FS_ROWS], rowIni[SD_FS_ROWS];   // NMS survivors per scan row: all / those >= iniTh
+    __shared__ unsigned long long rowAll[SD_FS_ROWS];                       // NMS survivors per scan row, one bit per column
     extern __shared__ __align__(16) unsigned char dyn_smem[];
     unsigned short* list1 = (unsigned short*)dyn_smem;              // [listCap] pixels that pass the compass test
     unsigned short* list2 = list1 + A.listCap;                      // [listCap] corners at minTh
     unsigned* kept = (unsigned*)(list2 + A.listCap);                // [listCap / 4 + 4] NMS maxima: (sy<<16)|(sx<<8)|score
-    __shared__ int s_cnt1, s_cnt2, s_cnt3, s_any;
+    __shared__ int s_cnt1, s_cnt2, s_cnt3;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int T = A.minTh;
     uint32_t* tileW = (uint32_t*)tile;
     uint32_t* scoreW = (uint32_t*)score;
     // XCD-aware order: grid = (8 * cells, image groups); the linear workgroup id % 8 = blockIdx.x % 8 picks the XCD
@@ -99,8 +99,8 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         }
         // only the frame and the scanned rows of the score tile are ever read: rows 0 .. sh+1
         for (int i = tid; i < (sh + 2) * (SD_FS_SW / 4); i += NT) scoreW[i] = 0;
-        if (tid < SD_FS_ROWS) { rowAll[tid] = 0; rowIni[tid] = 0; }
-        if (tid == 0) { s_cnt1 = 0; s_cnt2 = 0; s_cnt3 = 0; s_any = 0; }
+        if (tid < SD_FS_ROWS) rowAll[tid] = 0;
+        if (tid == 0) { s_cnt1 = 0; s_cnt2 = 0; s_cnt3 = 0; }
 #pragma unroll
         for (int k = 0; k < NR; k++) {
             const int y = y0 + k * (NT / 16);
@@ -113,10 +113,16 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         // loses a corner; the few extra survivors (+6 % measured) are rejected by the exact score of phase 2.
         // The adjacent-pair test over the cycle S-E-N-W collapses to (dS|dN) & (dE|dW); same for the brighter side.
         const uint32_t M7 = 0x7f7f7f7fu, G7 = 0x80808080u;
-        const uint32_t KG = G7 - (uint32_t)((T + 1) >> 1) * 0x01010101u;
         const int ng = (sw + 3) >> 2;
         const int shift = ng <= 8 ? 3 : 4;                 // items per scan row = 1 << shift (no division)
         const int nitems = sh << shift;
+        // The reference's order (ORBextractor.cc:809-816): FAST at iniTh; only a cell that yields NO keypoint is redone at minTh.
+        // Most cells of a textured image stop after the first pass, whose survivor lists are ~40 % shorter than minTh's.
+        int n3 = 0;
+#pragma nounroll
+        for (int pass = 0; pass < 2; pass++) {
+        const int T = pass ? A.minTh : A.iniTh;
+        const uint32_t KG = G7 - (uint32_t)((T + 1) >> 1) * 0x01010101u;
         for (int it0 = 0; it0 < nitems; it0 += NT) {
             const int it = it0 + tid;
             const int sy = it >> shift, gq = it & ((1 << shift) - 1);
@@ -201,7 +207,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         }
         __syncthreads();
         // ---- phase 3: 3x3 strict-maximum NMS over the corner list (zero frame = outside the scanned area); survivors go to a
-        //      compact list and set their bit in the row masks; the cell threshold is iniTh iff one of them reaches it
+        //      compact list and set their bit in the row masks
         const int n2 = s_cnt2;
         for (int i0 = 0; i0 < n2; i0 += NT) {
             const int i = i0 + tid;
@@ -215,21 +221,20 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 ok = s > q[-SD_FS_SW - 1] && s > q[-SD_FS_SW] && s > q[-SD_FS_SW + 1] && s > q[-1] && s > q[1] &&
                      s > q[SD_FS_SW - 1] && s > q[SD_FS_SW] && s > q[SD_FS_SW + 1];
                 key = ((unsigned)ent << 8) | (unsigned)s;
-                if (ok) {
-                    atomicOr(&rowAll[sy], 1ull << sx);
-                    if (s >= A.iniTh) { atomicOr(&rowIni[sy], 1ull << sx); s_any = 1; }
-                }
+                if (ok) atomicOr(&rowAll[sy], 1ull << sx);
             }
             const int slot = sd_wave_append(ok, &s_cnt3);
             if (ok) kept[slot] = key;
         }
         __syncthreads();
+        n3 = s_cnt3;
+        if (n3 > 0 || pass == 1 || A.iniTh == A.minTh) break;
+        if (tid == 0) { s_cnt1 = 0; s_cnt2 = 0; }          // nothing survived at iniTh: once more at minTh (the score tile keeps its, identical, values)
+        __syncthreads();
+        }
         // ---- phase 4: row-major emission.  rank of a survivor = survivors in the rows above (wave prefix sum over the row
         //      masks, one row per lane) + survivors to its left in its own row (popcount of the masked row word)
-        const int n3 = s_cnt3;
-        const bool any = s_any != 0;
-        const int Tc = any ? A.iniTh : A.minTh;
-        const unsigned long long* rows = any ? rowIni : rowAll;
+        const unsigned long long* rows = rowAll;
         const int rowPop = lane < SD_FS_ROWS ? __popcll(rows[lane]) : 0;
         int incl = rowPop;
 #pragma unroll
@@ -241,7 +246,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
             const unsigned key = i < n3 ? kept[i] : 0u;
             const int sx = (key >> 8) & 255, sy = key >> 16;
             const int base = __shfl(excl, sy, 64);
-            if (i < n3 && (int)(key & 255u) >= Tc) {
+            if (i < n3) {
                 const int rank = base + __popcll(rows[sy] & ((1ull << sx) - 1ull));
                 const uint32_t px = (uint32_t)(sx + 3 + c.jw), py = (uint32_t)(sy + 3 + c.ih);
                 if (rank < c.cap) out[rank] = px | (py << 12) | ((key & 255u) << 24);

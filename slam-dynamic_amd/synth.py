@@ -169,12 +169,16 @@ def mask_from_boxes(rows, width, height):
 
 
 def random_image(width, height, seed, kind="texture"):
-    """Small helper for unit tests: 'texture' (corner-rich) or 'noise' (uniform random bytes)."""
+    """Small helper for unit tests: 'texture' (corner-rich), 'noise' (uniform random bytes) or 'mixed' (half of it low-contrast)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     if kind == "noise":
         return rng.integers(0, 256, (height, width), dtype=np.uint8)
     tex = base_texture(width, height, seq=seed % 97, margin=0)
-    return np.ascontiguousarray(tex[:height, :width])
+    tex = np.ascontiguousarray(tex[:height, :width])
+    if kind == "mixed":            # left half at 1/8 contrast: cells whose corners only show at minThFAST (the extractor's retry), next to full-contrast cells
+        half = width // 2
+        tex[:, :half] = (100 + (tex[:, :half].astype(np.int32) - 128) // 8).astype(np.uint8)
+    return tex
 
 
 # ---------------------------------------------------------------------------------------------------------

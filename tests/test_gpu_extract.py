@@ -14,6 +14,9 @@ CASES = [
     (640, 480, 1500, 20, 7, "noise", 6),         # uniform noise: every cell saturated with corners
     (752, 480, 1200, 20, 7, "texture", 7),       # EuRoC-like size: different cell grid / nIni
     (331, 257, 500, 20, 7, "texture", 8),        # small, odd sizes
+    (640, 480, 1000, 20, 7, "mixed", 9),         # half the cells have corners at minThFAST only: the per-cell retry
+    (640, 480, 1000, 30, 5, "mixed", 11),
+    (640, 480, 1000, 7, 7, "texture", 10),       # iniThFAST == minThFAST: no retry
 ]
 
 
