@@ -156,7 +156,10 @@ __global__ void __launch_bounds__(256) k_pyr_level(uint8_t* __restrict__ pyr, co
     short4 re[SD_PYR_ROWS];
 #pragma unroll
     for (int r = 0; r < SD_PYR_ROWS; r++) re[r] = rt[sd_reflect101(min(Yb + 4 * r, HP - 1) - SD_EDGE, g.H)];
-    if (X0 >= 0 && X0 + 3 < g.W) {
+    // interior groups whose four source columns (+1) fit one 8-byte window (resize ratios up to 2); wider ratios and the
+    // groups on the reflected frame take the per-pixel path
+    const bool interior = X0 >= 0 && X0 + 3 < g.W;
+    if (interior && ct[X0 + 3].x - ct[X0].x <= 6) {
         const short4 c0 = ct[X0], c1 = ct[X0 + 1], c2 = ct[X0 + 2], c3 = ct[X0 + 3];
         const int sx0 = c0.x;
         const int o1 = 8 * (c1.x - sx0), o2 = 8 * (c2.x - sx0), o3 = 8 * (c3.x - sx0);

@@ -99,3 +99,23 @@ def test_other_scale_factors(gpu, fe, orc, synth, scale, levels):
     assert_kp_equal(kp, rk, "scale %.1f" % scale)
     assert np.array_equal(desc, rd)
     b.close()
+
+
+@pytest.mark.parametrize("scale,levels", [(2.5, 2), (3.0, 2), (2.2, 3)])
+def test_per_thread_pyramid_fallback(gpu, fe, orc, synth, scale, levels):
+    """Wide images at resize ratios above 2 exceed the LDS budget of the tile kernel and run k_pyr_level (one thread per
+    4 pixels); its 8-byte source window only holds ratios up to 2, wider groups must take the per-pixel path."""
+    w, h, nf = 1241, 376, 1000
+    img = synth.random_image(w, h, 92, "texture")
+    ex = fe.ORBextractor(nf, scale, levels, 20, 7)
+    b = fe.Batch(ex, w, h, 1)
+    b.extract_host(img[None])
+    o = orc.Extractor(nf, scale, levels, 20, 7)
+    rk, rd = o(img)
+    for l in range(levels):
+        assert np.array_equal(b.pyramid(0, l), o.pyramid(l)), "pyramid level %d" % l
+    kp, desc, per_level = b.download(0)
+    assert np.array_equal(per_level, o.per_level)
+    assert_kp_equal(kp, rk, "scale %.1f" % scale)
+    assert np.array_equal(desc, rd)
+    b.close()
