@@ -141,7 +141,7 @@ static inline bool sd_plan_build(SdPlan& P, const SdParams& prm, int W, int H)
         g.nCols = (int)(width / 30.f); g.nRows = (int)(height / 30.f);
         if (g.nCols < 1 || g.nRows < 1) { P.error = "level " + std::to_string(l) + " has no FAST cell"; return false; }
         g.wCell = (int)ceilf(width / g.nCols); g.hCell = (int)ceilf(height / g.nRows);
-        if (g.wCell + 6 > 64 || g.hCell + 6 > 64) { P.error = "FAST cell window larger than 64 px"; return false; }
+        if (g.wCell + 6 > 70 || g.hCell + 6 > 70) { P.error = "FAST cell window larger than 70 px"; return false; }   // cannot happen: wCell <= 59 (k_fast_cells holds 70)
         g.cell0 = cellTotal;
         g.candOffset = candOff;
         for (int i = 0; i < g.nRows; i++) {

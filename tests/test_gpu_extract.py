@@ -119,3 +119,44 @@ def test_per_thread_pyramid_fallback(gpu, fe, orc, synth, scale, levels):
     assert_kp_equal(kp, rk, "scale %.1f" % scale)
     assert np.array_equal(desc, rd)
     b.close()
+
+
+def test_blur_taps_variant_sum_257(gpu, fe, orc, synth):
+    """The plain-rounding 8.8 kernel (taps sum to 257, oracle spec Q on GaussianBlur) needs the clamping store of k_blur_wide:
+    saturated white areas would otherwise wrap.  Blurred planes, keypoints and descriptors against the oracle."""
+    w, h, nf = 640, 480, 800
+    img = synth.random_image(w, h, 93, "texture").copy()
+    img[100:220, 50:300] = 255                       # a saturated block: sum * 257 * 257 / 65536 > 255 before the clamp
+    taps = [18, 34, 49, 55, 49, 34, 18]
+    ex = fe.ORBextractor(nf, 1.2, 8, 20, 7); ex.set_blur_taps(taps)
+    o = orc.Extractor(nf, 1.2, 8, 20, 7); o.set_blur_taps(taps)
+    b = fe.Batch(ex, w, h, 1)
+    b.extract_host(img[None])
+    rk, rd = o(img)
+    for l in range(8):
+        assert np.array_equal(b.blurred(0, l), o.blurred(l)), "blurred level %d" % l
+    kp, desc, per_level = b.download(0)
+    assert_kp_equal(kp, rk, "taps 257")
+    assert np.array_equal(desc, rd)
+    b.close()
+
+
+@pytest.mark.parametrize("w,h,scale,levels", [(120, 100, 1.4, 2), (91, 91, 1.2, 1), (200, 150, 1.3, 3)])
+def test_small_images_generic_fast_kernel(gpu, fe, orc, synth, w, h, scale, levels):
+    """Small levels have one or two wide FAST cells (window > 52 px): the batch then runs the generic k_fast_cells instead of
+    the staged kernel, and levels under 40 px the per-thread pyramid kernel."""
+    img = synth.random_image(w, h, 94, "texture")
+    ex = fe.ORBextractor(300, scale, levels, 20, 7)
+    b = fe.Batch(ex, w, h, 2)
+    b.extract_host(np.stack([img, img[::-1].copy()]))
+    for i, im in enumerate([img, img[::-1].copy()]):
+        o = orc.Extractor(300, scale, levels, 20, 7)
+        rk, rd = o(im)
+        for l in range(levels):
+            assert np.array_equal(b.pyramid(i, l), o.pyramid(l)), "pyramid level %d" % l
+        assert np.array_equal(b.candidate_counts(i), o.cand_per_level)
+        kp, desc, per_level = b.download(i)
+        assert np.array_equal(per_level, o.per_level)
+        assert_kp_equal(kp, rk, "image %d" % i)
+        assert np.array_equal(desc, rd)
+    b.close()
