@@ -160,3 +160,12 @@ def test_small_images_generic_fast_kernel(gpu, fe, orc, synth, w, h, scale, leve
         assert_kp_equal(kp, rk, "image %d" % i)
         assert np.array_equal(desc, rd)
     b.close()
+
+
+def test_randomised_configurations(gpu):
+    """20 fixed draws of tools/fuzz_extract.py (image size, scale factor, level count, feature count, thresholds, texture kind):
+    keypoints and descriptors identical to the oracle.  (250 draws were run on an MI355X when this was written.)"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_extract", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_extract.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    assert m.run(20, 23) == 0
