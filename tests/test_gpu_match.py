@@ -190,3 +190,12 @@ def test_search_by_projection_crowded_windows(gpu, fe, orc, synth):
         assert np.array_equal(m[:len(cur["kp"])], om)
     finally:
         b.close()
+
+
+def test_randomised_frame_configurations(gpu):
+    """8 fixed draws of tools/fuzz_frame.py (image size, intrinsics, scale factor, levels, search radius, predicted pose):
+    stereo association, UnprojectStereo and SearchByProjection identical to the oracle.  (40 draws were run when written.)"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_frame", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_frame.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    assert m.run(8, 31) == 0
