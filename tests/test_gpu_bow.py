@@ -116,3 +116,13 @@ def test_search_by_bow(seq, fe, orc, synth, L, levelsup, nnratio, valid_frac, or
         total += onm
     assert total > 30 * npairs, "expected plenty of matches, got %d" % total
     V.close()
+
+
+def test_randomised_vocabularies(gpu):
+    """8 fixed draws of tools/fuzz_bow.py (branching factor 2..20, depth, early leaves, zero-weight words, scoring / weighting,
+    levelsup 0..L+1, SearchByBoW ratio / orientation / valid mask): identical to the oracle, f64 values bit for bit.
+    (40 draws were run when written.)"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_bow", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_bow.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    assert m.run(8, 5) == 0
