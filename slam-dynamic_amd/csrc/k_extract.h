@@ -893,60 +893,82 @@ __global__ void __launch_bounds__(256) k_blur(const uint8_t* __restrict__ pyr, u
 #define SD_DP_W 40    // staged bytes per patch row
 #define SD_DP_R 18    // patch radius
 typedef uint32_t __attribute__((aligned(1))) sd_u32_ua;
+#define SD_DP_KPW 2   // keypoints per wave: their loads are in flight together (the kernel is bound by memory round trips x occupancy)
 __global__ void __launch_bounds__(256) k_describe(const uint8_t* __restrict__ blur, const uint32_t* __restrict__ lvlKp,
                                                   const int* __restrict__ lvlCount, const float2* __restrict__ rot,
                                                   uint8_t* __restrict__ descOut, const SdDevPlan* __restrict__ PP, int nImages,
                                                   int groupsPerImage)
 {
     const SdDevPlan& P = *PP;
-    __shared__ __align__(16) uint8_t patch[4][37 * SD_DP_W];
+    __shared__ __align__(16) uint8_t patch[4][SD_DP_KPW][37 * SD_DP_W];
     int img, grp;
     if (!sd_xcd_image_item(blockIdx.x, groupsPerImage, nImages, img, grp)) return;
     const int wv = threadIdx.x >> 6;
-    const int slot = grp * 4 + wv;
+    const int slot0 = grp * (4 * SD_DP_KPW) + wv * SD_DP_KPW;      // the 8 slots of a workgroup share a level (slices start on multiples of 8)
     const int lane = threadIdx.x & 63;
-    if (slot >= P.kpCapLevels) return;
-    const int level = sd_slot_level(P, grp * 4);
+    if (slot0 >= P.kpCapLevels) return;
+    const int level = sd_slot_level(P, grp * (4 * SD_DP_KPW));
     const SdLevel& g = P.lv[level];
-    const int idx = slot - g.kpOffset;
+    const int idx0 = slot0 - g.kpOffset;
     int before, mine, tot;
     sd_level_counts(lvlCount + (size_t)img * P.nlevels, P.nlevels, level, before, mine, tot);
-    if (idx >= mine) return;
-    const uint32_t v = lvlKp[(size_t)img * P.kpCapLevels + slot];
-    const int px = (int)(v & 0xFFF) + g.minBX, py = (int)((v >> 12) & 0xFFF) + g.minBY;
-    const float2 ab = rot[(size_t)img * P.kpCapLevels + slot];
-    const float a = ab.x, b = ab.y;
+    if (idx0 >= mine) return;
+    const int nk = min(SD_DP_KPW, mine - idx0);                       // keypoints of this wave (wave-uniform)
     const int step = g.blurStride;
-    const uint8_t* corner = blur + (size_t)img * P.blurImageBytes + g.blurOffset + (size_t)(py - SD_DP_R) * step + (px - SD_DP_R);
-    uint32_t* pw = (uint32_t*)patch[wv];
-    uint32_t pqs[4];                                                       // requested before the patch: one round trip for both
+    uint32_t v[SD_DP_KPW];
+    float2 ab[SD_DP_KPW];
+#pragma unroll
+    for (int q = 0; q < SD_DP_KPW; q++) {
+        const size_t o = (size_t)img * P.kpCapLevels + slot0 + (q < nk ? q : 0);
+        v[q] = lvlKp[o]; ab[q] = rot[o];
+    }
+    uint32_t pqs[4];                                                       // requested before the patches: one round trip for both
 #pragma unroll
     for (int r = 0; r < 4; r++) pqs[r] = *(const uint32_t*)(c_pattern + 4 * (lane + 64 * r));       // one dword = (x0, y0, x1, y1) as int8
+    uint32_t pix[SD_DP_KPW][6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-        const int i = lane + 64 * k;
-        if (i < 370) {
+    for (int q = 0; q < SD_DP_KPW; q++) {
+        const int px = (int)(v[q] & 0xFFF) + g.minBX, py = (int)((v[q] >> 12) & 0xFFF) + g.minBY;
+        const uint8_t* corner = blur + (size_t)img * P.blurImageBytes + g.blurOffset + (size_t)(py - SD_DP_R) * step + (px - SD_DP_R);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int i = lane + 64 * k;
             const int r = i / 10, c = i - r * 10;
-            pw[i] = *(const sd_u32_ua*)(corner + (size_t)r * step + 4 * c);
+            pix[q][k] = 0;
+            if (i < 370) pix[q][k] = *(const sd_u32_ua*)(corner + (size_t)r * step + 4 * c);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < SD_DP_KPW; q++) {
+        uint32_t* pw = (uint32_t*)patch[wv][q];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int i = lane + 64 * k;
+            if (i < 370) pw[i] = pix[q][k];
         }
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave's LDS writes are done
-    const uint8_t* center = patch[wv] + SD_DP_R * SD_DP_W + SD_DP_R;
-    unsigned long long words[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const uint32_t pq = pqs[r];
-        const float x0 = (float)(signed char)(pq & 255u), y0 = (float)(signed char)((pq >> 8) & 255u);
-        const float x1 = (float)(signed char)((pq >> 16) & 255u), y1 = (float)(signed char)(pq >> 24);
-        const int iy0 = __float2int_rn(x0 * b + y0 * a), ix0 = __float2int_rn(x0 * a - y0 * b);
-        const int iy1 = __float2int_rn(x1 * b + y1 * a), ix1 = __float2int_rn(x1 * a - y1 * b);
-        const int t0 = center[iy0 * SD_DP_W + ix0];
-        const int t1 = center[iy1 * SD_DP_W + ix1];
-        words[r] = __ballot(t0 < t1);
-    }
-    if (lane < 4) {
-        unsigned long long w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
-        *(unsigned long long*)(descOut + ((size_t)img * P.kpCap + before + idx) * 32 + 8 * lane) = w;
+    for (int q = 0; q < SD_DP_KPW; q++) {
+        if (q >= nk) break;
+        const float a = ab[q].x, b = ab[q].y;
+        const uint8_t* center = patch[wv][q] + SD_DP_R * SD_DP_W + SD_DP_R;
+        unsigned long long words[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t pq = pqs[r];
+            const float x0 = (float)(signed char)(pq & 255u), y0 = (float)(signed char)((pq >> 8) & 255u);
+            const float x1 = (float)(signed char)((pq >> 16) & 255u), y1 = (float)(signed char)(pq >> 24);
+            const int iy0 = __float2int_rn(x0 * b + y0 * a), ix0 = __float2int_rn(x0 * a - y0 * b);
+            const int iy1 = __float2int_rn(x1 * b + y1 * a), ix1 = __float2int_rn(x1 * a - y1 * b);
+            const int t0 = center[iy0 * SD_DP_W + ix0];
+            const int t1 = center[iy1 * SD_DP_W + ix1];
+            words[r] = __ballot(t0 < t1);
+        }
+        if (lane < 4) {
+            unsigned long long w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
+            *(unsigned long long*)(descOut + ((size_t)img * P.kpCap + before + idx0 + q) * 32 + 8 * lane) = w;
+        }
     }
 }

@@ -579,7 +579,7 @@ static int extract_impl(sd_batch* b, const uint8_t* d_gray, size_t stride, size_
     LAUNCH_CHECK("k_orient");
     {
         ProfScope ps(b, s, K_DESC);
-        const int gpi = (P.kpCapLevels + 3) / 4, n8 = (n_images + 7) / 8 * 8;
+        const int gpi = (P.kpCapLevels + 4 * SD_DP_KPW - 1) / (4 * SD_DP_KPW), n8 = (n_images + 7) / 8 * 8;
         hipLaunchKernelGGL(k_describe, dim3((unsigned)gpi * n8), dim3(256), 0, s, b->d_blur, b->d_lvlKp, b->d_lvlCount, b->d_rot, b->d_desc, b->d_plan,
                            n_images, gpi);
     }
