@@ -466,6 +466,7 @@ __device__ __forceinline__ int sd_proj_point(const SdProjArgs& A, int pair, int 
     int minLevel = -1, maxLevel = -1;
     const float* T = A.Tcw + (size_t)pair * 16;
     const float* Tl = A.Tlw + (size_t)pair * 16;
+    const float scaleOfLane = lane < P.nlevels ? P.lv[lane].scale : 0.f;
     {
         const float X = A.xw[3 * oL], Y = A.xw[3 * oL + 1], Z = A.xw[3 * oL + 2];
         const int nLastOctave = A.kp[oL].octave;
@@ -485,7 +486,7 @@ __device__ __forceinline__ int sd_proj_point(const SdProjArgs& A, int pair, int 
         float lx, ly, lz;
         sd_mat3_mul_add(Tl, twx, twy, twz, lx, ly, lz);
         const bool bForward = lz > cam.mb && !A.bMono, bBackward = -lz > cam.mb && !A.bMono;
-        radius = A.th * P.lv[nLastOctave].scale;
+        radius = A.th * __shfl(scaleOfLane, nLastOctave, 64);         // lane l holds scale[l]: no load chained behind the octave
         if (bForward) { minLevel = nLastOctave; maxLevel = -1; }
         else if (bBackward) { minLevel = 0; maxLevel = nLastOctave; }
         else { minLevel = nLastOctave - 1; maxLevel = nLastOctave + 1; }
