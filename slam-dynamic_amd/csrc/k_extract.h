@@ -734,13 +734,19 @@ __global__ void __launch_bounds__(256, 4) k_quadtree(const uint32_t* __restrict_
     const uint32_t* myList = cellList + (size_t)img * P.cellListCap;
 
     // ---- compact the per-cell candidate lists in cell order (row-major cells, row-major pixels)
-    for (int i = tid; i < g.nCells; i += 256) S.tmp[i] = myCellCount[i];
+    // One thread per OUTPUT slot: its cell is found by bisection over the scanned counts in LDS, so all reads of the cell lists
+    // are independent and in flight together (a wave-per-cell loop chained ~120 dependent count -> list round trips per wave and
+    // was half of this kernel's time on level 0).
+    for (int i = tid; i < g.nCells; i += 256) { S.tmp[i] = myCellCount[i]; S.gidx[i] = cells[g.cell0 + i].listOffset; }
     __syncthreads();
     const int M = sd_block_excl_scan(S.tmp, g.nCells, S.wsum);
-    for (int ci = wv; ci < g.nCells; ci += 4) {
-        const int n = myCellCount[ci], off = S.tmp[ci];
-        const int lo = cells[g.cell0 + ci].listOffset;
-        for (int r = lane; r < n; r += 64) myCand[off + r] = myList[lo + r];
+    for (int j = tid; j < M; j += 256) {
+        int lo = 0, hi = g.nCells - 1;                    // largest cell whose first slot is <= j (empty cells share a slot with their successor)
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (S.tmp[mid] <= j) lo = mid; else hi = mid - 1;
+        }
+        myCand[j] = myList[S.gidx[lo] + (j - S.tmp[lo])];
     }
     __syncthreads();     // workgroup-scope: myCand is re-read below by other threads of this workgroup
     if (tid == 0) candCount[(size_t)img * P.nlevels + level] = M;
