@@ -647,9 +647,14 @@ __global__ void __launch_bounds__(64) k_proj_resolve(
     const SdDevPlan& P = *PP;
     extern __shared__ __align__(16) unsigned char smem[];
     const int cap = P.kpCap;
-    int* s_match = (int*)smem;                              // [cap]
-    uint8_t* s_taken = (uint8_t*)(s_match + cap);           // [cap]
-    uint8_t* s_bin = s_taken + ((cap + 15) & ~15);          // [cap]  rotation bin of pair p
+    const int capA = (cap + 15) & ~15;
+    int* s_match = (int*)smem;                              // [capA]
+    float* s_angL = (float*)(s_match + capA);               // [capA] angles of the Last-frame keypoints
+    float* s_angC = s_angL + capA;                          // [capA] angles of the Current-frame keypoints
+    unsigned short* s_c0 = (unsigned short*)(s_angC + capA);   // [capA] first candidate of every Last-frame point
+    uint8_t* s_taken = (uint8_t*)(s_c0 + capA);             // [capA]
+    uint8_t* s_bin = s_taken + capA;                        // [capA] rotation bin of pair p
+    uint8_t* s_n = s_bin + capA;                            // [capA] candidate count (<= 64) of every Last-frame point | 0x80 if it has observations
     __shared__ int s_hist[SD_HISTO];
     __shared__ int s_ind[3];
     const int pair = blockIdx.x, lane = threadIdx.x;
@@ -661,20 +666,43 @@ __global__ void __launch_bounds__(64) k_proj_resolve(
     const unsigned short* cd = cand + (size_t)pair * cap * SD_PROJ_K;
     const uint8_t* nc = ncand + (size_t)pair * cap;
     int* pairs = pairsOut + (size_t)pair * cap * 2;
-    for (int i = lane; i < Nc; i += 64) { s_match[i] = -1; s_taken[i] = occupied ? occupied[(size_t)pair * cap + i] : 0; }
+    // Everything the serial walk below reads per point is staged in LDS first, with independent requests (eight per lane in
+    // flight): the walk itself is one wave per pair, and a global round trip per 64-point chunk was most of its time.
+    for (int i0 = lane; i0 < max(Nc, Nl); i0 += 64 * 8) {
+        float aC[8], aL[8]; uint8_t tk[8], nn[8]; unsigned short c0[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = i0 + 64 * k;
+            const int ic = min(i, Nc - 1 < 0 ? 0 : Nc - 1), il = min(i, Nl - 1 < 0 ? 0 : Nl - 1);
+            aC[k] = kC[ic].angle; tk[k] = occupied ? occupied[(size_t)pair * cap + ic] : 0;
+            aL[k] = kL[il].angle; nn[k] = (uint8_t)(nc[il] | ((fl[il] & 2) ? 0x80 : 0)); c0[k] = cd[(size_t)il * SD_PROJ_K];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = i0 + 64 * k;
+            if (i < Nc) { s_match[i] = -1; s_taken[i] = tk[k]; s_angC[i] = aC[k]; }
+            if (i < Nl) { s_angL[i] = aL[k]; s_n[i] = nn[k]; s_c0[i] = c0[k]; }
+        }
+    }
     if (lane < SD_HISTO) s_hist[lane] = 0;
     __syncthreads();
     const float factor = 1.0f / SD_HISTO;
     int np = 0;
     for (int base = 0; base < Nl; base += 64) {
         const int i = base + lane;
-        const int n = i < Nl ? nc[i] : 0;
-        const bool obs = i < Nl && (fl[i] & 2) != 0;
-        // speculative pick against the state at chunk start
+        const int nf = i < Nl ? s_n[i] : 0;
+        const int n = nf & 0x7F;
+        const bool obs = (nf & 0x80) != 0;
+        // speculative pick against the state at chunk start (the first candidate comes from LDS, the rare later ones from HBM)
         int pick = -1;
-        for (int j = 0; j < n; j++) {
-            const int c = cd[(size_t)i * SD_PROJ_K + j];
-            if (!s_taken[c]) { pick = c; break; }
+        if (n > 0) {
+            const int c = s_c0[i];
+            if (!s_taken[c]) pick = c;
+            else
+                for (int j = 1; j < n; j++) {
+                    const int c2 = cd[(size_t)i * SD_PROJ_K + j];
+                    if (!s_taken[c2]) { pick = c2; break; }
+                }
         }
         // conflict: an earlier lane with observations wants the same keypoint
         bool conflict = false;
@@ -713,7 +741,7 @@ __global__ void __launch_bounds__(64) k_proj_resolve(
             pairs[2 * p] = i; pairs[2 * p + 1] = pick;
             int bin = 0;
             if (checkOrientation) {
-                float rot = kL[i].angle - kC[pick].angle;
+                float rot = s_angL[i] - s_angC[pick];
                 if (rot < 0.0f) rot += 360.0f;
                 bin = (int)roundf(rot * factor);
                 if (bin == SD_HISTO) bin = 0;

@@ -1025,7 +1025,10 @@ int sd_batch_search_by_projection(sd_batch* b, int n_pairs, const int32_t* cur_i
     LAUNCH_CHECK("k_proj_candidates");
     {
         ProfScope ps(b, s, K_PROJ_B);
-        size_t lds = (size_t)cap * 4 + ((cap + 15) & ~15) + cap + 16;
+        const size_t capA = (size_t)((cap + 15) & ~15);
+        size_t lds = capA * (4 + 4 + 4 + 2 + 1 + 1 + 1) + 16;
+        if (lds > 160 * 1024 - 256) return set_err(SD_ERR_UNSUPPORTED, "too many keypoints per image for the projection matcher's LDS tables");
+        if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_proj_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_proj_resolve, dim3(n_pairs), dim3(64), lds, s, b->d_kp, b->d_count, b->d_flags, b->d_pcand, b->d_pncand,
                            d_occupied, b->d_match, b->d_pairs, b->d_npairs, b->d_nmatch, b->d_plan, checkOrientation, b->d_pairIdx);
     }
