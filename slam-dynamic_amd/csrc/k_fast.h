@@ -266,17 +266,18 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
 template <bool CLAMP>
 __global__ void __launch_bounds__(256) k_blur_wide(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
-                                                   const SdDevPlan* __restrict__ PP)
+                                                   const SdDevPlan* __restrict__ PP, const int* __restrict__ tiles, int nTiles, int nImages)
 {
     const SdDevPlan& P = *PP;
     __shared__ uint2 hbuf[SD_BLUR_TR + 6][32];
-    // (The XCD-aware image order of sd_xcd_image_item was measured here too: FETCH_SIZE 514 -> 203 MiB per 256 images, but
-    // the kernel went from 0.47 to 0.56 ms; the dispatch order is kept.)
-    const int zi = blockIdx.z;
-    const int img = zi / P.nlevels, level = zi - img * P.nlevels;
+    // XCD-aware order over an exact tile list (level | tx << 8 | ty << 16 per tile of one image): all tiles of an image meet
+    // in one L2, so the 6 halo rows and the 128-byte lines that neighbouring tiles share are fetched from HBM once.
+    int img, item;
+    if (!sd_xcd_image_item(blockIdx.x, nTiles, nImages, img, item)) return;
+    const int td = tiles[item];
+    const int level = td & 255;
     const SdLevel& g = P.lv[level];
-    const int x0 = blockIdx.x * 128, y0 = blockIdx.y * SD_BLUR_TR;
-    if (x0 >= g.W || y0 >= g.H) return;
+    const int x0 = ((td >> 8) & 255) * 128, y0 = (td >> 16) * SD_BLUR_TR;
     const int tid = threadIdx.x;
     const uint32_t tapsLo = (uint32_t)P.taps[0] | ((uint32_t)P.taps[1] << 8) | ((uint32_t)P.taps[2] << 16) | ((uint32_t)P.taps[3] << 24);
     const uint32_t tapsHi = (uint32_t)P.taps[4] | ((uint32_t)P.taps[5] << 8) | ((uint32_t)P.taps[6] << 16);

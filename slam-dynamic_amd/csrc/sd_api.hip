@@ -43,6 +43,7 @@ struct SdPyrTiles { int tilesX = 0, tilesY = 0, srcRowBytes = 0, srcRowsMax = 0,
 struct sd_batch {
     std::vector<SdPyrTiles> pyrTiles;      // per level: tile grid of k_pyr_level_tiles
     int* d_pyrExt = nullptr;
+    int* d_blurTiles = nullptr; int nBlurTiles = 0;      // k_blur_wide: tile list of one image
     sd_extractor* ex = nullptr;
     SdPlan plan;
     SdDevPlan hplan;
@@ -215,7 +216,7 @@ int sd_extractor_level_size(const sd_extractor* ex, int width, int height, int l
 static void batch_free(sd_batch* b)
 {
     if (!b) return;
-    void* ptrs[] = {b->d_plan, b->d_cells, b->d_fcells, b->d_tabs, b->d_pyr, b->d_blur, b->d_cellList, b->d_cellCount, b->d_cand,
+    void* ptrs[] = {b->d_plan, b->d_cells, b->d_fcells, b->d_blurTiles, b->d_tabs, b->d_pyr, b->d_blur, b->d_cellList, b->d_cellCount, b->d_cand,
                     b->d_nodeOf, b->d_lvlCount, b->d_candCount, b->d_lvlKp, b->d_rot, b->d_kp, b->d_desc, b->d_count,
                     b->d_err, b->d_uright, b->d_depth, b->d_sad, b->d_stage, b->d_cellOf, b->d_xw, b->d_flags,
                     b->d_pcand, b->d_pncand, b->d_match, b->d_pairs, b->d_npairs, b->d_nmatch, b->d_pose, b->d_pairIdx, b->d_sortedIdx, b->d_cellStart,
@@ -537,11 +538,20 @@ static int extract_impl(sd_batch* b, const uint8_t* d_gray, size_t stride, size_
         // FAST so that it runs beside the quadtree both kernels stretch (0.45 + 0.35 ms -> 0.73 ms together): +0.8 % frames/s,
         // not worth a second stream and overlapped per-kernel timings — everything stays on one stream.)
         ProfScope ps(b, s, K_BLUR);
-        dim3 grd((P.lv[0].W + 127) / 128, (P.lv[0].H + SD_BLUR_TR - 1) / SD_BLUR_TR, n_images * nl);
+        if (!b->d_blurTiles) {                                // once per batch: the non-empty 128 x SD_BLUR_TR tiles of one image, level by level
+            std::vector<int> t;
+            for (int l = 0; l < nl; l++)
+                for (int ty = 0; ty * SD_BLUR_TR < P.lv[l].H; ty++)
+                    for (int tx = 0; tx * 128 < P.lv[l].W; tx++) t.push_back(l | (tx << 8) | (ty << 16));
+            b->nBlurTiles = (int)t.size();
+            HIPCHK(hipMalloc((void**)&b->d_blurTiles, t.size() * 4));
+            HIPCHK(hipMemcpy(b->d_blurTiles, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+        }
+        dim3 grd((unsigned)b->nBlurTiles * (unsigned)((n_images + 7) / 8 * 8));
         unsigned tapSum = 0;
         for (int i = 0; i < 7; i++) tapSum += b->hplan.taps[i];
-        if (tapSum <= 256) hipLaunchKernelGGL(k_blur_wide<false>, grd, dim3(256), 0, s, b->d_pyr, b->d_blur, b->d_plan);
-        else hipLaunchKernelGGL(k_blur_wide<true>, grd, dim3(256), 0, s, b->d_pyr, b->d_blur, b->d_plan);
+        if (tapSum <= 256) hipLaunchKernelGGL(k_blur_wide<false>, grd, dim3(256), 0, s, b->d_pyr, b->d_blur, b->d_plan, b->d_blurTiles, b->nBlurTiles, n_images);
+        else hipLaunchKernelGGL(k_blur_wide<true>, grd, dim3(256), 0, s, b->d_pyr, b->d_blur, b->d_plan, b->d_blurTiles, b->nBlurTiles, n_images);
     }
     LAUNCH_CHECK("k_blur");
     {
