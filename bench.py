@@ -137,7 +137,12 @@ def cpu_baseline(workload, cfg, n_frames, seq):
     th = 15.0 if workload == "rgbd" else 7.0
     exL = orc.Extractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
     exR = orc.Extractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+    return _cpu_walk(orc, workload, cfg, frames, exL, exR, cam10, I, th)
+
+
+def _cpu_walk(orc, workload, cfg, frames, exL, exR, cam10, I, th):
     last = None
+    n_frames = len(frames)
     t0 = time.perf_counter()
     for fr in frames:
         if workload == "rgbd":
@@ -159,6 +164,30 @@ def cpu_baseline(workload, cfg, n_frames, seq):
         last = (kp, desc, xw, valid)
     dt = time.perf_counter() - t0
     return n_frames / dt, dt
+
+
+def cpu_baseline_all_cores(workload, cfg, seq, threads, frames_per_thread=48):
+    """The same walk on `threads` host threads at once, one independent frame stream per thread ("an all-cores run,
+    one frame per core"); the oracle's C calls release the GIL.  Reported beside the single-stream figure, never instead of it."""
+    import threading
+    orc = graft.load_oracle()
+    pkg = graft.load_package()
+    synth, fe = pkg.synth, pkg.frontend
+    cam10 = fe.camera_array(fe.make_camera(cfg))
+    I = np.eye(4, dtype=np.float32)
+    pool = [synth.rgbd_frame(seq, t, cfg) if workload == "rgbd" else synth.stereo_frame(seq, t, cfg) for t in range(16)]
+    th = 15.0 if workload == "rgbd" else 7.0
+    mk = lambda: orc.Extractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+    ex = [(mk(), mk()) for _ in range(threads)]
+    def work(k):
+        frames = [pool[(k + t) % len(pool)] for t in range(frames_per_thread)]
+        _cpu_walk(orc, workload, cfg, frames, ex[k][0], ex[k][1], cam10, I, th)
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+    t0 = time.perf_counter()
+    for t in ts: t.start()
+    for t in ts: t.join()
+    dt = time.perf_counter() - t0
+    return threads * frames_per_thread / dt, dt
 
 
 # --------------------------------------------------------------------------- main
@@ -480,6 +509,10 @@ def main():
             cpu = {"value": round(v, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                    "sample": "%d frames (64 distinct, cycled) of the same synthetic workload through the CPU oracle (oracle/), "
                              "1 thread, %.1f s; host has %d logical cores" % (args.cpu_frames, dt, os.cpu_count() or 0)}
+            nthr = max(1, min(32, (os.cpu_count() or 1) // 2))
+            va, dta = cpu_baseline_all_cores(args.workload if args.workload in ("rgbd", "stereo") else "rgbd", cfg, seq, nthr)
+            cpu["all_cores"] = {"value": round(va, 2), "unit": "frames/s", "threads": nthr,
+                                "sample": "%d independent streams x 48 frames, %.1f s" % (nthr, dta)}
         out = {
             "metric": "tracking frames/sec (extract+match+dynamic-cull), KITTI 1241x376",
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
