@@ -2086,7 +2086,7 @@ int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int heig
             const int npix = n * r.H * r.W;
             dim3 grd((npix + SD_CV_BN - 1) / SD_CV_BN, (l.filters + SD_CV_BM - 1) / SD_CV_BM);
             const bool flat3 = l.size == 3 && l.stride == 1 && W <= 160 && l.filters % SD_G3_BM == 0 && r.cinPad % 32 == 0 && npix >= SD_G3_BN;
-            if (!flat3 && r.cinPad % 32 == 0 && npix >= 512 && (l.size == 1 || l.filters >= SD_G3_BM)) {
+            if (!flat3 && r.cinPad % 32 == 0 && npix >= 512 && (l.size == 1 || l.filters >= SD_G3_BM / 2)) {
                 static bool attr = false;
                 const int lds8 = 3 * (512 * 64 + SD_G3_WBYTES), lds4 = 3 * (256 * 64 + SD_G3_WBYTES);
                 if (!attr) {
