@@ -57,10 +57,12 @@ __global__ void __launch_bounds__(256) k_row_sort(const sd_keypoint* __restrict_
     for (int y = tid; y <= H; y += 256) rowStart[(size_t)f * (H + 8) + y] = start[y];
 }
 
-// One wave per left keypoint.  Row-band membership (the reference's vRowIndices table, Frame.cc:884-900)
-// is evaluated directly per (left, right) pair: right keypoint iR is a candidate of row yi iff
-// floor(kpY - r) <= yi <= ceil(kpY + r), r = 2*scale[octave]; candidates are visited in increasing iR
-// there, so "first best wins" == lexicographic min of (distance, iR) here.
+// Half a wave (32 lanes) per left keypoint, eight keypoints per workgroup.  Row-band membership (the reference's vRowIndices
+// table, Frame.cc:884-900) is evaluated directly per (left, right) pair: right keypoint iR is a candidate of row yi iff
+// floor(kpY - r) <= yi <= ceil(kpY + r), r = 2*scale[octave]; candidates are visited in increasing iR there, so "first best
+// wins" == lexicographic min of (distance, iR) here.  The kernel is bound by memory round trips per keypoint, not by lanes: two
+// keypoints per wave keep twice as many requests in flight; all cross-lane steps stay inside a half (xor < 32), loop bounds
+// are made wave-uniform with __any().
 __global__ void __launch_bounds__(256) k_stereo_match(const sd_keypoint* __restrict__ kp,
                                                       const uint8_t* __restrict__ desc, const int* __restrict__ count,
                                                       const uint8_t* __restrict__ pyr, float* __restrict__ uRight,
@@ -70,16 +72,18 @@ __global__ void __launch_bounds__(256) k_stereo_match(const sd_keypoint* __restr
                                                       const SdDevPlan* __restrict__ PP, float mbf, float fx)
 {
     const SdDevPlan& P = *PP;
-    __shared__ __align__(16) uint8_t s_win[4][11 * 12 + 11 * 24 + 4];       // per wave: left window + right strip
+    __shared__ __align__(16) uint8_t s_win[8][11 * 12 + 11 * 24 + 4];       // per keypoint: left window + right strip
     const int f = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, hl = lane & 31, grp = threadIdx.x >> 5;
     const int imgL = 2 * f, imgR = 2 * f + 1;
-    const int N = count[imgL], Nr = count[imgR];
-    if (iL >= N) return;
-    const size_t o = (size_t)imgL * P.kpCap + iL;   // outputs are indexed by the LEFT image
-    const sd_keypoint kL = kp[(size_t)imgL * P.kpCap + iL];
-    const uint4* dl = (const uint4*)(desc + ((size_t)imgL * P.kpCap + iL) * 32);
+    const int N = count[imgL];
+    const int iLraw = blockIdx.x * 8 + grp;
+    if (blockIdx.x * 8 >= N) return;                      // whole workgroup past the last keypoint
+    const bool live = iLraw < N;
+    const int iL = live ? iLraw : 0;
+    const size_t o = (size_t)imgL * P.kpCap + iL;         // outputs are indexed by the LEFT image
+    const sd_keypoint kL = kp[o];
+    const uint4* dl = (const uint4*)(desc + o * 32);
     const uint4 l0 = dl[0], l1 = dl[1];
     const float mb = mbf / fx;
     const float minZ = mb, minD = 0.f;
@@ -91,16 +95,18 @@ __global__ void __launch_bounds__(256) k_stereo_match(const sd_keypoint* __restr
     unsigned bestKey = ((unsigned)SD_TH_HIGH << 16) | 0xFFFFu;
     const sd_keypoint* kR = kp + (size_t)imgR * P.kpCap;
     const uint8_t* dR = desc + (size_t)imgR * P.kpCap * 32;
-    // lane l holds scale[l]: the band radius of a right keypoint comes from a cross-lane read, not from a load chained behind its octave
-    const float scaleOfLane = lane < P.nlevels ? P.lv[lane].scale : 0.f;
-    if (!(maxU < 0)) {
+    // lane l of each half holds scale[l]: the band radius of a right keypoint comes from a cross-lane read, not from a load
+    // chained behind its octave
+    const float scaleOfLane = hl < P.nlevels ? P.lv[hl].scale : 0.f;
+    {
         // only right keypoints whose integer row lies within bandR (>= 2*scale_max + 1) rows can contain yi
         const int H0 = P.lv[0].H;
         const int* rs = rowStart + (size_t)f * (H0 + 8);
         const unsigned short* ridx = rowIdx + (size_t)f * P.kpCap;
-        const int p0 = rs[max(yi - bandR, 0)], p1 = rs[min(yi + bandR, H0 - 1) + 1];
-        for (int pb = p0; pb < p1; pb += 64) {
-            const int p = pb + lane;
+        const bool scan = live && !(maxU < 0);
+        const int p0 = rs[min(max(yi - bandR, 0), H0 - 1)], p1 = scan ? rs[min(max(yi + bandR, 0), H0 - 1) + 1] : p0;
+        for (int pb = 0; __any(p0 + pb < p1); pb += 32) {
+            const int p = p0 + pb + hl;
             const bool in = p < p1;
             // position, octave and descriptor of the candidate are requested together (one round trip after its index)
             const int iR = in ? ridx[p] : 0;
@@ -109,7 +115,7 @@ __global__ void __launch_bounds__(256) k_stereo_match(const sd_keypoint* __restr
             const int koct = kq->octave;
             const uint4* dr = (const uint4*)(dR + (size_t)iR * 32);
             const uint4 d0 = dr[0], d1 = dr[1];
-            const float r = 2.0f * __shfl(scaleOfLane, koct, 64);
+            const float r = 2.0f * __shfl(scaleOfLane, (lane & 32) + koct, 64);
             const int maxr = (int)ceilf(ky + r), minr = (int)floorf(ky - r);
             const bool cand = in && !(yi < minr || yi > maxr) && !(koct < levelL - 1 || koct > levelL + 1) && kx >= minU && kx <= maxU;
             const unsigned dist = (unsigned)sd_hamming256(l0, l1, d0, d1);
@@ -118,12 +124,12 @@ __global__ void __launch_bounds__(256) k_stereo_match(const sd_keypoint* __restr
         }
     }
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1) bestKey = min(bestKey, (unsigned)__shfl_xor((int)bestKey, s, 64));
+    for (int s = 16; s > 0; s >>= 1) bestKey = min(bestKey, (unsigned)__shfl_xor((int)bestKey, s, 64));
     const int bestDist = (int)(bestKey >> 16);
     const int thOrbDist = (SD_TH_HIGH + SD_TH_LOW) / 2;
     float outU = -1.f, outD = -1.f;
     int outS = -1;
-    if (bestDist < thOrbDist) {
+    if (live && bestDist < thOrbDist) {                   // uniform inside a half
         const int bestIdxR = (int)(bestKey & 0xFFFFu);
         const float uR0 = kR[bestIdxR].x;
         const SdLevel& g = P.lv[levelL];
@@ -137,21 +143,23 @@ __global__ void __launch_bounds__(256) k_stereo_match(const sd_keypoint* __restr
             const int rowT = (int)(scaledvL - w);
             const uint8_t* IL = baseL + (ptrdiff_t)rowT * g.stride + (int)(scaleduL - w);
             const uint8_t* IR = baseR + (ptrdiff_t)rowT * g.stride + (int)(scaleduR0 - w);   // incR = 0 window
-            // The 11x11 left window and the 11x21 strip the right window slides over are staged in this wave's LDS with
-            // 99 unaligned dword requests (two per lane, one round trip); the 1331 absolute differences then read LDS bytes
-            // (the previous form issued 46 global byte-load instructions per keypoint and was bound by them).
-            uint8_t* sIL = s_win[threadIdx.x >> 6];              // [11][12]
+            // The 11x11 left window and the 11x21 strip the right window slides over are staged in this keypoint's LDS with
+            // 99 unaligned dword requests (four per lane, one round trip); the 1331 absolute differences then read LDS bytes.
+            uint8_t* sIL = s_win[grp];                           // [11][12]
             uint8_t* sIR = sIL + 11 * 12;                        // [11][24]: columns -5 .. +18 of the incR = 0 window
+            uint32_t ld[4];
 #pragma unroll
-            for (int it = 0; it < 2; it++) {
-                const int id = lane + 64 * it;
-                if (id < 33) {
-                    const int yy = id / 3, q = id - yy * 3;
-                    *(uint32_t*)(sIL + yy * 12 + 4 * q) = *(const sd_u32_una*)(IL + yy * g.stride + 4 * q);
-                } else if (id < 99) {
-                    const int j = id - 33, yy = j / 6, q = j - yy * 6;
-                    *(uint32_t*)(sIR + yy * 24 + 4 * q) = *(const sd_u32_una*)(IR + yy * g.stride - L + 4 * q);
-                }
+            for (int it = 0; it < 4; it++) {
+                const int id = hl + 32 * it;
+                ld[it] = 0;
+                if (id < 33) { const int yy = id / 3, q = id - yy * 3; ld[it] = *(const sd_u32_una*)(IL + yy * g.stride + 4 * q); }
+                else if (id < 99) { const int j = id - 33, yy = j / 6, q = j - yy * 6; ld[it] = *(const sd_u32_una*)(IR + yy * g.stride - L + 4 * q); }
+            }
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const int id = hl + 32 * it;
+                if (id < 33) { const int yy = id / 3, q = id - yy * 3; *(uint32_t*)(sIL + yy * 12 + 4 * q) = ld[it]; }
+                else if (id < 99) { const int j = id - 33, yy = j / 6, q = j - yy * 6; *(uint32_t*)(sIR + yy * 24 + 4 * q) = ld[it]; }
             }
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): this wave's LDS writes are done
@@ -162,22 +170,26 @@ __global__ void __launch_bounds__(256) k_stereo_match(const sd_keypoint* __restr
             int sums[11];
 #pragma unroll
             for (int k = 0; k < 11; k++) sums[k] = 0;
-            for (int p = lane; p < 121; p += 64) {
-                const int yy = p / 11, xx = p - yy * 11;
-                const int a = (int)sIL[yy * 12 + xx] - cL;
-                const uint8_t* rowR = sIR + yy * 24 + xx;
 #pragma unroll
-                for (int k = 0; k < 11; k++) {
-                    const int b = (int)rowR[k] - cR[k];
-                    const int d = a - b;
-                    sums[k] += d < 0 ? -d : d;
+            for (int it = 0; it < 4; it++) {
+                const int p = hl + 32 * it;
+                if (p < 121) {
+                    const int yy = p / 11, xx = p - yy * 11;
+                    const int a = (int)sIL[yy * 12 + xx] - cL;
+                    const uint8_t* rowR = sIR + yy * 24 + xx;
+#pragma unroll
+                    for (int k = 0; k < 11; k++) {
+                        const int b = (int)rowR[k] - cR[k];
+                        const int d = a - b;
+                        sums[k] += d < 0 ? -d : d;
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int k = 0; k < 11; k++)
 #pragma unroll
-                for (int s = 32; s > 0; s >>= 1) sums[k] += __shfl_xor(sums[k], s, 64);
+                for (int s = 16; s > 0; s >>= 1) sums[k] += __shfl_xor(sums[k], s, 64);
             int bestS = 0x7FFFFFFF, bestinc = 0;
 #pragma unroll
             for (int k = 0; k < 11; k++)
@@ -204,7 +216,7 @@ __global__ void __launch_bounds__(256) k_stereo_match(const sd_keypoint* __restr
             }
         }
     }
-    if (lane == 0) { uRight[o] = outU; depthOut[o] = outD; sadOut[o] = outS; }
+    if (hl == 0 && live) { uRight[o] = outU; depthOut[o] = outD; sadOut[o] = outS; }
 }
 
 // Median-of-SAD outlier rejection (Frame.cc:1033-1047): median = element [size/2] of the sorted SAD

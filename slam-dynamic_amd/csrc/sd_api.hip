@@ -740,7 +740,7 @@ int sd_batch_stereo_match(sd_batch* b, int n_frames, float mbf, float fx, void* 
     LAUNCH_CHECK("k_row_sort");
     {
         ProfScope ps(b, s, K_STEREO);
-        dim3 grd((b->plan.kpCap + 3) / 4, n_frames);
+        dim3 grd((b->plan.kpCap + 7) / 8, n_frames);               // eight left keypoints per workgroup (half a wave each)
         hipLaunchKernelGGL(k_stereo_match, grd, dim3(256), 0, s, b->d_kp, b->d_desc, b->d_count, b->d_pyr, b->d_uright,
                            b->d_depth, b->d_sad, b->d_rowIdx, b->d_rowStart, bandR, b->d_plan, mbf, fx);
     }
