@@ -104,7 +104,11 @@ __global__ void __launch_bounds__(256) k_stereo_match(const sd_keypoint* __restr
         const int* rs = rowStart + (size_t)f * (H0 + 8);
         const unsigned short* ridx = rowIdx + (size_t)f * P.kpCap;
         const bool scan = live && !(maxU < 0);
-        const int p0 = rs[min(max(yi - bandR, 0), H0 - 1)], p1 = scan ? rs[min(max(yi + bandR, 0), H0 - 1) + 1] : p0;
+        // a candidate must sit on level levelL - 1 .. levelL + 1, so its band radius is at most 2 * scale[levelL + 1]: rows further
+        // than that (+1 for the floor / ceil of the band test) hold no candidate of THIS keypoint; bandR is the all-level bound
+        const float rmax = 2.0f * __shfl(scaleOfLane, (lane & 32) + min(levelL + 1, P.nlevels - 1), 64);
+        const int band = min(bandR, (int)ceilf(rmax) + 1);
+        const int p0 = rs[min(max(yi - band, 0), H0 - 1)], p1 = scan ? rs[min(max(yi + band, 0), H0 - 1) + 1] : p0;
         for (int pb = 0; __any(p0 + pb < p1); pb += 32) {
             const int p = p0 + pb + hl;
             const bool in = p < p1;
