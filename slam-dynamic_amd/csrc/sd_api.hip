@@ -2087,7 +2087,7 @@ int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int heig
             dim3 grd((npix + SD_CV_BN - 1) / SD_CV_BN, (l.filters + SD_CV_BM - 1) / SD_CV_BM);
             const bool flat3 = l.size == 3 && l.stride == 1 && W <= 160 && l.filters % SD_G3_BM == 0 && r.cinPad % 32 == 0 && npix >= SD_G3_BN;
             if (!flat3 && r.cinPad % 32 == 0 && npix >= 512 && (l.size == 1 || l.filters >= SD_G3_BM / 2)) {
-                static bool attr = false;
+                bool& attr = y->attrGlds;          // per detector (= per device): function attributes are per device
                 const int lds8 = 3 * (512 * 64 + SD_G3_WBYTES), lds4 = 3 * (256 * 64 + SD_G3_WBYTES);
                 if (!attr) {
                     HIPCHK(hipFuncSetAttribute((const void*)k_conv_glds<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds8));
@@ -2104,7 +2104,7 @@ int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int heig
                 else if (big) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_glds<8, 3>), g8, dim3(512), lds8, s, A);
                 else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_glds<4, 3>), g4, dim3(256), lds4, s, A);
             } else if (flat3) {
-                static bool attr = false;
+                bool& attr = y->attrFlat3;
                 if (!attr) {
                     HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_glds<80>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_G3_LDS(80)));
                     HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_glds<160>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_G3_LDS(160)));

@@ -25,6 +25,7 @@ struct sd_yolo {
     int tabW = 0, tabH = 0;
     size_t wTotal = 0, bTotal = 0;
     bool weightsLoaded = false;
+    bool attrGlds = false, attrFlat3 = false;      // dynamic-LDS limits of the convolution kernels raised on this device
     int lastN = 0;
     hipStream_t stream = nullptr;
     std::vector<void*> owned;
