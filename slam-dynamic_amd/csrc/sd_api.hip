@@ -1246,7 +1246,7 @@ int sd_batch_compute_bow(sd_batch* b, const sd_vocab* v, int n_images, const int
     if (v->h.nNodes <= 1) return set_err(SD_ERR_INVALID, "compute_bow: empty vocabulary");
     for (int i = 0; i < n_images; i++) if (!slot_ok(b, image_index[i])) return set_err(SD_ERR_STATE, "compute_bow: image slot holds no results");
     const int cap = b->plan.kpCap;
-    int sortN = 64;
+    int sortN = 256;                     // LDS capacity of k_bow_finalize's sort: its per-image sort size starts at 256 too
     while (sortN < cap) sortN <<= 1;
     if (sortN > 8192) return set_err(SD_ERR_UNSUPPORTED, "compute_bow: more than 8192 keypoints per image");
     int rc = bow_alloc(b);
