@@ -196,7 +196,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
     ap.add_argument("--workload", choices=["rgbd", "stereo", "rgbd-cull", "rgbd-bow", "stereo-yolo"], default="rgbd")
     ap.add_argument("--cpu-frames", type=int, default=320, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): kernel trace + the two PMC passes of the default bench.py command.
 #   bash tools/profile_bench.sh <tag>      -> gpurun_out/<tag>_kt, <tag>_pmc_fetch, <tag>_pmc_write
-# Then, back in the container:  python tools/summarize_prof.py <tag> gpurun_out/<tag>_kt gpurun_out/<tag>_pmc_fetch gpurun_out/<tag>_pmc_write 256
+# Then, back in the container:  python tools/summarize_prof.py <tag> gpurun_out/<tag>_kt gpurun_out/<tag>_pmc_fetch gpurun_out/<tag>_pmc_write 512
 set -e
 TAG=${1:-prof}
 REPO=$(pwd)
