@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "sd_plan.h"
+#include "sd_trig.h"
 #include "../../include/sd_frontend.h"
 
 #define SD_WAVE 64
@@ -810,9 +811,13 @@ __global__ void __launch_bounds__(256) k_orient(const uint8_t* __restrict__ pyr,
     if (idx >= mine) return;
     const uint32_t v = lvlKp[(size_t)img * P.kpCapLevels + slot];
     const int px = (int)(v & 0xFFF) + g.minBX, py = (int)((v >> 12) & 0xFFF) + g.minBY;
-    const uint8_t* center = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)(SD_EDGE + py) * g.stride +
-                            SD_XOFF + px;
+    // Buffer addressing: wave-uniform descriptor of this image's level plane + one 32-bit per-lane offset (patch row 0) + a SCALAR
+    // row offset per load, so the 31 row loads need no vector address arithmetic (per-lane 64-bit pointers cost a chained 64-bit
+    // VALU add per load, a quarter of this VALU-bound kernel's instructions).
+    const __amdgpu_buffer_rsrc_t plane = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + SD_XOFF), 0, 0x7FFFFFFF, 0x00020000);
     const int u = l32 - SD_HALF_PATCH;
+    const int off0 = __mul24(SD_EDGE + py - SD_HALF_PATCH, g.stride) + px + u;         // >= 0: py >= 16 - 3, EDGE = 19
     int m10 = 0, m01 = 0;
     if (l32 < 31) {
         // umax of ORBextractor.cc:452-470 depends only on HALF_PATCH_SIZE = 15 (checked against the plan on the
@@ -821,7 +826,7 @@ __global__ void __launch_bounds__(256) k_orient(const uint8_t* __restrict__ pyr,
         const int au = u < 0 ? -u : u;
         int vals[31];
 #pragma unroll
-        for (int r = 0; r < 31; r++) vals[r] = center[(ptrdiff_t)(r - SD_HALF_PATCH) * g.stride + u];
+        for (int r = 0; r < 31; r++) vals[r] = __builtin_amdgcn_raw_buffer_load_b8(plane, off0, r * g.stride, 0);
 #pragma unroll
         for (int r = 0; r < 31; r++) {
             const int vv = r - SD_HALF_PATCH;
@@ -844,7 +849,8 @@ __global__ void __launch_bounds__(256) k_orient(const uint8_t* __restrict__ pyr,
         const float factorPI = (float)(M_PI / 180.f);
         const float ang = angle * factorPI;
         // a,b := correctly rounded f32 of cos/sin of the f32 angle (oracle spec Q3)
-        rot[(size_t)img * P.kpCapLevels + slot] = make_float2((float)cos((double)ang), (float)sin((double)ang));
+        const sd_cs cs = sd_cos_sin_f32((double)ang);
+        rot[(size_t)img * P.kpCapLevels + slot] = make_float2(cs.c, cs.s);
     }
 }
 

@@ -133,3 +133,19 @@ def test_descriptor_distance(orc, fe):
         assert orc.descriptor_distance(a, b) == ref == fe.DescriptorDistance(a, b)
     z = np.zeros(32, np.uint8)
     assert orc.descriptor_distance(z, z) == 0 and orc.descriptor_distance(z, ~z) == 256
+
+
+def test_steering_cos_sin_equals_libm():
+    """The kernels' f64 cos / sin of the steering angle (slam-dynamic_amd/csrc/sd_trig.h: IEEE fma / multiply / rint only, so host ==
+    device) gives the f32 values of the C library's cos() / sin() that the oracle uses: every 61st f32 angle in degrees [0.001, 360]
+    here (2.5 M values); `cos_sin_check 1` checks all 154 M (no difference when written)."""
+    import os, shutil, subprocess, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "cos_sin_check")
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-I" + os.path.join(root, "slam-dynamic_amd", "csrc"), "-o", exe,
+                               os.path.join(root, "tests", "cpp", "cos_sin_check.cpp")])
+        out = subprocess.run([exe, "61"], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout
