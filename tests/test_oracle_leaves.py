@@ -2,6 +2,7 @@
 import math
 
 import numpy as np
+import pytest
 
 RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0),
         (-3, 1), (-2, 2), (-1, 3)]
