@@ -281,25 +281,35 @@ __global__ void __launch_bounds__(256) k_pyr_level_tiles(uint8_t* __restrict__ p
         const int d1 = c[1].x - c[0].x, d2 = c[2].x - c[0].x, d3 = c[3].x - c[0].x;
         const bool window = d1 >= 0 && d2 >= d1 && d3 >= d2 && d3 <= 6;          // per lane; false only on the reflected frame
         const int sh = o0 & 3;
+        // window path: the 8 source bytes of the group sit in two dwords (lo, hi); pixel k needs bytes d_k and d_k + 1 of them.
+        // One v_perm spreads the pair into two u16 lanes, one v_dot2_u32_u16 applies (a0, a1): two instructions per pixel
+        // (the byte-shift form needed 64-bit shifts and masks, ~4x as many; the kernel is VALU-bound).
+        typedef unsigned short sd_us2 __attribute__((ext_vector_type(2)));
+        uint32_t sel[4], wk[4];
+        const int dk[4] = {0, d1, d2, d3};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            sel[k] = (uint32_t)dk[k] | 0x0C00u | ((uint32_t)(dk[k] + 1) << 16) | 0x0C000000u;
+            wk[k] = ((uint32_t)c[k].y & 0xFFFFu) | ((uint32_t)c[k].z << 16);
+        }
         for (int r = tid / NG; r < nrows; r += STEP) {
             const uint8_t* row = sS + r * srcRowBytes;
-            int h[4];
+            uint32_t h[4];
             if (window) {
                 const uint32_t* p = (const uint32_t*)(row + (o0 & ~3));
                 const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
-                const unsigned long long a = ((unsigned long long)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32) | __builtin_amdgcn_alignbyte(w1, w0, sh);
-                h[0] = __mul24((int)(a & 255), c[0].y) + __mul24((int)((a >> 8) & 255), c[0].z);
-                h[1] = __mul24((int)((a >> (8 * d1)) & 255), c[1].y) + __mul24((int)((a >> (8 * d1 + 8)) & 255), c[1].z);
-                h[2] = __mul24((int)((a >> (8 * d2)) & 255), c[2].y) + __mul24((int)((a >> (8 * d2 + 8)) & 255), c[2].z);
-                h[3] = __mul24((int)((a >> (8 * d3)) & 255), c[3].y) + __mul24((int)((a >> (8 * d3 + 8)) & 255), c[3].z);
+                const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh), hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    h[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(sd_us2, __builtin_amdgcn_perm(hi, lo, sel[k])), __builtin_bit_cast(sd_us2, wk[k]), 0u, false);
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int o = c[k].x - sxA;           // the byte after the last source column has weight a1 == 0
-                    h[k] = __mul24((int)row[o], c[k].y) + __mul24((int)row[o + 1], c[k].z);
+                    h[k] = (uint32_t)(__mul24((int)row[o], c[k].y) + __mul24((int)row[o + 1], c[k].z));
                 }
             }
-            *(uint2*)(sH + r * TW + 4 * gq) = make_uint2((uint32_t)(h[0] >> 4) | ((uint32_t)(h[1] >> 4) << 16), (uint32_t)(h[2] >> 4) | ((uint32_t)(h[3] >> 4) << 16));
+            *(uint2*)(sH + r * TW + 4 * gq) = make_uint2((h[0] >> 4) | ((h[1] >> 4) << 16), (h[2] >> 4) | ((h[3] >> 4) << 16));
         }
     }
     __syncthreads();
