@@ -320,26 +320,38 @@ __global__ void __launch_bounds__(256) k_blur_wide(const uint8_t* __restrict__ p
     const int gq = tid & 31, r0 = (tid >> 5) * RPT;
     const int x = x0 + 4 * gq;
     if (x >= g.W) return;
-    uint32_t t[7];
+    // taps as u16 pairs for v_dot2_u32_u16: (t0,t1) (t2,t3) (t4,t5) and (0,t6); each accumulation step handles two rows of one
+    // pixel, so an output pixel costs 4 instructions instead of 7 multiply-adds (+ one v_perm per pixel to pair the incoming row
+    // with its predecessor) — the kernel is bound by vector instruction issue
+    typedef unsigned short sd_us2 __attribute__((ext_vector_type(2)));
+    const sd_us2 t01 = __builtin_bit_cast(sd_us2, (uint32_t)P.taps[0] | ((uint32_t)P.taps[1] << 16));
+    const sd_us2 t23 = __builtin_bit_cast(sd_us2, (uint32_t)P.taps[2] | ((uint32_t)P.taps[3] << 16));
+    const sd_us2 t45 = __builtin_bit_cast(sd_us2, (uint32_t)P.taps[4] | ((uint32_t)P.taps[5] << 16));
+    const sd_us2 t_6 = __builtin_bit_cast(sd_us2, (uint32_t)P.taps[6] << 16);
+    // pr[a % 6][j] = (h[row a][column j], h[row a + 1][column j]) as a u16 pair; rows are relative to r0
+    uint32_t pr[6][4];
+    uint2 prev = hbuf[r0][gq];
 #pragma unroll
-    for (int k = 0; k < 7; k++) t[k] = (uint32_t)P.taps[k];      // < 2^8, sums < 2^16: full-rate 24-bit multiplies (v_mul_lo_u32 is quarter rate)
-    uint32_t win[7][4];
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        const uint2 v = hbuf[r0 + k][gq];
-        win[k][0] = v.x & 0xFFFFu; win[k][1] = v.x >> 16; win[k][2] = v.y & 0xFFFFu; win[k][3] = v.y >> 16;
+    for (int a = 0; a < 5; a++) {
+        const uint2 cur = hbuf[r0 + a + 1][gq];
+        pr[a][0] = __builtin_amdgcn_perm(cur.x, prev.x, 0x05040100u); pr[a][1] = __builtin_amdgcn_perm(cur.x, prev.x, 0x07060302u);
+        pr[a][2] = __builtin_amdgcn_perm(cur.y, prev.y, 0x05040100u); pr[a][3] = __builtin_amdgcn_perm(cur.y, prev.y, 0x07060302u);
+        prev = cur;
     }
 #pragma unroll
     for (int r = 0; r < RPT; r++) {
-        const uint2 v = hbuf[r0 + r + 6][gq];
-        uint32_t* nw = win[(r + 6) % 7];
-        nw[0] = v.x & 0xFFFFu; nw[1] = v.x >> 16; nw[2] = v.y & 0xFFFFu; nw[3] = v.y >> 16;
-        uint32_t sum[4] = {0x8000u, 0x8000u, 0x8000u, 0x8000u};
+        const uint2 cur = hbuf[r0 + r + 6][gq];
+        uint32_t* np = pr[(r + 5) % 6];
+        np[0] = __builtin_amdgcn_perm(cur.x, prev.x, 0x05040100u); np[1] = __builtin_amdgcn_perm(cur.x, prev.x, 0x07060302u);
+        np[2] = __builtin_amdgcn_perm(cur.y, prev.y, 0x05040100u); np[3] = __builtin_amdgcn_perm(cur.y, prev.y, 0x07060302u);
+        prev = cur;
+        uint32_t sum[4];
 #pragma unroll
-        for (int k = 0; k < 7; k++) {
-            const uint32_t* w = win[(r + k) % 7];
-#pragma unroll
-            for (int j = 0; j < 4; j++) sum[j] += __umul24(t[k], w[j]);
+        for (int j = 0; j < 4; j++) {
+            uint32_t acc = __builtin_amdgcn_udot2(__builtin_bit_cast(sd_us2, pr[r % 6][j]), t01, 0x8000u, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(sd_us2, pr[(r + 2) % 6][j]), t23, acc, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(sd_us2, pr[(r + 4) % 6][j]), t45, acc, false);
+            sum[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(sd_us2, pr[(r + 5) % 6][j]), t_6, acc, false);
         }
         const int y = y0 + r0 + r;
         if (y < g.H) {
