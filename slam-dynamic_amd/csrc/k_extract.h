@@ -87,40 +87,8 @@ typedef unsigned long long __attribute__((aligned(1))) sd_u64_una;
 typedef uint32_t sd_u4v __attribute__((ext_vector_type(4)));
 typedef sd_u4v sd_u128_unaligned __attribute__((aligned(1)));       // the hardware takes unaligned dwordx4 accesses
 
-// ------------------------------------------------------------------ pyramid, level 0
-// Padded copy of the gray input with BORDER_REFLECT_101 (ORBextractor.cc:1127-1128).
-// Thread = 16 consecutive bytes of a padded row (one ALIGNED 16-byte store: the interior starts SD_XOFF = 32 bytes into the
-// row); block 64x4.  Groups inside the interior are one 16-byte load (aligned too when the caller's gray rows are 16-byte
-// multiples); only the groups on the 19-px frame take the per-byte reflect path.
-__global__ void __launch_bounds__(256) k_pyr_level0(const uint8_t* __restrict__ gray, size_t gstride, size_t gpitch,
-                                                    uint8_t* __restrict__ pyr, const SdDevPlan* __restrict__ PP)
-{
-    const SdDevPlan& P = *PP;
-    const SdLevel& g = P.lv[0];
-    const int img = blockIdx.z;
-    const int gx = blockIdx.x * 64 + threadIdx.x;
-    const int Yp = blockIdx.y * 4 + threadIdx.y;          // padded row 0 .. H+37
-    if (Yp >= g.H + 2 * SD_EDGE) return;
-    const int X0 = -SD_XOFF + 16 * gx;                     // first interior-relative column of this 16-byte group
-    if (X0 > g.W + SD_EDGE - 1) return;
-    const int sy = sd_reflect101(Yp - SD_EDGE, g.H);
-    const uint8_t* srow = gray + (size_t)img * gpitch + (size_t)sy * gstride;
-    sd_u4v pack;
-    if (X0 >= 0 && X0 + 15 < g.W) {
-        pack = *(const sd_u128_unaligned*)(srow + X0);
-    } else {
-        uint32_t w[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            int X = X0 + k;
-            X = X < -SD_EDGE ? -SD_EDGE : (X > g.W + SD_EDGE - 1 ? g.W + SD_EDGE - 1 : X);     // margin bytes: any value
-            w[k >> 2] |= (uint32_t)srow[sd_reflect101(X, g.W)] << (8 * (k & 3));
-        }
-        pack.x = w[0]; pack.y = w[1]; pack.z = w[2]; pack.w = w[3];
-    }
-    uint8_t* drow = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)Yp * g.stride;
-    *(sd_u4v*)(drow + SD_XOFF + X0) = pack;
-}
+// (pyramid level 0 = padded copy of the input with BORDER_REFLECT_101, ORBextractor.cc:1127-1128: k_pyr_level0_gray / _rgb and
+//  their _frame kernels in k_fast.h)
 
 // ------------------------------------------------------------------ pyramid, level >= 1
 // cv::resize(INTER_LINEAR) of level-1's interior + REFLECT_101 border in one pass: every padded

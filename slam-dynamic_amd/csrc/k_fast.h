@@ -463,3 +463,47 @@ __global__ void __launch_bounds__(256) k_pyr_level0_rgb_frame(const uint8_t* __r
     uint8_t* drow = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)Yp * g.stride;
     *(sd_u4v*)(drow + SD_XOFF + X0) = o;
 }
+
+// The same pair for 8-bit gray input (the stereo path: GrabImageStereo hands two gray images to the extractor): one unaligned
+// 16-byte load and one aligned 16-byte store per interior group; the frame groups copy reflected bytes.
+__global__ void __launch_bounds__(256) k_pyr_level0_gray(const uint8_t* __restrict__ src, size_t sstride, size_t spitch,
+                                                         uint8_t* __restrict__ pyr, const SdDevPlan* __restrict__ PP, int groupsPerRow,
+                                                         uint32_t gprInv)
+{
+    const SdDevPlan& P = *PP;
+    const SdLevel& g = P.lv[0];
+    const int img = blockIdx.y;
+    const uint32_t item = blockIdx.x * 256u + threadIdx.x;
+    const int Yp = (int)__umulhi(item, gprInv);            // item / groupsPerRow
+    if (Yp >= g.H + 2 * SD_EDGE) return;
+    const int X0 = 16 * (int)(item - (uint32_t)Yp * (uint32_t)groupsPerRow);
+    const int sy = sd_reflect101(Yp - SD_EDGE, g.H);
+    const sd_u4v v = *(const sd_u128_unaligned*)(src + (size_t)img * spitch + (size_t)sy * sstride + X0);
+    *(sd_u4v*)(pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)Yp * g.stride + SD_XOFF + X0) = v;
+}
+
+__global__ void __launch_bounds__(256) k_pyr_level0_gray_frame(const uint8_t* __restrict__ src, size_t sstride, size_t spitch,
+                                                               uint8_t* __restrict__ pyr, const SdDevPlan* __restrict__ PP, int groupsPerRow,
+                                                               int tailGroups)
+{
+    const SdDevPlan& P = *PP;
+    const SdLevel& g = P.lv[0];
+    const int img = blockIdx.y;
+    const int per = 2 + tailGroups;
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    const int Yp = item / per, q = item - Yp * per;
+    if (Yp >= g.H + 2 * SD_EDGE) return;
+    const int X0 = q < 2 ? -SD_XOFF + 16 * q : 16 * (groupsPerRow + q - 2);
+    const int sy = sd_reflect101(Yp - SD_EDGE, g.H);
+    const uint8_t* srow = src + (size_t)img * spitch + (size_t)sy * sstride;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int X = X0 + k;
+        X = X < -SD_EDGE ? -SD_EDGE : (X > g.W + SD_EDGE - 1 ? g.W + SD_EDGE - 1 : X);     // margin bytes: any value
+        w[k >> 2] |= (uint32_t)srow[sd_reflect101(X, g.W)] << (8 * (k & 3));
+    }
+    sd_u4v o;
+    o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+    *(sd_u4v*)(pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)Yp * g.stride + SD_XOFF + X0) = o;
+}

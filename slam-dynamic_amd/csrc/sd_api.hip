@@ -465,18 +465,20 @@ static int extract_impl(sd_batch* b, const uint8_t* d_gray, size_t stride, size_
     {
         ProfScope ps(b, s, K_PYR0);
         const SdLevel& g = P.lv[0];
-        dim3 blk(64, 4), grd(((g.W + SD_XOFF + SD_EDGE + 15) / 16 + 63) / 64, (g.H + 2 * SD_EDGE + 3) / 4, n_images);
-        if (colorMode) {
+        {
+            // interior 16-byte groups flattened over (row, group) so that every wave is full + a small kernel for the groups on the frame
             const int gpr = g.W / 16;                                                    // groups fully inside the interior
             const int lastGroup = (g.W + SD_EDGE - 1) / 16;                              // group of the last frame column
             const int tail = lastGroup - gpr + 1, rows = g.H + 2 * SD_EDGE;
-            const uint32_t gprInv = 0xFFFFFFFFu / (uint32_t)gpr + 1u;
-            hipLaunchKernelGGL(k_pyr_level0_rgb, dim3((unsigned)((size_t)rows * gpr + 255) / 256, n_images), dim3(256), 0, s, d_gray, stride, image_pitch,
-                               colorMode == 2 ? 1 : 0, b->d_pyr, b->d_plan, gpr, gprInv);
-            hipLaunchKernelGGL(k_pyr_level0_rgb_frame, dim3((unsigned)(rows * (2 + tail) + 255) / 256, n_images), dim3(256), 0, s, d_gray, stride,
-                               image_pitch, colorMode == 2 ? 1 : 0, b->d_pyr, b->d_plan, gpr, tail);
+            const dim3 gi((unsigned)((size_t)rows * gpr + 255) / 256, n_images), gf((unsigned)(rows * (2 + tail) + 255) / 256, n_images);
+            if (gpr > 0) {
+                const uint32_t gprInv = 0xFFFFFFFFu / (uint32_t)gpr + 1u;
+                if (colorMode) hipLaunchKernelGGL(k_pyr_level0_rgb, gi, dim3(256), 0, s, d_gray, stride, image_pitch, colorMode == 2 ? 1 : 0, b->d_pyr, b->d_plan, gpr, gprInv);
+                else hipLaunchKernelGGL(k_pyr_level0_gray, gi, dim3(256), 0, s, d_gray, stride, image_pitch, b->d_pyr, b->d_plan, gpr, gprInv);
+            }
+            if (colorMode) hipLaunchKernelGGL(k_pyr_level0_rgb_frame, gf, dim3(256), 0, s, d_gray, stride, image_pitch, colorMode == 2 ? 1 : 0, b->d_pyr, b->d_plan, gpr, tail);
+            else hipLaunchKernelGGL(k_pyr_level0_gray_frame, gf, dim3(256), 0, s, d_gray, stride, image_pitch, b->d_pyr, b->d_plan, gpr, tail);
         }
-        else hipLaunchKernelGGL(k_pyr_level0, grd, blk, 0, s, d_gray, stride, image_pitch, b->d_pyr, b->d_plan);
     }
     LAUNCH_CHECK("k_pyr_level0");
     if (b->pyrTiles.empty()) {          // once per batch: LDS extents of k_pyr_level_tiles per level, or the per-thread kernel as a fallback
