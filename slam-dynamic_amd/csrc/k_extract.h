@@ -915,17 +915,31 @@ __global__ void __launch_bounds__(256) k_describe(const uint8_t* __restrict__ bl
     uint32_t pqs[4];                                                       // requested before the patches: one round trip for both
 #pragma unroll
     for (int r = 0; r < 4; r++) pqs[r] = *(const uint32_t*)(c_pattern + 4 * (lane + 64 * r));       // one dword = (x0, y0, x1, y1) as int8
+    // Patch fetch: lane -> (row, dword) of the 37 x 10-dword patch is the same for every keypoint, so the per-lane byte offsets are
+    // computed once (incrementally, no division per load) and a keypoint only adds its wave-uniform origin as the SCALAR offset of
+    // buffer loads: no vector address arithmetic per load (the kernel is bound by vector instruction issue).
+    const __amdgpu_buffer_rsrc_t plane = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(blur + (size_t)img * P.blurImageBytes + g.blurOffset), 0, 0x7FFFFFFF, 0x00020000);
+    int offs[6];
+    {
+        int r = lane / 10, c = lane - r * 10;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            offs[k] = r * step + 4 * c;
+            r += 6; c += 4;                                   // + 64 = 6 rows of 10 dwords + 4
+            if (c >= 10) { c -= 10; r += 1; }
+        }
+    }
     uint32_t pix[SD_DP_KPW][6];
 #pragma unroll
     for (int q = 0; q < SD_DP_KPW; q++) {
-        const int px = (int)(v[q] & 0xFFF) + g.minBX, py = (int)((v[q] >> 12) & 0xFFF) + g.minBY;
-        const uint8_t* corner = blur + (size_t)img * P.blurImageBytes + g.blurOffset + (size_t)(py - SD_DP_R) * step + (px - SD_DP_R);
+        const uint32_t vq = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[q]);      // the same in every lane: make it scalar
+        const int px = (int)(vq & 0xFFF) + g.minBX, py = (int)((vq >> 12) & 0xFFF) + g.minBY;
+        const int origin = (py - SD_DP_R) * step + (px - SD_DP_R);                    // >= 0: the patch lies inside the blurred plane
 #pragma unroll
         for (int k = 0; k < 6; k++) {
-            const int i = lane + 64 * k;
-            const int r = i / 10, c = i - r * 10;
             pix[q][k] = 0;
-            if (i < 370) pix[q][k] = *(const sd_u32_ua*)(corner + (size_t)r * step + 4 * c);
+            if (lane + 64 * k < 370) pix[q][k] = __builtin_amdgcn_raw_buffer_load_b32(plane, offs[k], origin, 0);
         }
     }
 #pragma unroll
