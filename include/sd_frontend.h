@@ -308,6 +308,73 @@ int sd_refqueue_candidate(sd_refqueue* q, double cur_timestamp, int cur_has_boxe
 int sd_refqueue_reject(sd_refqueue* q, int* again);
 int sd_refqueue_push(sd_refqueue* q, double timestamp, int slot, int has_boxes, int max_frames, int* evicted_slot);
 
+/* ---- Frame-level boundary: Tracking::GrabImage* -> Frame::Frame -> the dynamic block of Tracking::Track_new ----
+ * sd_tracker is the per-frame front end of ORB_SLAM2::Tracking for n_lanes independent camera streams ("lanes": one
+ * System each in the reference) that advance together, one frame per lane per call.  One call =
+ *   System::TrackStereo / TrackRGBD / TrackMonocular (include/System.h:66-79, src/System.cc:119-375)
+ *   -> Tracking::GrabImageStereo / GrabImageRGBD / GrabImageMonocular (src/Tracking.cc:170-343): cvtColor, depth scaling
+ *   -> Frame::Frame, all five constructors (src/Frame.cc:66-126, 129-237, 240-294, 297-403, 406-461): extract (both eyes),
+ *      boxTrack, firstSeparate + split, stereo / RGB-D association, grid
+ *   -> Track_new's dynamic block (src/Tracking.cc:620-666): reference frame from q_frame, TrackHomo (:968-1086, th / 2*th
+ *      retry, H / F fit), Separate (:1093-1239), UpdateFrame (Frame.cc:607-641)
+ *   -> [track_last] TrackWithMotionModel's SearchByProjection(mCurrentFrame, mLastFrame, th) (src/Tracking.cc:1714-1741)
+ *   -> q_frame.push / mLastFrame = Frame(mCurrentFrame) (src/Tracking.cc:952-959).
+ * What is NOT behind this boundary is the SLAM state: the pose prediction mVelocity * mLastFrame.mTcw is an input (Tcw,
+ * identity when NULL), a frame's map points are its own stereo points (Frame::UnprojectStereo), and `mState == OK &&
+ * !mVelocity.empty()` is taken to hold from a lane's third frame on.  Stereo + boxes follows DESIGN.md Q9.
+ * Results stay in the tracker's sd_batch (sd_tracker_batch): lane s's mCurrentFrame is slot cur_slot (valid until the next
+ * call), TrackHomo's pair index is s, the last-frame matcher's pair index is n_lanes + s (sd_batch_download_matches /
+ * _motion / _separate); every sd_batch_download_* call works on these slots. */
+#define SD_SENSOR_MONOCULAR 0 /* System::eSensor, include/System.h:60-64 */
+#define SD_SENSOR_STEREO 1
+#define SD_SENSOR_RGBD 2
+typedef struct sd_tracker sd_tracker;
+typedef struct sd_tracker_params {
+    int32_t sensor;         /* SD_SENSOR_* */
+    int32_t width, height;
+    int32_t channels;       /* input images: 1 = 8-bit gray, 3 = 8-bit BGR / RGB (cvtColor fused into the level-0 copy) */
+    int32_t rgb_order;      /* Camera.RGB (Tracking.cc:107-112) */
+    int32_t n_lanes;        /* independent camera streams */
+    int32_t track_last;     /* != 0: also match against mLastFrame */
+    int32_t reserved;
+    sd_camera cam;          /* Camera.fx .. Camera.bf and the image bounds */
+    float dist[5];          /* Camera.k1, k2, p1, p2, k3; must be zero (SD_ERR_UNSUPPORTED otherwise) */
+    float fps;              /* Camera.fps = mMaxFrames (Tracking.cc:93-98) */
+    float depth_map_factor; /* DepthMapFactor (Tracking.cc:141-146); RGB-D only */
+    float th_depth;         /* ThDepth (kept for the caller; not used on this path) */
+} sd_tracker_params;
+typedef struct sd_lane_result {
+    int32_t frame_id;       /* mnId within the lane (0, 1, ...) */
+    int32_t cur_slot;       /* sd_batch slot of mCurrentFrame */
+    int32_t last_slot;      /* slot of the copy kept as mLastFrame and as q_frame's newest entry */
+    int32_t ref_slot, ref_frame_id; /* the reference frame TrackHomo ran against last (-1: the dynamic block did not run) */
+    int32_t track_flag;     /* TrackHomo's return value: 0 failed / not run, 1 H, 2 F */
+    int32_t separate_ret;   /* Separate's return value (0 when it did not run) */
+    int32_t n_track_matches, n_track_pairs, n_h, n_f; /* nmatches, points_last.size(), n_H, n_F of TrackHomo */
+    int32_t n_last_matches; /* SearchByProjection(mCurrentFrame, mLastFrame) or -1 */
+    int32_t N, N_s, N_d;    /* keypoints after UpdateFrame; static / dynamic after the ctor's split */
+    int32_t n_boxes;        /* objects.size() after the empty-box erase */
+    int32_t box_idx[SD_MAX_BOXES], box_status[SD_MAX_BOXES];
+    uint8_t omit[SD_MAX_BOXES];
+    uint8_t pad_[4];
+    double objects[SD_MAX_BOXES][4], box_velocity[SD_MAX_BOXES][2];
+} sd_lane_result;
+int sd_tracker_create(sd_tracker** out, sd_extractor* ex, const sd_tracker_params* params);
+int sd_tracker_destroy(sd_tracker* t);
+int sd_tracker_reset(sd_tracker* t);              /* Tracking::Reset (src/Tracking.cc:2369-2409): every lane starts over */
+int sd_tracker_batch(sd_tracker* t, sd_batch** b); /* the workspace that holds the frames (owned by the tracker) */
+/* One frame of every lane.  d_images: image k (0 = left / the only one, 1 = right) of lane s starts at
+ * d_images + (s * images_per_lane + k) * image_pitch, rows `stride` bytes apart, `channels` bytes per pixel.
+ * d_depth (RGB-D): CV_16U depth image of lane s at d_depth + s * depth_pitch_elems.  boxes [n_lanes][SD_MAX_BOXES][4]
+ * (x, y, w, h) / n_boxes [n_lanes]: the detector's boxes of this frame; n_boxes[s] < 0 (or boxes == NULL) selects the
+ * constructor without boxes for that lane.  timestamps [n_lanes].  Tcw / Twc (nullable, [n_lanes][16] row-major): pose
+ * of the frame and its inverse.  results [n_lanes] (nullable).  The call returns after the results are on the host. */
+int sd_tracker_track(sd_tracker* t, const uint8_t* d_images, size_t stride, size_t image_pitch, const uint16_t* d_depth,
+                     size_t depth_stride_elems, size_t depth_pitch_elems, const double* boxes, const int32_t* n_boxes,
+                     const double* timestamps, const float* Tcw, const float* Twc, sd_lane_result* results, void* stream);
+/* Batch copy of frame slots (Frame's copy constructor, src/Frame.cc:39-63) in one launch: slot src[i] -> dst[i]. */
+int sd_batch_copy_frames(sd_batch* b, int n, const int32_t* src, const int32_t* dst, void* stream);
+
 /* ---- detector: yolov3Segment (include/yolo.h:22-48, src/yolo.cc, src/yolo/yolov3.cfg) ----
  * cv::dnn's Darknet importer + Net::forward + the reference's post-processing, on MFMA (f16 operands, f32
  * accumulation).  The network is given as a layer list (the five layer types of yolov3.cfg); weights are the

@@ -16,20 +16,23 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 
 
 def build(force=False):
+    """make decides staleness (every *.inc / *.h is a prerequisite in the Makefile)."""
     so = os.path.join(_HERE, "libsd_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("sd_oracle.cpp", "cv_leaves.h", "orb_pattern.inc", "frame_oracle.inc", "cull_oracle.inc")]
-    srcs = [s for s in srcs if os.path.exists(s)]
-    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    if force and os.path.exists(so):
+        os.remove(so)
+    if os.path.exists(os.path.join(_HERE, "Makefile")):
+        try:
+            subprocess.check_call(["make", "-C", _HERE, "-s"])
+        except (OSError, subprocess.CalledProcessError):
+            if not os.path.exists(so):
+                raise
     return so
 
 
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "libsd_oracle.so")
-        if not os.path.exists(so):
-            build()
+        so = build()
         _LIB = C.CDLL(so)
         _LIB.orc_extractor_create.restype = C.c_void_p
         _LIB.orc_extractor_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]

@@ -223,6 +223,8 @@ struct SdSepArgs {
     int* dynStatus;               // [pairs][itemsCap]
     int* matches;                 // [pairs][itemsCap][2]
     int* ret;                     // [pairs] 1 = a static box exists
+    const int* lastSlot;          // nullable: [pairs] slot of mLastFrame; its box_idx / box_status are read on the device instead of lastIdx / lastStatus
+    const int* active;            // nullable: [pairs] 0 = skip the pair, leave its results untouched (sd_tracker)
 };
 
 __device__ __forceinline__ void sd_inv3x3(const float* S, float* D)
@@ -283,10 +285,11 @@ __device__ __forceinline__ bool sd_classify_one(const float* M, const float* Mi,
 // train descriptors in LDS; the column minima (nearest query of every train) are LDS atomicMin on
 // (distance << 16 | query), which is exactly "first nearest wins".
 // HorF / flag of pair p from the model fit of the same pair index (sd_batch_estimate_motion -> sd_batch_separate)
-__global__ void k_motion_to_sep(const SdMotionResult* __restrict__ res, float* __restrict__ HorF, int* __restrict__ flag, int n)
+__global__ void k_motion_to_sep(const SdMotionResult* __restrict__ res, float* __restrict__ HorF, int* __restrict__ flag, int n,
+                                const int* __restrict__ active)
 {
     const int p = blockIdx.x * 64 + threadIdx.x;
-    if (p >= n) return;
+    if (p >= n || (active && !active[p])) return;
     for (int k = 0; k < 9; k++) HorF[(size_t)p * 9 + k] = res[p].HorF[k];
     flag[p] = res[p].flag;
 }
@@ -301,6 +304,7 @@ __global__ void __launch_bounds__(256) k_separate(SdCullPtrs A, SdSepArgs G)
     __shared__ float s_M[9], s_Mi[9];
     __shared__ int s_num0, s_static;
     const int pair = blockIdx.x, tid = threadIdx.x;
+    if (G.active && !G.active[pair]) return;
     const int cs = G.pairIdx[pair].x, rs = G.pairIdx[pair].y;
     SdFrameBoxes& FC = A.fb[cs];
     const SdFrameBoxes& FR = A.fb[rs];
@@ -386,8 +390,13 @@ __global__ void __launch_bounds__(256) k_separate(SdCullPtrs A, SdSepArgs G)
                 s_static = 1;                                      // `box_status[n_box] == 1;` is a no-op (:1188)
             } else {
                 int ls = -1;
-                const int nl = G.nLast[pair];
-                for (int j = 0; j < nl; j++) if (G.lastIdx[(size_t)pair * SD_MAXB + j] == id) { ls = G.lastStatus[(size_t)pair * SD_MAXB + j]; break; }
+                if (G.lastSlot) {                                  // mLastFrame lives in a slot of this batch
+                    const SdFrameBoxes& FL = A.fb[G.lastSlot[pair]];
+                    for (int j = 0; j < FL.nb; j++) if (FL.box_idx[j] == id) { ls = FL.box_status[j]; break; }
+                } else {
+                    const int nl = G.nLast[pair];
+                    for (int j = 0; j < nl; j++) if (G.lastIdx[(size_t)pair * SD_MAXB + j] == id) { ls = G.lastStatus[(size_t)pair * SD_MAXB + j]; break; }
+                }
                 FC.box_status[nbx] = (ls == 0 || ls == 2) ? 2 : 0;
             }
         }
@@ -406,6 +415,7 @@ __global__ void __launch_bounds__(256) k_update_frame(SdCullPtrs A, SdSepArgs G,
     uint8_t* seen = (uint8_t*)(list + A.itemsCap); // [cap] by class_id (= original index)
     __shared__ int s_n;
     const int pair = blockIdx.x, tid = threadIdx.x;
+    if (G.active && !G.active[pair]) return;
     if (doUpdate && !doUpdate[pair]) return;
     const int cs = G.pairIdx[pair].x;
     SdFrameBoxes& F = A.fb[cs];

@@ -347,9 +347,9 @@ struct SdCamera { float fx, fy, cx, cy, mbf, mb, mnMinX, mnMaxX, mnMinY, mnMaxY;
 // per-cell index lists are ordered by keypoint index, so (cell id, index) is the visiting order of
 // GetFeaturesInArea (cells ix-major, iy-minor; insertion order inside a cell).
 __global__ void __launch_bounds__(256) k_grid_cells(const sd_keypoint* __restrict__ kp, const int* __restrict__ count,
-                                                    short* __restrict__ cellOf, SdCamera cam, int cap)
+                                                    short* __restrict__ cellOf, SdCamera cam, int cap, int imgStep)
 {
-    const int img = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int img = blockIdx.y * imgStep, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= count[img]) return;
     const sd_keypoint k = kp[(size_t)img * cap + i];
     const float wInv = (float)SD_GRID_COLS / (cam.mnMaxX - cam.mnMinX);
@@ -366,14 +366,14 @@ __global__ void __launch_bounds__(256) k_grid_cells(const sd_keypoint* __restric
 #define SD_GRID_CELLS (SD_GRID_COLS * SD_GRID_ROWS)
 __global__ void __launch_bounds__(256) k_grid_sort(const short* __restrict__ cellOf, const int* __restrict__ count,
                                                    unsigned short* __restrict__ sortedIdx,
-                                                   unsigned short* __restrict__ cellStart, int cap, int /*sortN*/)
+                                                   unsigned short* __restrict__ cellStart, int cap, int imgStep)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     int* start = (int*)smem;                                   // [3072 + 1]
     int* fill = start + SD_GRID_CELLS + 8;                     // [3072]
     unsigned short* out = (unsigned short*)(fill + SD_GRID_CELLS);   // [cap]
     __shared__ int s_wsum[4];
-    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int img = blockIdx.x * imgStep, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int N = count[img];
     const short* cells = cellOf + (size_t)img * cap;
     for (int c = tid; c < SD_GRID_CELLS; c += 256) { start[c] = 0; fill[c] = 0; }
@@ -459,6 +459,9 @@ struct SdProjArgs {
     const unsigned short* sortedIdx; const unsigned short* cellStart; const float* xw; const uint8_t* flags; const uint8_t* dmp;
     const float* Tcw; const float* Tlw; unsigned short* cand; uint8_t* ncand; int* errFlag; const SdDevPlan* P;
     SdCamera cam; float th; int bMono; const int2* pairIdx;
+    // Tracker mode (sd_tracker): pairs whose `active` entry is 0 are skipped; with redoBelow > 0 only the pairs whose previous
+    // search returned fewer than redoBelow matches are searched again (TrackHomo's `if(nmatches<20)` retry with 2*th).
+    const int* active; const int* redoNmatch; int redoBelow;
 };
 
 // GW lanes (a group) work on point i of the pair; `live` = the group has a point.  Loop bounds are made wave-uniform with
@@ -618,6 +621,8 @@ __global__ void __launch_bounds__(256) k_proj_candidates(const SdProjArgs A)
 {
     __shared__ unsigned long long s_keys[4][SD_PROJ_K];
     const int pair = blockIdx.y;
+    if (A.active && !A.active[pair]) return;
+    if (A.redoBelow > 0 && A.redoNmatch[pair] >= A.redoBelow) return;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int Nl = A.count[A.pairIdx[pair].y];
     const int cap = A.P->kpCap;
@@ -658,8 +663,11 @@ __global__ void __launch_bounds__(64) k_proj_resolve(
     const sd_keypoint* __restrict__ kp, const int* __restrict__ count, const uint8_t* __restrict__ flags,
     const unsigned short* __restrict__ cand, const uint8_t* __restrict__ ncand, const uint8_t* __restrict__ occupied,
     int* __restrict__ matchOut, int* __restrict__ pairsOut, int* __restrict__ npairsOut, int* __restrict__ nmatchOut,
-    const SdDevPlan* __restrict__ PP, int checkOrientation, const int2* __restrict__ pairIdx)
+    const SdDevPlan* __restrict__ PP, int checkOrientation, const int2* __restrict__ pairIdx,
+    const int* __restrict__ active, int redoBelow)
 {
+    if (active && !active[blockIdx.x]) return;                       // tracker mode: see SdProjArgs
+    if (redoBelow > 0 && nmatchOut[blockIdx.x] >= redoBelow) return;
     const SdDevPlan& P = *PP;
     extern __shared__ __align__(16) unsigned char smem[];
     const int cap = P.kpCap;

@@ -45,11 +45,14 @@ __device__ inline bool sd_motion_sample(int m, int h, int N, int need, int* idx)
 __global__ void __launch_bounds__(256) k_motion_prepare(const sd_keypoint* __restrict__ kp, const int* __restrict__ pairs,
                                                         const int* __restrict__ npairs, const int2* __restrict__ pairIdx, int cap,
                                                         float* __restrict__ pts /*[pair][cap][4]: x1 y1 x2 y2*/,
-                                                        SdMotionNorm* __restrict__ norm)
+                                                        SdMotionNorm* __restrict__ norm, const int* __restrict__ active,
+                                                        const int* __restrict__ nmatch, int minMatches)
 {
     const int pair = blockIdx.x, tid = threadIdx.x;
+    if (active && !active[pair]) return;
     const int imgC = pairIdx[pair].x, imgL = pairIdx[pair].y;
-    const int N = npairs[pair];
+    // TrackHomo's `if(nmatches<20) return 0` (Tracking.cc:1013-1017): no model is fitted, the flag comes out 0
+    const int N = (nmatch && nmatch[pair] < minMatches) ? 0 : npairs[pair];
     float* P = pts + (size_t)pair * cap * 4;
     for (int i = tid; i < N; i += 256) {
         const int iL = pairs[((size_t)pair * cap + i) * 2], iC = pairs[((size_t)pair * cap + i) * 2 + 1];
@@ -235,10 +238,11 @@ __device__ inline bool sd_motion_model(const float* P, const SdMotionNorm& n, in
 }
 
 __global__ void __launch_bounds__(256) k_motion_hyp(const float* __restrict__ pts, const SdMotionNorm* __restrict__ norm, int cap,
-                                                    int* __restrict__ counts /*[pair][SD_MOTION_K]*/)
+                                                    int* __restrict__ counts /*[pair][SD_MOTION_K]*/, const int* __restrict__ active)
 {
     extern __shared__ __align__(16) float sP[];               // [N][4]
     const int pair = blockIdx.y, hyp = blockIdx.x * 256 + threadIdx.x;
+    if (active && !active[pair]) return;
     const SdMotionNorm n = norm[pair];
     const float* P = pts + (size_t)pair * cap * 4;
     if (!n.ok) { if (hyp < SD_MOTION_K) counts[(size_t)pair * SD_MOTION_K + hyp] = -1; return; }
@@ -257,8 +261,10 @@ __global__ void __launch_bounds__(256) k_motion_hyp(const float* __restrict__ pt
 
 __global__ void __launch_bounds__(256) k_motion_select(const float* __restrict__ pts, const SdMotionNorm* __restrict__ norm,
                                                        const int* __restrict__ counts, int cap, uint8_t* __restrict__ maskH,
-                                                       uint8_t* __restrict__ maskF, SdMotionResult* __restrict__ res)
+                                                       uint8_t* __restrict__ maskF, SdMotionResult* __restrict__ res,
+                                                       const int* __restrict__ active)
 {
+    if (active && !active[blockIdx.x]) return;
     __shared__ int s_best[2], s_cnt[2];
     __shared__ double s_H[9], s_F[9], s_M[81], s_V[81];
     __shared__ double s_rows[SD_MOTION_CHUNK * 18];

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <string>
 #include <vector>
 #include "k_extract.h"
@@ -12,6 +13,7 @@
 #include "k_fast.h"
 #include "k_motion.h"
 #include "k_cull.h"
+#include "k_tracker.h"
 #include "sd_yolo.h"
 #include "sd_vocab.h"
 
@@ -99,6 +101,7 @@ struct sd_batch {
     int* d_nmatch = nullptr;
     float* d_pose = nullptr;        // staging for host poses: [2][maxImages][16]
     int nPairs = 0;
+    int dlPairs = 0;          // pairs sd_batch_download_matches may read (the tracker also keeps pairs at [n_lanes, 2 * n_lanes))
     // dynamic-object cull
     SdFrameBoxes* d_fb = nullptr;
     int* d_boxItems = nullptr;
@@ -108,10 +111,12 @@ struct sd_batch {
     float* d_HorF = nullptr; int* d_sepFlag = nullptr; int* d_lastIdx = nullptr; int* d_lastStatus = nullptr; int* d_nLast = nullptr;
     int* d_dynStart = nullptr; int* d_dynStatus = nullptr; int* d_sepMatches = nullptr; int* d_sepRet = nullptr;
     int2* d_sepPairs = nullptr;
+    int2* d_copyPairs = nullptr;
     int itemsCap = 0;
     int nSepPairs = 0;
+    const int* sepActive = nullptr;          // active mask of the last separate (tracker mode), applied by update_frame too
     std::vector<SdFrameBoxes> hostBoxes;     // staging that must outlive the async uploads
-    std::vector<int2> hostPairs;
+    std::vector<int2> hostPairs, hostCopyPairs;
     uint8_t* d_stage = nullptr;    // staging for host-image uploads
     size_t stageBytes = 0;
     int qtMN = 0, qtSortP = 0;
@@ -225,7 +230,7 @@ static void batch_free(sd_batch* b)
                     b->d_sepPairs, b->d_kpD, b->d_descD, b->d_urD, b->d_depD, b->d_rowIdx, b->d_rowStart,
                     b->d_lmCand, b->d_lmN, b->d_lmOvf, b->d_lmIdx, b->d_bowWordF, b->d_bowWF, b->d_bowNidF, b->d_fvNode, b->d_fvFeat,
                     b->d_fvRunStart, b->d_fvRunNode, b->d_bowWord, b->d_bowVal, b->d_bowMeta, b->d_bowImg,
-                    b->d_moPts, b->d_moNorm, b->d_moCounts, b->d_moMaskH, b->d_moMaskF, b->d_moRes, b->d_pyrExt};
+                    b->d_moPts, b->d_moNorm, b->d_moCounts, b->d_moMaskH, b->d_moMaskF, b->d_moRes, b->d_pyrExt, b->d_copyPairs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& r : b->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : b->pool) (void)hipEventDestroy(e);
@@ -341,6 +346,7 @@ int sd_batch_create(sd_batch** out, sd_extractor* ex, int width, int height, int
     ALLOC(b->d_sepMatches, nI * b->itemsCap * 8);
     ALLOC(b->d_sepRet, nI * 4);
     ALLOC(b->d_sepPairs, nI * sizeof(int2));
+    ALLOC(b->d_copyPairs, nI * sizeof(int2));
     ALLOC(b->d_pairIdx, nI * sizeof(int2));
     b->slotValid.assign(nI, 0);
 #undef ALLOC
@@ -908,17 +914,21 @@ static SdCamera to_cam(const sd_camera* c)
     return k;
 }
 
-int sd_batch_assign_grid(sd_batch* b, int n_images, const sd_camera* cam, void* stream_)
+static int assign_grid_impl(sd_batch* b, int n_images, int image_step, const sd_camera* cam, void* stream_);
+int sd_batch_assign_grid(sd_batch* b, int n_images, const sd_camera* cam, void* stream_) { return assign_grid_impl(b, n_images, 1, cam, stream_); }
+
+// slots 0, image_step, 2 * image_step, ... (n_images of them): the tracker grids the left images only
+static int assign_grid_impl(sd_batch* b, int n_images, int image_step, const sd_camera* cam, void* stream_)
 {
-    if (!b || n_images < 0 || !cam_ok(cam)) return set_err(SD_ERR_INVALID, "bad grid arguments");
-    if (n_images > b->nExtracted) return set_err(SD_ERR_STATE, "grid needs extracted images");
+    if (!b || n_images < 0 || image_step < 1 || !cam_ok(cam)) return set_err(SD_ERR_INVALID, "bad grid arguments");
+    if ((n_images - 1) * image_step + 1 > b->nExtracted) return set_err(SD_ERR_STATE, "grid needs extracted images");
     hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
     b->lastStream = s;
     if (n_images == 0) return SD_OK;
     {
         ProfScope ps(b, s, K_GRID);
         dim3 grd((b->plan.kpCap + 255) / 256, n_images);
-        hipLaunchKernelGGL(k_grid_cells, grd, dim3(256), 0, s, b->d_kp, b->d_count, b->d_cellOf, to_cam(cam), b->plan.kpCap);
+        hipLaunchKernelGGL(k_grid_cells, grd, dim3(256), 0, s, b->d_kp, b->d_count, b->d_cellOf, to_cam(cam), b->plan.kpCap, image_step);
     }
     LAUNCH_CHECK("k_grid_cells");
     const size_t gridLds = (size_t)(SD_GRID_CELLS + 8) * 4 + (size_t)SD_GRID_CELLS * 4 + (size_t)b->plan.kpCap * 2 + 16;
@@ -926,7 +936,7 @@ int sd_batch_assign_grid(sd_batch* b, int n_images, const sd_camera* cam, void* 
     {
         ProfScope ps(b, s, K_GRID);
         hipLaunchKernelGGL(k_grid_sort, dim3(n_images), dim3(256), gridLds, s, b->d_cellOf, b->d_count, b->d_sortedIdx,
-                           b->d_cellStart, b->plan.kpCap, b->gridSortN);
+                           b->d_cellStart, b->plan.kpCap, image_step);
     }
     LAUNCH_CHECK("k_grid_sort");
     return SD_OK;
@@ -1000,11 +1010,28 @@ int sd_batch_download_mappoints(sd_batch* b, int image, float* xw, uint8_t* flag
     return SD_OK;
 }
 
+// pairBase: first pair index of the per-pair arrays this call uses (the tracker keeps TrackHomo's pairs at [0, S) and
+// TrackWithMotionModel's at [S, 2S)); d_active / redoBelow: see SdProjArgs; upload: 0 = index and pose arrays of a preceding
+// call are reused (the 2*th retry).
+static int search_by_projection_impl(sd_batch* b, int pairBase, int n_pairs, const int32_t* cur_index, const int32_t* last_index,
+                                     const float* Tcw_host, const float* Tlw_host, const sd_camera* cam, float th, int bMono,
+                                     int checkOrientation, const uint8_t* d_occupied, const uint8_t* d_mp_desc, void* stream_,
+                                     const int* d_active, int redoBelow, int upload);
+
 int sd_batch_search_by_projection(sd_batch* b, int n_pairs, const int32_t* cur_index, const int32_t* last_index,
                                   const float* Tcw_host, const float* Tlw_host, const sd_camera* cam, float th, int bMono,
                                   int checkOrientation, const uint8_t* d_occupied, const uint8_t* d_mp_desc, void* stream_)
 {
-    if (!b || n_pairs < 0 || n_pairs > b->maxImages || !cam_ok(cam) || !Tcw_host || !Tlw_host || !(th > 0) ||
+    return search_by_projection_impl(b, 0, n_pairs, cur_index, last_index, Tcw_host, Tlw_host, cam, th, bMono, checkOrientation,
+                                     d_occupied, d_mp_desc, stream_, nullptr, 0, 1);
+}
+
+static int search_by_projection_impl(sd_batch* b, int pairBase, int n_pairs, const int32_t* cur_index, const int32_t* last_index,
+                                     const float* Tcw_host, const float* Tlw_host, const sd_camera* cam, float th, int bMono,
+                                     int checkOrientation, const uint8_t* d_occupied, const uint8_t* d_mp_desc, void* stream_,
+                                     const int* d_active, int redoBelow, int upload)
+{
+    if (!b || n_pairs < 0 || pairBase < 0 || pairBase + n_pairs > b->maxImages || !cam_ok(cam) || !Tcw_host || !Tlw_host || !(th > 0) ||
         (n_pairs > 0 && (!cur_index || !last_index)))
         return set_err(SD_ERR_INVALID, "bad search_by_projection arguments");
     std::vector<int2> idx(n_pairs);
@@ -1016,22 +1043,27 @@ int sd_batch_search_by_projection(sd_batch* b, int n_pairs, const int32_t* cur_i
     if (b->plan.kpCap > 65535) return set_err(SD_ERR_UNSUPPORTED, "more than 65535 keypoints per image");
     hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
     b->lastStream = s;
-    b->nPairs = 0;
+    if (pairBase == 0) b->nPairs = 0;
     if (n_pairs == 0) return SD_OK;
-    float* dTc = b->d_pose;
-    float* dTl = b->d_pose + (size_t)b->maxImages * 16;
-    HIPCHK(hipMemcpyAsync(dTc, Tcw_host, (size_t)n_pairs * 64, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(dTl, Tlw_host, (size_t)n_pairs * 64, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(b->d_pairIdx, idx.data(), (size_t)n_pairs * sizeof(int2), hipMemcpyHostToDevice, s));
+    float* dTc = b->d_pose + (size_t)pairBase * 16;
+    float* dTl = b->d_pose + ((size_t)b->maxImages + pairBase) * 16;
+    int2* dIdx = b->d_pairIdx + pairBase;
+    if (upload) {
+        HIPCHK(hipMemcpyAsync(dTc, Tcw_host, (size_t)n_pairs * 64, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(dTl, Tlw_host, (size_t)n_pairs * 64, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(dIdx, idx.data(), (size_t)n_pairs * sizeof(int2), hipMemcpyHostToDevice, s));
+    }
     const int cap = b->plan.kpCap;
+    const size_t pOff = (size_t)pairBase * cap;
     {
         ProfScope ps(b, s, K_PROJ_A);
         dim3 grd((cap + 15) / 16, n_pairs);                 // 16 points per workgroup: four per wave, 16 lanes each
         SdProjArgs pa;
         pa.kp = b->d_kp; pa.desc = b->d_desc; pa.uRight = b->d_uright; pa.count = b->d_count; pa.cellOf = b->d_cellOf;
         pa.sortedIdx = b->d_sortedIdx; pa.cellStart = b->d_cellStart; pa.xw = b->d_xw; pa.flags = b->d_flags;
-        pa.dmp = d_mp_desc ? d_mp_desc : b->d_desc; pa.Tcw = dTc; pa.Tlw = dTl; pa.cand = b->d_pcand; pa.ncand = b->d_pncand;
-        pa.errFlag = b->d_err; pa.P = b->d_plan; pa.cam = to_cam(cam); pa.th = th; pa.bMono = bMono; pa.pairIdx = b->d_pairIdx;
+        pa.dmp = d_mp_desc ? d_mp_desc : b->d_desc; pa.Tcw = dTc; pa.Tlw = dTl; pa.cand = b->d_pcand + pOff * SD_PROJ_K; pa.ncand = b->d_pncand + pOff;
+        pa.errFlag = b->d_err; pa.P = b->d_plan; pa.cam = to_cam(cam); pa.th = th; pa.bMono = bMono; pa.pairIdx = dIdx;
+        pa.active = d_active; pa.redoNmatch = b->d_nmatch + pairBase; pa.redoBelow = redoBelow;
         hipLaunchKernelGGL(k_proj_candidates, grd, dim3(256), 0, s, pa);
     }
     LAUNCH_CHECK("k_proj_candidates");
@@ -1041,11 +1073,13 @@ int sd_batch_search_by_projection(sd_batch* b, int n_pairs, const int32_t* cur_i
         size_t lds = capA * (4 + 4 + 4 + 2 + 1 + 1 + 1) + 16;
         if (lds > 160 * 1024 - 256) return set_err(SD_ERR_UNSUPPORTED, "too many keypoints per image for the projection matcher's LDS tables");
         if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_proj_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_proj_resolve, dim3(n_pairs), dim3(64), lds, s, b->d_kp, b->d_count, b->d_flags, b->d_pcand, b->d_pncand,
-                           d_occupied, b->d_match, b->d_pairs, b->d_npairs, b->d_nmatch, b->d_plan, checkOrientation, b->d_pairIdx);
+        hipLaunchKernelGGL(k_proj_resolve, dim3(n_pairs), dim3(64), lds, s, b->d_kp, b->d_count, b->d_flags, b->d_pcand + pOff * SD_PROJ_K, b->d_pncand + pOff,
+                           d_occupied, b->d_match + pOff, b->d_pairs + pOff * 2, b->d_npairs + pairBase, b->d_nmatch + pairBase, b->d_plan, checkOrientation,
+                           dIdx, d_active, redoBelow);
     }
     LAUNCH_CHECK("k_proj_resolve");
-    b->nPairs = n_pairs;
+    if (pairBase == 0) b->nPairs = n_pairs;
+    b->dlPairs = std::max(pairBase + n_pairs, pairBase ? b->dlPairs : 0);
     return SD_OK;
 }
 
@@ -1075,7 +1109,7 @@ int sd_batch_search_local_map(sd_batch* b, int n_frames, const int32_t* frame_in
     b->lastStream = s;
     if (total > b->lmCap) {                       // candidate scratch grows with the largest local map seen
         HIPCHK(hipStreamSynchronize(s));
-        if (b->d_lmCand) { hipFree(b->d_lmCand); hipFree(b->d_lmN); hipFree(b->d_lmOvf); b->d_lmCand = nullptr; b->d_lmN = b->d_lmOvf = nullptr; }
+        if (b->d_lmCand) { (void)hipFree(b->d_lmCand); (void)hipFree(b->d_lmN); (void)hipFree(b->d_lmOvf); b->d_lmCand = nullptr; b->d_lmN = b->d_lmOvf = nullptr; }
         const int want = std::max(total, 2 * b->lmCap);
         HIPCHK(hipMalloc((void**)&b->d_lmCand, (size_t)want * SD_PROJ_K * 4));
         HIPCHK(hipMalloc((void**)&b->d_lmN, (size_t)want));
@@ -1333,7 +1367,7 @@ int sd_batch_search_by_bow(sd_batch* b, int n_pairs, const int32_t* kf_index, co
     }
     hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
     b->lastStream = s;
-    b->nPairs = 0;
+    b->nPairs = 0; b->dlPairs = 0;
     if (n_pairs == 0) return SD_OK;
     HIPCHK(hipMemcpyAsync(b->d_pairIdx, idx.data(), (size_t)n_pairs * sizeof(int2), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(b->d_npairs, 0, (size_t)n_pairs * 4, s));
@@ -1345,16 +1379,19 @@ int sd_batch_search_by_bow(sd_batch* b, int n_pairs, const int32_t* kf_index, co
                            b->d_bowMeta, d_kf_valid, b->d_pairIdx, cap, nnratio, checkOrientation, b->d_match, b->d_nmatch);
         LAUNCH_CHECK("k_search_by_bow");
     }
-    b->nPairs = n_pairs;
+    b->nPairs = n_pairs; b->dlPairs = n_pairs;
     return SD_OK;
 }
 
 // The model fit of Tracking::TrackHomo (src/Tracking.cc:1026-1075) for every pair of the preceding
 // sd_batch_search_by_projection: points_last / points_current -> H, F, inlier masks, the choice 1 (H) / 2 (F) / 0.
-int sd_batch_estimate_motion(sd_batch* b, void* stream_)
+static int estimate_motion_impl(sd_batch* b, int n_pairs, void* stream_, const int* d_active, int minMatches);
+int sd_batch_estimate_motion(sd_batch* b, void* stream_) { return estimate_motion_impl(b, b ? b->nPairs : 0, stream_, nullptr, 0); }
+
+// d_active: see SdProjArgs; minMatches > 0: a pair whose matcher returned fewer matches gets flag 0 (TrackHomo's `nmatches<20`)
+static int estimate_motion_impl(sd_batch* b, int n_pairs, void* stream_, const int* d_active, int minMatches)
 {
     if (!b) return set_err(SD_ERR_INVALID, "null batch");
-    const int n_pairs = b->nPairs;
     b->nMotion = 0;
     if (n_pairs <= 0) return set_err(SD_ERR_STATE, "estimate_motion: no preceding sd_batch_search_by_projection");
     hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
@@ -1367,17 +1404,18 @@ int sd_batch_estimate_motion(sd_batch* b, void* stream_)
     }
     {
         ProfScope ps(b, s, K_MOTION_P);
-        hipLaunchKernelGGL(k_motion_prepare, dim3(n_pairs), dim3(256), cap * 16, s, b->d_kp, b->d_pairs, b->d_npairs, b->d_pairIdx, (int)cap, b->d_moPts, b->d_moNorm);
+        hipLaunchKernelGGL(k_motion_prepare, dim3(n_pairs), dim3(256), cap * 16, s, b->d_kp, b->d_pairs, b->d_npairs, b->d_pairIdx, (int)cap, b->d_moPts, b->d_moNorm,
+                           d_active, minMatches > 0 ? (const int*)b->d_nmatch : (const int*)nullptr, minMatches);
         LAUNCH_CHECK("k_motion_prepare");
     }
     {
         ProfScope ps(b, s, K_MOTION_H);
-        hipLaunchKernelGGL(k_motion_hyp, dim3(SD_MOTION_K / 256, n_pairs), dim3(256), cap * 16, s, b->d_moPts, b->d_moNorm, (int)cap, b->d_moCounts);
+        hipLaunchKernelGGL(k_motion_hyp, dim3(SD_MOTION_K / 256, n_pairs), dim3(256), cap * 16, s, b->d_moPts, b->d_moNorm, (int)cap, b->d_moCounts, d_active);
         LAUNCH_CHECK("k_motion_hyp");
     }
     {
         ProfScope ps(b, s, K_MOTION_S);
-        hipLaunchKernelGGL(k_motion_select, dim3(n_pairs), dim3(256), 0, s, b->d_moPts, b->d_moNorm, b->d_moCounts, (int)cap, b->d_moMaskH, b->d_moMaskF, b->d_moRes);
+        hipLaunchKernelGGL(k_motion_select, dim3(n_pairs), dim3(256), 0, s, b->d_moPts, b->d_moNorm, b->d_moCounts, (int)cap, b->d_moMaskH, b->d_moMaskF, b->d_moRes, d_active);
         LAUNCH_CHECK("k_motion_select");
     }
     b->nMotion = n_pairs;
@@ -1509,7 +1547,7 @@ int sd_batch_matches_device(sd_batch* b, int32_t** d_match, int32_t** d_pairs, i
 
 int sd_batch_download_matches(sd_batch* b, int pair, int32_t* match, int32_t* pairs, int cap, int* npairs, int* nmatches)
 {
-    if (!b || pair < 0 || pair >= b->nPairs) return SD_ERR_INVALID;
+    if (!b || pair < 0 || pair >= b->dlPairs) return SD_ERR_INVALID;
     int rc = sd_batch_sync(b);
     if (rc != SD_OK) return rc;
     if (cap < b->plan.kpCap) return set_err(SD_ERR_CAPACITY, "match buffers need kp_capacity entries");
@@ -1696,12 +1734,23 @@ int sd_batch_download_dynamic(sd_batch* b, int slot, sd_keypoint* kp, uint8_t* d
     return SD_OK;
 }
 
+static int separate_impl(sd_batch* b, int n_pairs, const int32_t* cur_index, const int32_t* ref_index, const float* HorF,
+                         const int32_t* flag, const int32_t* last_box_idx, const int32_t* last_box_status, const int32_t* n_last,
+                         void* stream_, const int32_t* last_slot, const int* d_active);
 int sd_batch_separate(sd_batch* b, int n_pairs, const int32_t* cur_index, const int32_t* ref_index, const float* HorF,
                       const int32_t* flag, const int32_t* last_box_idx, const int32_t* last_box_status, const int32_t* n_last,
                       void* stream_)
 {
+    return separate_impl(b, n_pairs, cur_index, ref_index, HorF, flag, last_box_idx, last_box_status, n_last, stream_, nullptr, nullptr);
+}
+
+// last_slot (host, nullable): slot of mLastFrame per pair, replaces last_box_idx / last_box_status / n_last; d_active: see SdSepArgs
+static int separate_impl(sd_batch* b, int n_pairs, const int32_t* cur_index, const int32_t* ref_index, const float* HorF,
+                         const int32_t* flag, const int32_t* last_box_idx, const int32_t* last_box_status, const int32_t* n_last,
+                         void* stream_, const int32_t* last_slot, const int* d_active)
+{
     if (!b || n_pairs < 0 || n_pairs > b->maxImages ||
-        (n_pairs > 0 && (!cur_index || !ref_index || (!HorF) != (!flag) || !last_box_idx || !last_box_status || !n_last)))
+        (n_pairs > 0 && (!cur_index || !ref_index || (!HorF) != (!flag) || (!last_slot && (!last_box_idx || !last_box_status || !n_last)))))
         return set_err(SD_ERR_INVALID, "bad separate arguments");
     const bool fromMotion = n_pairs > 0 && !HorF;          // HorF == flag == NULL: pair p uses the model fit of pair p
     if (fromMotion && b->nMotion < n_pairs) return set_err(SD_ERR_STATE, "separate: no sd_batch_estimate_motion results for these pairs");
@@ -1714,23 +1763,29 @@ int sd_batch_separate(sd_batch* b, int n_pairs, const int32_t* cur_index, const 
     for (int p = 0; p < n_pairs; p++) {
         if (!slot_ok(b, cur_index[p]) || !slot_ok(b, ref_index[p])) return set_err(SD_ERR_STATE, "separate: slot holds no results");
         if (!fromMotion && flag[p] != 1 && flag[p] != 2) return set_err(SD_ERR_INVALID, "separate: flag must be 1 (H) or 2 (F)");
-        if (n_last[p] < 0 || n_last[p] > SD_MAXB) return set_err(SD_ERR_INVALID, "separate: bad n_last");
+        if (last_slot ? !slot_ok(b, last_slot[p]) : (n_last[p] < 0 || n_last[p] > SD_MAXB)) return set_err(SD_ERR_INVALID, "separate: bad n_last / last slot");
         idx[p] = make_int2(cur_index[p], ref_index[p]);
     }
     HIPCHK(hipMemcpyAsync(b->d_sepPairs, idx.data(), (size_t)n_pairs * sizeof(int2), hipMemcpyHostToDevice, s));
     if (fromMotion) {
-        hipLaunchKernelGGL(k_motion_to_sep, dim3((n_pairs + 63) / 64), dim3(64), 0, s, b->d_moRes, b->d_HorF, b->d_sepFlag, n_pairs);
+        hipLaunchKernelGGL(k_motion_to_sep, dim3((n_pairs + 63) / 64), dim3(64), 0, s, b->d_moRes, b->d_HorF, b->d_sepFlag, n_pairs, d_active);
         LAUNCH_CHECK("k_motion_to_sep");
     } else {
         HIPCHK(hipMemcpyAsync(b->d_HorF, HorF, (size_t)n_pairs * 36, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(b->d_sepFlag, flag, (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));
     }
-    HIPCHK(hipMemcpyAsync(b->d_lastIdx, last_box_idx, (size_t)n_pairs * SD_MAXB * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(b->d_lastStatus, last_box_status, (size_t)n_pairs * SD_MAXB * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(b->d_nLast, n_last, (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));
+    if (last_slot) {
+        HIPCHK(hipMemcpyAsync(b->d_nLast, last_slot, (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));      // d_nLast doubles as the slot list
+    } else {
+        HIPCHK(hipMemcpyAsync(b->d_lastIdx, last_box_idx, (size_t)n_pairs * SD_MAXB * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(b->d_lastStatus, last_box_status, (size_t)n_pairs * SD_MAXB * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(b->d_nLast, n_last, (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));
+    }
     SdSepArgs G;
     G.pairIdx = b->d_sepPairs; G.HorF = b->d_HorF; G.flag = b->d_sepFlag; G.lastIdx = b->d_lastIdx; G.lastStatus = b->d_lastStatus;
     G.nLast = b->d_nLast; G.dynStart = b->d_dynStart; G.dynStatus = b->d_dynStatus; G.matches = b->d_sepMatches; G.ret = b->d_sepRet;
+    G.lastSlot = last_slot ? b->d_nLast : nullptr; G.active = d_active;
+    b->sepActive = d_active;
     {
         ProfScope ps(b, s, K_SEPARATE);
         hipLaunchKernelGGL(k_separate, dim3(n_pairs), dim3(256), (size_t)SD_BF_TCAP * 40 + 64, s, cull_ptrs(b), G);
@@ -1767,6 +1822,7 @@ int sd_batch_update_frame(sd_batch* b, int only_if_static, void* stream_)
     SdSepArgs G;
     G.pairIdx = b->d_sepPairs; G.HorF = b->d_HorF; G.flag = b->d_sepFlag; G.lastIdx = b->d_lastIdx; G.lastStatus = b->d_lastStatus;
     G.nLast = b->d_nLast; G.dynStart = b->d_dynStart; G.dynStatus = b->d_dynStatus; G.matches = b->d_sepMatches; G.ret = b->d_sepRet;
+    G.lastSlot = nullptr; G.active = b->sepActive;
     {
         ProfScope ps(b, s, K_UPDATE);
         const size_t lds = (size_t)b->itemsCap * 4 + (size_t)b->plan.kpCap + 64;
@@ -2357,5 +2413,7 @@ int sd_batch_reset_kernel_times(sd_batch* b)
     for (int i = 0; i < K_COUNT; i++) { b->totalMs[i] = 0; b->launches[i] = 0; }
     return SD_OK;
 }
+
+#include "sd_tracker.inc"
 
 } // extern "C"

@@ -104,6 +104,12 @@ def lib():
         L.sd_batch_reset_kernel_times.argtypes = [vp]
         L.sd_batch_sync.argtypes = [vp]
         L.sd_device_count.argtypes = [C.POINTER(i)]
+        L.sd_tracker_create.argtypes = [C.POINTER(vp), vp, vp]
+        L.sd_tracker_destroy.argtypes = [vp]
+        L.sd_tracker_reset.argtypes = [vp]
+        L.sd_tracker_batch.argtypes = [vp, C.POINTER(vp)]
+        L.sd_tracker_track.argtypes = [vp, vp, sz, sz, vp, sz, sz, vp, vp, vp, vp, vp, vp, vp]
+        L.sd_batch_copy_frames.argtypes = [vp, i, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -161,19 +167,23 @@ class ORBextractor:
 class Batch:
     """Device workspace: batched ORBextractor::operator() + the Frame-side association steps."""
 
-    def __init__(self, extractor, width, height, max_images):
+    def __init__(self, extractor, width, height, max_images, handle=None):
         self.ex = extractor
         self.W, self.H, self.max_images = width, height, max_images
+        self.owned = handle is None
         self.h = C.c_void_p()
-        check(lib().sd_batch_create(C.byref(self.h), extractor.h, width, height, max_images))
+        if handle is None:
+            check(lib().sd_batch_create(C.byref(self.h), extractor.h, width, height, max_images))
+        else:                                  # a view of the workspace owned by a Tracker
+            self.h = C.c_void_p(handle)
         c = C.c_int()
         check(lib().sd_batch_kp_capacity(self.h, C.byref(c)))
         self.cap = c.value
 
     def close(self):
-        if self.h:
+        if self.h and self.owned:
             lib().sd_batch_destroy(self.h)
-            self.h = C.c_void_p()
+        self.h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -345,6 +355,10 @@ class Batch:
     def copy_frame(self, src, dst, stream=None):
         check(lib().sd_batch_copy_frame(self.h, src, dst, C.c_void_p(stream or 0)))
 
+    def copy_frames(self, src, dst, stream=None):
+        a = np.ascontiguousarray(src, np.int32); d = np.ascontiguousarray(dst, np.int32)
+        check(lib().sd_batch_copy_frames(self.h, len(a), _p(a), _p(d), C.c_void_p(stream or 0)))
+
     def download_matches(self, pair):
         match = np.zeros(self.cap, np.int32); pairs = np.zeros((self.cap, 2), np.int32)
         npairs = C.c_int(); nm = C.c_int()
@@ -431,6 +445,88 @@ class Batch:
 
 
 MAXB = 32
+SENSOR_MONOCULAR, SENSOR_STEREO, SENSOR_RGBD = 0, 1, 2
+
+
+class _Camera(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("fx", "fy", "cx", "cy", "mbf", "mb", "mnMinX", "mnMaxX", "mnMinY", "mnMaxY")]
+
+
+class TrackerParams(C.Structure):
+    """sd_tracker_params (include/sd_frontend.h)."""
+    _fields_ = [("sensor", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32), ("rgb_order", C.c_int32),
+                ("n_lanes", C.c_int32), ("track_last", C.c_int32), ("reserved", C.c_int32), ("cam", _Camera), ("dist", C.c_float * 5),
+                ("fps", C.c_float), ("depth_map_factor", C.c_float), ("th_depth", C.c_float)]
+
+
+class LaneResult(C.Structure):
+    """sd_lane_result (include/sd_frontend.h)."""
+    _fields_ = [("frame_id", C.c_int32), ("cur_slot", C.c_int32), ("last_slot", C.c_int32), ("ref_slot", C.c_int32), ("ref_frame_id", C.c_int32),
+                ("track_flag", C.c_int32), ("separate_ret", C.c_int32), ("n_track_matches", C.c_int32), ("n_track_pairs", C.c_int32),
+                ("n_h", C.c_int32), ("n_f", C.c_int32), ("n_last_matches", C.c_int32), ("N", C.c_int32), ("N_s", C.c_int32), ("N_d", C.c_int32),
+                ("n_boxes", C.c_int32), ("box_idx", C.c_int32 * 32), ("box_status", C.c_int32 * 32), ("omit", C.c_uint8 * 32), ("pad_", C.c_uint8 * 4),
+                ("objects", (C.c_double * 4) * 32), ("box_velocity", (C.c_double * 2) * 32)]
+
+
+class Tracker:
+    """sd_tracker: System::TrackStereo / TrackRGBD / TrackMonocular for n_lanes independent camera streams, one frame per lane per call
+    (Tracking::GrabImage* -> Frame::Frame -> Track_new's dynamic block -> match vs mLastFrame -> q_frame)."""
+
+    def __init__(self, extractor, cfg, sensor, n_lanes, channels=1, rgb_order=True, track_last=True):
+        p = TrackerParams()
+        p.sensor, p.width, p.height, p.channels, p.rgb_order = sensor, cfg["width"], cfg["height"], channels, int(bool(rgb_order))
+        p.n_lanes, p.track_last = n_lanes, int(bool(track_last))
+        cam = make_camera(cfg)
+        for k in ("fx", "fy", "cx", "cy", "mbf", "mb", "mnMinX", "mnMaxX", "mnMinY", "mnMaxY"):
+            setattr(p.cam, k, float(cam[k]))
+        for k, name in enumerate(("k1", "k2", "p1", "p2", "k3")):
+            p.dist[k] = float(cfg.get(name, 0.0))
+        p.fps, p.depth_map_factor, p.th_depth = float(cfg["fps"]), float(cfg.get("depth_map_factor", 1.0)), float(cfg.get("th_depth", 0.0))
+        self.params, self.ex, self.cfg, self.sensor, self.n_lanes = p, extractor, cfg, sensor, n_lanes
+        self.images_per_lane = 2 if sensor == SENSOR_STEREO else 1
+        self.h = C.c_void_p()
+        check(lib().sd_tracker_create(C.byref(self.h), extractor.h, C.byref(p)))
+        bh = C.c_void_p()
+        check(lib().sd_tracker_batch(self.h, C.byref(bh)))
+        self.batch = Batch(extractor, cfg["width"], cfg["height"], 0, handle=bh.value)
+        self.results = (LaneResult * n_lanes)()
+
+    def close(self):
+        if self.h:
+            self.batch.close()
+            lib().sd_tracker_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        check(lib().sd_tracker_reset(self.h))
+
+    def track(self, d_images, stride, image_pitch, timestamps, boxes=None, n_boxes=None, d_depth=0, depth_stride=0, depth_pitch=0,
+              Tcw=None, Twc=None, stream=None):
+        """boxes: (n_lanes, 32, 4) f64 with n_boxes (n_lanes,) int32 (-1 = the constructor without boxes), or a list of (k, 4) arrays / None per lane."""
+        S = self.n_lanes
+        ts = np.ascontiguousarray(timestamps, np.float64).reshape(S)
+        if boxes is not None and n_boxes is None:
+            bx = np.zeros((S, MAXB, 4), np.float64); nb = np.full(S, -1, np.int32)
+            for l in range(S):
+                if boxes[l] is not None:
+                    a = np.asarray(boxes[l], np.float64).reshape(-1, 4)
+                    nb[l] = len(a); bx[l, :len(a)] = a
+            boxes, n_boxes = bx, nb
+        bp = _p(np.ascontiguousarray(boxes, np.float64)) if boxes is not None else None
+        self._keep = (boxes, n_boxes)
+        np_ = _p(np.ascontiguousarray(n_boxes, np.int32)) if n_boxes is not None else None
+        tc = np.ascontiguousarray(Tcw, np.float32).reshape(S, 16) if Tcw is not None else None
+        tw = np.ascontiguousarray(Twc, np.float32).reshape(S, 16) if Twc is not None else None
+        check(lib().sd_tracker_track(self.h, C.c_void_p(d_images), stride, image_pitch, C.c_void_p(d_depth or 0), depth_stride, depth_pitch,
+                                     bp, np_, _p(ts), _p(tc) if tc is not None else None, _p(tw) if tw is not None else None,
+                                     C.cast(self.results, C.c_void_p), C.c_void_p(stream or 0)))
+        return self.results
 
 
 class RefQueue:

@@ -154,6 +154,49 @@ def boxes_for_frame(seq, t, cfg=KITTI_STEREO, n_boxes=3):
     return rows
 
 
+def paste_objects(img, rows, seq):
+    """Independently moving objects: every box but the first (which rides on the background) gets its own texture patch that moves
+    rigidly with the box, so the geometric cull has something to reject.  In place on a gray image; returns it."""
+    H, W = img.shape
+    for (b, cx, cy, w, h) in rows:
+        if b == 0:
+            continue
+        rng = np.random.Generator(np.random.PCG64(BASE_SEED + 77000 + 1000 * seq + int(b)))
+        bw, bh = int(w), int(h)
+        patch = np.full((bh, bw), 120, np.int16)
+        n_rect = max(12, bw * bh // 120)
+        xs = rng.integers(0, bw, n_rect); ys = rng.integers(0, bh, n_rect)
+        ws = rng.integers(3, 24, n_rect); hs = rng.integers(3, 18, n_rect); vs = rng.integers(20, 236, n_rect)
+        for x, y, ww, hh, v in zip(xs, ys, ws, hs, vs):
+            patch[y:y + hh, x:x + ww] = v
+        patch = np.clip(patch + rng.integers(-3, 4, patch.shape), 0, 255).astype(np.uint8)
+        x0 = int(np.floor(cx - w / 2)); y0 = int(np.floor(cy - h / 2))
+        xa, ya = max(x0, 0), max(y0, 0)
+        xb, yb = min(x0 + bw, W), min(y0 + bh, H)
+        if xb > xa and yb > ya:
+            img[ya:yb, xa:xb] = patch[ya - y0:yb - y0, xa - x0:xb - x0]
+    return img
+
+
+def stereo_frame_dyn(seq=0, t=0, cfg=KITTI_STEREO, n_boxes=3):
+    """stereo_frame with the moving objects of boxes_for_frame pasted into the left image before the disparity warp."""
+    left, _, ts = stereo_frame(seq, t, cfg)
+    left = paste_objects(left.copy(), boxes_for_frame(seq, t, cfg, n_boxes), seq)
+    return left, warp_right(left, disparity_map(cfg["width"], cfg["height"], seq)), ts
+
+
+def rgbd_frame_dyn(seq=0, t=0, cfg=KITTI03_RGBD, n_boxes=3):
+    """rgbd_frame with the moving objects pasted into all three channels (the per-channel offsets are kept)."""
+    rgb, depth, ts = rgbd_frame(seq, t, cfg)
+    gray = paste_objects(rgb[:, :, 1].copy(), boxes_for_frame(seq, t, cfg, n_boxes), seq)
+    changed = gray != rgb[:, :, 1]
+    out = rgb.copy()
+    for c in range(3):
+        ch = out[:, :, c]
+        ch[changed] = gray[changed]
+    return out, depth, ts
+
+
 def rows_to_rects(rows):
     """rgbd_my.cc:246-249: Rect2d(max(cx-w/2,0), max(cy-h/2,0), w, h) as (x, y, w, h) float64."""
     return np.array([[max(cx - w / 2, 0.0), max(cy - h / 2, 0.0), w, h] for (_, cx, cy, w, h) in rows], np.float64)

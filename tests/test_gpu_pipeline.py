@@ -1,0 +1,195 @@
+"""GPU parity of the WHOLE per-frame chain against the frame-level oracle (oracle/pipeline.py), frame by frame and bit for bit:
+Tracking::GrabImage* -> Frame::Frame -> boxTrack -> firstSeparate -> TrackHomo (SearchByProjection, th / 2*th retry, H / F fit) ->
+Separate -> UpdateFrame -> grid -> match vs mLastFrame -> q_frame, through the Frame-level C ABI (sd_tracker_track).
+
+  test_stereo_chain_kitti    BASELINE configs[2]: KITTI stereo 1241x376, 2000 features, boxes per frame (detector output), cull
+  test_rgbd_chain_tum3       BASELINE configs[3]: TUM3 640x480 RGB-D, DepthMapFactor 5000, 30 fps, mask + boxes
+  test_mono_chain_tum3       BASELINE configs[0]'s constructor (Frame.cc:406-461) through the same boundary
+Lanes are chosen to hit every branch of Track_new's loop (Tracking.cc:620-666): frames without boxes in the queue, the constructor
+without boxes, a reference frame that cannot be matched (flag 0 -> pop -> next candidate -> extra round), H and F outcomes.
+"""
+import numpy as np
+import pytest
+
+import __graft_entry__ as graft
+
+pytestmark = pytest.mark.gpu
+
+
+def _pipe():
+    import importlib.util, os, sys
+    if "sd_oracle_pipeline" in sys.modules:
+        return sys.modules["sd_oracle_pipeline"]
+    spec = importlib.util.spec_from_file_location("sd_oracle_pipeline", os.path.join(graft.ROOT, "oracle", "pipeline.py"))
+    m = importlib.util.module_from_spec(spec); sys.modules["sd_oracle_pipeline"] = m; spec.loader.exec_module(m)
+    return m
+
+
+def _u32(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _check_frame(fe, trk, lane, R, F, tag):
+    """R: sd_lane_result of the lane, F: oracle FrameState."""
+    b = trk.batch
+    S = trk.n_lanes
+    slot = R.cur_slot
+    assert R.frame_id == F.mnId, tag
+    assert (R.N, R.N_s, R.N_d) == (F.N, F.N_s, F.N_d), "%s: N %r vs %r" % (tag, (R.N, R.N_s, R.N_d), (F.N, F.N_s, F.N_d))
+    nb = len(F.objects)
+    assert R.n_boxes == nb, "%s: boxes %d vs %d" % (tag, R.n_boxes, nb)
+    assert np.array_equal(np.array(R.box_idx[:nb]), F.box_idx) and np.array_equal(np.array(R.box_status[:nb]), F.box_status), \
+        "%s: box_idx/status %r %r vs %r %r" % (tag, R.box_idx[:nb], R.box_status[:nb], F.box_idx, F.box_status)
+    assert np.array_equal(np.array([list(o) for o in R.objects[:nb]], np.float64).reshape(nb, 4), F.objects.reshape(nb, 4)), tag + ": objects"
+    assert np.array_equal(np.array(R.omit[:nb], np.uint8), F.omit[:nb]), tag + ": omit"
+    assert np.array_equal(np.array([list(v) for v in R.box_velocity[:nb]], np.float64).reshape(nb, 2), F.velocity.reshape(nb, 2)), tag + ": velocity"
+    # Frame members
+    kp, desc, _ = b.download(slot)
+    assert kp.tobytes() == F.kp.tobytes(), tag + ": mvKeys"
+    assert np.array_equal(desc, F.desc), tag + ": mDescriptors"
+    ur, dep = b.download_rgbd(slot)
+    assert np.array_equal(_u32(ur[:F.N]), _u32(F.ur)) and np.array_equal(_u32(dep[:F.N]), _u32(F.dep)), tag + ": mvuRight / mvDepth"
+    g = b.download_boxes(slot)
+    assert g["n_static"] + 0 == F.N_s or F.appended is not None, tag
+    assert np.array_equal(g["boxStart"], F.boxStart) and np.array_equal(g["boxItems"], F.boxItems), tag + ": per-box lists"
+    dk, dd, dur, ddep = b.download_dynamic(slot)
+    assert dk.tobytes() == F.dyn_kp.tobytes() and np.array_equal(dd, F.dyn_desc), tag + ": mvdynKeys / mdynDescriptors"
+    assert np.array_equal(_u32(dur), _u32(F.dyn_ur)) and np.array_equal(_u32(ddep), _u32(F.dyn_dep)), tag + ": mvudynRight / mvdynDepth"
+    assert np.array_equal(b.download_grid(slot)[:F.N].astype(np.int32), F.cells), tag + ": grid"
+    xw, fl = b.download_mappoints(slot)
+    assert np.array_equal(fl[:F.N], F.mp_flags) and np.array_equal(_u32(xw[:F.N]), _u32(F.xw)), tag + ": map points"
+    # Track_new's dynamic block
+    assert R.ref_frame_id == F.ref_id, "%s: reference frame %d vs %d" % (tag, R.ref_frame_id, F.ref_id)
+    assert R.track_flag == F.track_flag, "%s: TrackHomo flag %d vs %d" % (tag, R.track_flag, F.track_flag)
+    if F.pairs is not None:                                   # TrackHomo's matcher ran
+        assert R.n_track_matches == F.n_track_matches, "%s: nmatches %d vs %d" % (tag, R.n_track_matches, F.n_track_matches)
+        _, pairs, nm = b.download_matches(lane)
+        assert nm == F.n_track_matches and np.array_equal(pairs, F.pairs), tag + ": points_last / points_current"
+    if F.motion is not None:
+        mo = b.download_motion(lane)
+        om = F.motion
+        assert (mo["flag"], mo["n_h"], mo["n_f"]) == (om["flag"], om["n_h"], om["n_f"]), tag + ": H / F inliers"
+        assert (R.n_h, R.n_f) == (om["n_h"], om["n_f"])
+        assert np.array_equal(mo["mask_h"], om["mask_h"]) and np.array_equal(mo["mask_f"], om["mask_f"]), tag + ": inlier masks"
+        for k in ("H", "F"):
+            sc = max(1.0, float(np.abs(om[k]).max()))
+            assert np.abs(mo[k] - om[k]).max() <= 1e-9 * sc, tag + ": " + k
+        assert np.array_equal(_u32(mo["HorF"]), _u32(om["HorF"])), tag + ": HorF (f32) must be identical for classifyH / classifyF"
+    if F.separate_ret is not None:
+        assert R.separate_ret == F.separate_ret, "%s: Separate %d vs %d" % (tag, R.separate_ret, F.separate_ret)
+        ret, ds, dyn, mt = b.download_separate(lane)
+        assert ret == F.separate_ret and np.array_equal(ds[:nb + 1], F.dynStart) and np.array_equal(dyn, F.dynStatus) and np.array_equal(mt, F.sep_matches), \
+            tag + ": dynStatus"
+    else:
+        assert R.separate_ret == 0
+    if F.last_match is not None:
+        assert R.n_last_matches == F.n_last_matches, "%s: matches vs mLastFrame %d vs %d" % (tag, R.n_last_matches, F.n_last_matches)
+        m, _, nm = b.download_matches(S + lane)
+        assert nm == F.n_last_matches and np.array_equal(m[:F.N], F.last_match), tag + ": mvpMapPoints after SearchByProjection(cur, last)"
+
+
+def _run_chain(fe, orc, synth, cfg, sensor, lanes, n_frames, channels):
+    """lanes: list of dict(frames=callable t -> (im, im2), boxes=callable t -> (k,4) array or None, stamps=list)."""
+    import torch
+    P = _pipe()
+    S = len(lanes)
+    W, H = cfg["width"], cfg["height"]
+    ex = fe.ORBextractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+    trk = fe.Tracker(ex, cfg, sensor, S, channels=channels, rgb_order=True, track_last=True)
+    oracles = [P.SequenceOracle(orc, cfg, sensor, rgb_order=True, track_last=True) for _ in lanes]
+    stats = dict(flag1=0, flag2=0, flag0=0, static=0, dynamic=0, status2=0, appended=0, refs=[])
+    try:
+        for t in range(n_frames):
+            ims = [ln["frames"](t) for ln in lanes]
+            bxs = [ln["boxes"](t) for ln in lanes]
+            ts = [ln["stamps"][t] for ln in lanes]
+            d_depth = None
+            if sensor == fe.SENSOR_STEREO:
+                d_img = torch.from_numpy(np.stack([np.stack([a, c]) for a, c in ims])).cuda()
+                ipl = 2
+            else:
+                d_img = torch.from_numpy(np.stack([a for a, _ in ims])).cuda()
+                ipl = 1
+                if sensor == fe.SENSOR_RGBD:
+                    d_depth = torch.from_numpy(np.stack([c for _, c in ims]).view(np.int16)).cuda()
+            res = trk.track(d_img.data_ptr(), W * channels, W * H * channels, ts, boxes=bxs if sensor != fe.SENSOR_MONOCULAR else None,
+                            d_depth=d_depth.data_ptr() if d_depth is not None else 0, depth_stride=W, depth_pitch=W * H)
+            for l, ln in enumerate(lanes):
+                F = oracles[l].track(ims[l][0], ims[l][1], bxs[l], ts[l])
+                _check_frame(fe, trk, l, res[l], F, "frame %d lane %d" % (t, l))
+                stats["flag%d" % F.track_flag] += 1 if F.ref_id >= 0 else 0
+                if F.ref_id >= 0: stats["refs"].append((t, l, F.ref_id))
+                if F.separate_ret == 1: stats["static"] += 1
+                if F.separate_ret == 0: stats["dynamic"] += 1
+                stats["status2"] += int((F.box_status == 2).sum())
+                stats["appended"] += 0 if F.appended is None else len(F.appended)
+    finally:
+        trk.close()
+    return stats
+
+
+def test_stereo_chain_kitti(gpu, fe, orc, synth):
+    """BASELINE configs[2]: 7 consecutive synthetic KITTI stereo frames x 3 lanes."""
+    cfg = synth.KITTI_STEREO
+    T = 7
+    stamps = [0.1 * t for t in range(T)]
+
+    def lane(seq, boxes):
+        return dict(frames=lambda t: synth.stereo_frame_dyn(seq, t, cfg)[:2], boxes=boxes, stamps=stamps)
+
+    rect = lambda seq, t: synth.rows_to_rects(synth.boxes_for_frame(seq, t, cfg))
+    lanes = [
+        lane(21, lambda t: rect(21, t)),                                                   # boxes in every frame
+        lane(22, lambda t: np.zeros((0, 4)) if t in (1, 2) else rect(22, t)),              # the detector finds nothing in frames 1, 2
+        lane(23, lambda t: None),                                                          # Frame(imLeft, imRight, ...) without boxes
+    ]
+    st = _run_chain(fe, orc, synth, cfg, fe.SENSOR_STEREO, lanes, T, channels=1)
+    assert st["flag1"] + st["flag2"] >= 5, "TrackHomo must succeed on the static-background lanes: %r" % st
+    assert st["static"] >= 3 and st["appended"] > 0, "Separate must re-admit static boxes somewhere: %r" % st
+
+
+def _sparse_rgbd(synth, cfg, k):
+    """A nearly featureless frame: three rectangles on a flat background, all inside one box (so the frame has `objects`, but far
+    too few map points for TrackHomo's 20 matches)."""
+    W, H = cfg["width"], cfg["height"]
+    g = np.full((H, W), 128, np.uint8)
+    for j, (x, y) in enumerate(((200, 150), (260, 210), (330, 170))):
+        g[y + 3 * k:y + 3 * k + 30, x:x + 40] = 40 + 60 * j
+    rgb = np.stack([g, g, g], -1)
+    depth = synth.rgbd_frame(34, 0, cfg)[1]
+    return rgb, depth, np.array([[150.0, 100.0, 300.0, 200.0]])
+
+
+def test_rgbd_chain_tum3(gpu, fe, orc, synth):
+    """BASELINE configs[3]: TUM3 640x480 RGB-D (DepthMapFactor 5000, 30 fps), mask + boxes; lane 1 starts with three nearly
+    featureless frames and has a gap in its time stamps, so that Track_new's loop rejects two reference frames (flag 0 -> pop)
+    before it finds one it can match: the extra rounds of the tracker."""
+    cfg = synth.TUM3
+    T = 10
+    st0 = [t / 30.0 for t in range(T)]
+    st1 = [0.05 * t for t in range(6)] + [0.4 + 0.05 * (t - 6) for t in range(6, T)]
+
+    def frames(seq):
+        def f(t):
+            rgb, depth, _ = synth.rgbd_frame_dyn(seq, t, cfg)
+            return rgb, depth
+        return f
+
+    rect = lambda seq, t: synth.rows_to_rects(synth.boxes_for_frame(seq, t, cfg))
+    f32 = frames(32)
+    lanes = [
+        dict(frames=frames(31), boxes=lambda t: rect(31, t), stamps=st0),
+        dict(frames=lambda t: _sparse_rgbd(synth, cfg, t)[:2] if t < 3 else f32(t),
+             boxes=lambda t: _sparse_rgbd(synth, cfg, t)[2] if t < 3 else rect(32, t), stamps=st1),
+    ]
+    st = _run_chain(fe, orc, synth, cfg, fe.SENSOR_RGBD, lanes, T, channels=3)
+    assert st["flag0"] >= 1 and (5, 1, 0) in st["refs"], "lane 1 must see TrackHomo fail on a featureless frame: %r" % st
+    assert (6, 1, 3) in st["refs"], "frame 6 of lane 1 must reject frames 1 and 2 and settle on frame 3 (two extra rounds): %r" % st
+    assert st["flag1"] + st["flag2"] >= 4, "%r" % st
+
+
+def test_mono_chain_tum3(gpu, fe, orc, synth):
+    cfg = dict(synth.TUM3)
+    T = 3
+    lanes = [dict(frames=lambda t: (synth.rgbd_frame(33, t, cfg)[0], None), boxes=lambda t: None, stamps=[t / 30.0 for t in range(T)])]
+    _run_chain(fe, orc, synth, cfg, fe.SENSOR_MONOCULAR, lanes, T, channels=3)
