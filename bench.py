@@ -1,31 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py — tracking front-end frames/s (extract + match [+ dynamic cull]) on MI355X.
+"""bench.py -- tracking front-end frames/s (extract + match + dynamic cull) on MI355X, through the Frame-level C ABI (sd_tracker).
 
-One "step" = one pass of the hot path over one batch of synthetic frames that are already
-resident in HBM.  At N=1 the workload is BASELINE.json configs[1]:
-    KITTI-03 RGB-D 1241x376, 2000 features/frame, ORB extract + match, no semantic mask
-i.e. per frame (reference call stack SURVEY 3.2, 3-argument TrackRGBD):
-    cvtColor RGB->gray                      Tracking.cc:256-269
-    ORBextractor::operator()                ORBextractor.cc:1043-1105
-    depth scaling + ComputeStereoFromRGBD   Tracking.cc:271-272, Frame.cc:1051-1072
-    AssignFeaturesToGrid                    Frame.cc:463-478
-    UnprojectStereo of the frame's points   Frame.cc:1074-1088
-    SearchByProjection(cur, last, th=15)    ORBmatcher.cc:1485-1627 (th: Tracking.cc:990-994)
-    mLastFrame = Frame(mCurrentFrame)       (slot copy)
-`--workload stereo` runs BASELINE configs[2] without the detector: 2x extract + ComputeStereoMatches
-+ the same grid/unproject/projection match (th=7).
+One "step" = one frame of every lane (a lane = one independent camera stream; the cull's recurrence -- boxTrack, the
+reference frame 0.2-0.3 s back, box_status of the last frame -- runs along a lane, the batch runs across lanes).  Inputs
+are resident in HBM before the timed region.  Default workload = BASELINE.json configs[2], the configuration the metric is
+quoted on:
 
-Multi-GPU (driver launches one rank per GPU through torch.distributed.run): independent frames are
-sharded, every rank runs the same per-GPU batch (weak scaling), there is no data-path collective.
-Start-up: RCCL broadcast of the packed ORB vocabulary (synthetic k=10, L=6 tree, ~60 MB: sd_vocab) from rank 0; every rank adopts it.
-Per step: asynchronous gather (to rank 0) of the fixed-stride per-frame result records, overlapped with the next step.  value = frames of ALL ranks / max
-rank time.
+  stereo-yolo   KITTI stereo 1241x376 colour pairs, 2000 features: YOLOv3 @640x480 on the left image (own stream, one
+                step ahead) -> Segmentation_ boxes (device NMS) -> System::TrackStereo(imLeft, imRight, boxes, t) =
+                cvtColor x2 (fused) + ORB extract x2 + ComputeStereoMatches + boxTrack + firstSeparate + TrackHomo
+                (SearchByProjection vs the queued frame > 0.2 s back, H / F fit) + Separate + UpdateFrame + grid +
+                SearchByProjection vs mLastFrame + queue push
+  stereo        the same without detector and boxes (Frame.cc:66-126)
+  rgbd          BASELINE configs[1]: KITTI-03 RGB-D 1241x376, TrackRGBD(im, depth, t), no boxes / mask (Frame.cc:240-294)
+  rgbd-cull     RGB-D 1241x376 with 3 given boxes per frame (rgbd_my.cc's yolov5 box files): the cull without a detector
+  tum-mask      BASELINE configs[3]: TUM3 640x480 RGB-D, DepthMapFactor 5000, mask + boxes, cull + dense back-projection
+                of the unmasked pixels (pointcloudmapping.cc:59-103) -- the consumer of the semantic mask
+  kitti-batch   BASELINE configs[4]: 11 sequences x 256 stereo frames with boxes, WHOLE sequences assigned to ranks
+                (longest first); strong scaling
+The non-default single-GPU workloads are also run (short) by the default invocation and reported under "extra".
+
+Multi-GPU: one process per GPU.  `python bench.py --gpus N` without a torch.distributed environment starts the N ranks
+itself (child processes, before anything touches the GPU); under `python -m torch.distributed.run` it joins the given
+world.  Lanes are independent: no data-path collective.  Start-up: RCCL broadcast of the packed ORB vocabulary from rank 0.
+Per step: asynchronous gather (to rank 0) of the per-frame result records (N, N_s, keypoints, descriptors, uRight, depth,
+boxes / box_idx / box_status), overlapped with the next step.  value = frames of ALL ranks / max rank time.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -35,7 +41,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming)
+MFMA_PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3}   # dense peaks, MI355X_MICROARCH.md
+WORKLOADS = ["stereo-yolo", "stereo", "rgbd", "rgbd-cull", "tum-mask", "kitti-batch"]
 
 
 # --------------------------------------------------------------------------- host logic (also used by CPU tests)
@@ -55,21 +63,20 @@ def level_sizes(width, height, inv_scale):
     return [(int(np.rint(np.float32(width) * s)), int(np.rint(np.float32(height) * s))) for s in inv_scale]
 
 
-def algorithmic_bytes(width, height, inv_scale, n_features):
+def algorithmic_bytes(width, height, inv_scale, n_features, channels=1):
     """Compulsory HBM bytes per image and per kernel: each plane read/written once."""
     sizes = level_sizes(width, height, inv_scale)
     interior = [w * h for (w, h) in sizes]
     padded = [(w + 38) * (h + 38) for (w, h) in sizes]
     b = {
-        "k_pyr_level0": width * height + padded[0],
+        "k_pyr_level0": channels * width * height + padded[0],
         "k_pyr_level": sum(interior[:-1]) + sum(padded[1:]),
         "k_fast_cells": sum(interior),
         "k_blur": 2 * sum(interior),
         "k_orient": n_features * 749,
         "k_describe": n_features * 512 + n_features * 32,
-        "k_quadtree": 0,
     }
-    b["image_total"] = (width * height + sum(padded) + sum(interior[:-1]) + 3 * sum(interior) + n_features * 749 +
+    b["image_total"] = (channels * width * height + sum(padded) + sum(interior[:-1]) + 3 * sum(interior) + n_features * 749 +
                         n_features * 512 + n_features * 60)
     return b
 
@@ -93,13 +100,44 @@ def gather_records(dist, local, world):
     return out.view((world,) + tuple(local.shape))
 
 
+RECORD_FIELDS = ("count", "fb", "kp", "desc", "uright", "depth")      # N, boxes / box_status / N_s / N_d, kp, desc, uRight, depth
+
+
+def record_layout(cap, fb_bytes):
+    """Byte layout of one frame's result record (fixed stride): name -> (offset, bytes)."""
+    sizes = {"count": 4, "fb": fb_bytes, "kp": cap * 28, "desc": cap * 32, "uright": cap * 4, "depth": cap * 4}
+    off, out = 0, {}
+    for k in RECORD_FIELDS:
+        out[k] = (off, sizes[k]); off += (sizes[k] + 15) // 16 * 16
+    out["_stride"] = off
+    return out
+
+
+def decode_record(rec_u8, layout, cap):
+    """rec_u8: one frame's record (numpy uint8) -> dict(N, N_s, N_d, n_boxes, box_idx, box_status, kp, desc, uright, depth, readmitted)."""
+    def part(k):
+        o, n = layout[k]
+        return rec_u8[o:o + n]
+    N = int(part("count").view(np.int32)[0])
+    fb = part("fb")
+    head = fb[:16].view(np.int32)                     # SdFrameBoxes: nb, nAll, nOri, nDyn
+    nb, n_s = int(head[0]), int(head[2])
+    base = 16 + 32 * 4 * 8
+    box_idx = fb[base:base + 128].view(np.int32)[:nb].copy()
+    box_status = fb[base + 128:base + 256].view(np.int32)[:nb].copy()
+    kp = part("kp").view(np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")]))[:N]
+    readmitted = np.arange(N) >= n_s                 # dyn_mask of SURVEY 8e: keypoints UpdateFrame appended behind the static ones
+    return dict(N=N, N_s=n_s, N_d=int(head[3]), n_boxes=nb, box_idx=box_idx, box_status=box_status, kp=kp.copy(),
+                desc=part("desc").reshape(cap, 32)[:N].copy(), uright=part("uright").view(np.float32)[:N].copy(),
+                depth=part("depth").view(np.float32)[:N].copy(), readmitted=readmitted)
+
+
 class ResultGather:
     """Per-rank result gather to rank 0 (north star: "per-rank result gather"), overlapped with the next step.
 
-    The records (keypoints + descriptors, fixed stride) are first copied into a staging tensor on the compute
-    stream, then `dist.gather(..., dst=0, async_op=True)` moves them while the next step computes.  A gather to one
-    root uses the 7 direct xGMI links into rank 0 in parallel; an all_gather would move 7x the bytes into every
-    rank (57 GB/s per GPU at 59k frames/s) for no consumer."""
+    The records are first packed into a staging tensor on the compute stream, then `dist.gather(..., dst=0, async_op=True)`
+    moves them while the next step computes.  A gather to one root uses the 7 direct xGMI links into rank 0 in parallel; an
+    all_gather would move 7x the bytes into every rank for no consumer."""
 
     def __init__(self, dist, world, rank, nbytes, device):
         import torch
@@ -109,13 +147,17 @@ class ResultGather:
         self.work = None
 
     def submit(self, parts):
+        """parts: list of (dst_view_of_stage, src_tensor) pairs or plain tensors packed back to back."""
         if self.work is not None:
             self.work.wait()                     # previous gather must have drained the staging tensor
         off = 0
         for p in parts:
-            n = p.numel()
-            self.stage[off:off + n].copy_(p, non_blocking=True)
-            off += n
+            if isinstance(p, tuple):
+                p[0].copy_(p[1], non_blocking=True)
+            else:
+                n = p.numel()
+                self.stage[off:off + n].copy_(p, non_blocking=True)
+                off += n
         self.work = self.dist.gather(self.stage, gather_list=self.recv, dst=0, async_op=True)
 
     def finish(self):
@@ -124,98 +166,421 @@ class ResultGather:
             self.work = None
 
 
+def spawn_ranks(n, argv, script=None):
+    """`python bench.py --gpus N` outside torch.distributed: start N ranks as child processes (nothing in THIS process has
+    touched the GPU), pass rank 0's JSON line through, fail if any rank fails."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), SD_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+# --------------------------------------------------------------------------- synthetic inputs
+def colour_from_gray(gray, rng):
+    """3 unequal channels (so that cvtColor is exercised), as synth.rgbd_frame does."""
+    dr = rng.integers(-3, 4, gray.shape); db = rng.integers(-3, 4, gray.shape)
+    g = gray.astype(np.int16)
+    return np.stack([np.clip(g + dr, 0, 255), g, np.clip(g + db, 0, 255)], axis=-1).astype(np.uint8)
+
+
+def synth_timestep(synth, kind, cfg, seq, t, cut=120):
+    """One frame of one synthetic sequence (a sequence stays inside its texture canvas for ~128 frames: scene cut every `cut`).
+    -> dict(images (ipl, H, W, 3) u8, depth (H, W) u16 or None, boxes (k, 4) f64, mask (H, W) u8 or None, stamp)."""
+    s, tt = seq + 1000 * (t // cut), t % cut
+    rng = np.random.Generator(np.random.PCG64(7919 * seq + t))
+    stamp = t / float(cfg["fps"])
+    rows = synth.boxes_for_frame(s, tt, cfg)
+    if kind == "stereo":
+        left, right, _ = synth.stereo_frame_dyn(s, tt, cfg)
+        return dict(images=np.stack([colour_from_gray(left, rng), colour_from_gray(right, rng)]), depth=None,
+                    boxes=synth.rows_to_rects(rows), mask=None, stamp=stamp)
+    rgb, depth, _ = synth.rgbd_frame_dyn(s, tt, cfg)
+    return dict(images=rgb[None], depth=depth, boxes=synth.rows_to_rects(rows), mask=synth.mask_from_boxes(rows, cfg["width"], cfg["height"]), stamp=stamp)
+
+
 # --------------------------------------------------------------------------- CPU baseline (oracle; rank 0, N=1 only)
-def cpu_baseline(workload, cfg, n_frames, seq):
+def cpu_baseline(workload, cfg, kind, sensor, with_boxes, with_detector, pkg, budget_s=25.0):
+    """The frame-level oracle (oracle/pipeline.py) on the host: the reference's own threading (two extraction threads per stereo
+    frame, Frame.cc:87-90; everything else in the caller's thread), steady-clock per frame, 20 warm-up frames then as many
+    measured frames as fit the budget (>= 200 when they do), median and mean (stereo_kitti.cc:96-170).  The detector (torch fp32
+    on the host cores, the way cv::dnn runs it: DNN_TARGET_CPU) is timed on a few images and added per frame."""
+    import importlib.util
+    import torch
+    native = os.environ.get("SD_ORACLE_NATIVE", "1") != "0"
     orc = graft.load_oracle()
-    pkg = graft.load_package()
-    synth, fe = pkg.synth, pkg.frontend
-    cam10 = fe.camera_array(fe.make_camera(cfg))
-    I = np.eye(4, dtype=np.float32)
-    distinct = min(n_frames, 64)                 # generating a frame costs more than extracting it: cycle 64 distinct ones
-    pool = [synth.rgbd_frame(seq, t, cfg) if workload == "rgbd" else synth.stereo_frame(seq, t, cfg) for t in range(distinct)]
-    frames = [pool[t % distinct] for t in range(n_frames)]
-    th = 15.0 if workload == "rgbd" else 7.0
-    exL = orc.Extractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
-    exR = orc.Extractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
-    return _cpu_walk(orc, workload, cfg, frames, exL, exR, cam10, I, th)
+    flags = "-march=x86-64-v3"
+    if native:
+        try:
+            orc.use_native()
+            flags = "-march=native"
+        except Exception:
+            pass
+    spec = importlib.util.spec_from_file_location("sd_oracle_pipeline", os.path.join(ROOT, "oracle", "pipeline.py"))
+    P = importlib.util.module_from_spec(spec); spec.loader.exec_module(P)
+    synth = pkg.synth
+    o = P.SequenceOracle(orc, cfg, sensor, rgb_order=True, track_last=True, threads=2 if sensor == P.SENSOR_STEREO else 1)
+    warm, times = 20, []
+    pool = [synth_timestep(synth, kind, cfg, 900, t) for t in range(100)]        # generation is not timed
+    t_start = time.perf_counter()
+    k = 0
+    while True:
+        fr = pool[k % len(pool)] if k < len(pool) else synth_timestep(synth, kind, cfg, 900, k)
+        im0 = fr["images"][0]
+        im1 = fr["images"][1] if kind == "stereo" else fr["depth"]
+        t0 = time.perf_counter()
+        o.track(im0, im1, fr["boxes"] if with_boxes else None, fr["stamp"])
+        dt = time.perf_counter() - t0
+        if k >= warm:
+            times.append(dt)
+        k += 1
+        if len(times) >= 200 and time.perf_counter() - t_start > budget_s * 0.5:
+            break
+        if time.perf_counter() - t_start > budget_s and len(times) >= 30:
+            break
+    times.sort()
+    fe_median, fe_mean = times[len(times) // 2], sum(times) / len(times)
+    det_s, det_n, det_threads = 0.0, 0, 0
+    if with_detector:
+        yo = graft.load_yolo_oracle()
+        layers, anchors = pkg.yolo.v3_layers()
+        _, per = pkg.yolo.synth_weights(layers, seed=3)
+        det_threads = torch.get_num_threads()
+        blob = yo.blob_from_image(pool[0]["images"][0][:, :, ::-1], 640, 480, orc.resize_linear)
+        yo.torch_forward(layers, per, blob)                     # warm-up
+        t0 = time.perf_counter()
+        while det_n < 3 or (time.perf_counter() - t0 < 6.0 and det_n < 20):
+            yo.torch_forward(layers, per, blob); det_n += 1
+        det_s = (time.perf_counter() - t0) / det_n
+    per_frame = fe_mean + det_s
+    cores = max(2 if sensor == P.SENSOR_STEREO else 1, det_threads)
+    out = {"value": round(1.0 / per_frame, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": "%d warm-up + %d measured consecutive frames of one synthetic sequence of the same workload through the frame-level CPU oracle "
+                     "(oracle/pipeline.py over libsd_oracle, g++ -O3 %s), %d extraction thread(s) as the reference; front end median %.2f ms / mean %.2f ms"
+                     % (warm, len(times), flags, 2 if sensor == P.SENSOR_STEREO else 1, fe_median * 1e3, fe_mean * 1e3) +
+                     ("; detector = YOLOv3 torch-fp32 forward on %d host threads, %.0f ms / image over %d images, added per frame" % (det_threads, det_s * 1e3, det_n)
+                      if with_detector else "") + "; host has %d logical cores" % (os.cpu_count() or 0),
+           "front_end_ms": {"median": round(fe_median * 1e3, 3), "mean": round(fe_mean * 1e3, 3), "frames": len(times)},
+           "detector_ms": round(det_s * 1e3, 2) if with_detector else None}
+    return out
 
 
-def _cpu_walk(orc, workload, cfg, frames, exL, exR, cam10, I, th):
-    last = None
-    n_frames = len(frames)
-    t0 = time.perf_counter()
-    for fr in frames:
-        if workload == "rgbd":
-            rgb, depth, _ = fr
-            gray = orc.cvt_gray(rgb, 1)
-            kp, desc = exL(gray)
-            dep32 = orc.depth_to_f32(depth, float(np.float32(1.0) / np.float32(cfg["depth_map_factor"])))
-            ur, dep = orc.stereo_from_rgbd(kp, dep32, cfg["bf"])
-        else:
-            l, r, _ = fr
-            kp, desc = exL(l)
-            kpR, descR = exR(r)
-            ur, dep, _, _ = orc.stereo_matches(exL, exR, kp, desc, kpR, descR, cfg["bf"], cfg["fx"])
-        xw, valid = orc.unproject(kp, dep, cam10, I)
-        if last is not None:
-            orc.search_by_projection(kp, desc, ur, last[0], last[1], last[2], last[3], I, I, cam10, exL.scale, th)
-        else:
-            orc.grid_cells(kp, cam10)
-        last = (kp, desc, xw, valid)
-    dt = time.perf_counter() - t0
-    return n_frames / dt, dt
-
-
-def cpu_baseline_all_cores(workload, cfg, seq, threads, frames_per_thread=48):
-    """The same walk on `threads` host threads at once, one independent frame stream per thread ("an all-cores run,
-    one frame per core"); the oracle's C calls release the GIL.  Reported beside the single-stream figure, never instead of it."""
+def cpu_all_cores(cfg, kind, sensor, with_boxes, pkg, threads, frames_per_thread=6):
+    """`threads` independent camera streams at once, one per host thread (the oracle's C calls release the GIL): an all-cores
+    figure for the front end only, reported beside the single-stream baseline, never instead of it."""
+    import importlib.util
     import threading
     orc = graft.load_oracle()
-    pkg = graft.load_package()
-    synth, fe = pkg.synth, pkg.frontend
-    cam10 = fe.camera_array(fe.make_camera(cfg))
-    I = np.eye(4, dtype=np.float32)
-    pool = [synth.rgbd_frame(seq, t, cfg) if workload == "rgbd" else synth.stereo_frame(seq, t, cfg) for t in range(16)]
-    th = 15.0 if workload == "rgbd" else 7.0
-    mk = lambda: orc.Extractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
-    ex = [(mk(), mk()) for _ in range(threads)]
+    spec = importlib.util.spec_from_file_location("sd_oracle_pipeline", os.path.join(ROOT, "oracle", "pipeline.py"))
+    P = importlib.util.module_from_spec(spec); spec.loader.exec_module(P)
+    pool = [synth_timestep(pkg.synth, kind, cfg, 901, t) for t in range(frames_per_thread)]
+    os_ = [P.SequenceOracle(orc, cfg, sensor, track_last=True, threads=1) for _ in range(threads)]
+
     def work(k):
-        frames = [pool[(k + t) % len(pool)] for t in range(frames_per_thread)]
-        _cpu_walk(orc, workload, cfg, frames, ex[k][0], ex[k][1], cam10, I, th)
+        for fr in pool:
+            os_[k].track(fr["images"][0], fr["images"][1] if kind == "stereo" else fr["depth"], fr["boxes"] if with_boxes else None, fr["stamp"])
     ts = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
     t0 = time.perf_counter()
     for t in ts: t.start()
     for t in ts: t.join()
     dt = time.perf_counter() - t0
-    return threads * frames_per_thread / dt, dt
+    return {"value": round(threads * frames_per_thread / dt, 2), "unit": "frames/s", "threads": threads,
+            "sample": "front end only: %d independent streams x %d consecutive frames, one stream per thread, %.1f s" % (threads, frames_per_thread, dt)}
 
 
-# --------------------------------------------------------------------------- main
+# --------------------------------------------------------------------------- one workload on this rank
+class Workload:
+    def __init__(self, name, args, rank, world, dev, pkg, dist):
+        import torch
+        self.torch = torch
+        fe, synth = pkg.frontend, pkg.synth
+        self.fe, self.synth, self.pkg, self.name, self.dev, self.dist, self.rank, self.world = fe, synth, pkg, name, dev, dist, rank, world
+        self.detector = name in ("stereo-yolo",)
+        self.with_boxes = name in ("stereo-yolo", "rgbd-cull", "tum-mask", "kitti-batch")
+        self.kind = "stereo" if name in ("stereo-yolo", "stereo", "kitti-batch") else "rgbd"
+        self.cfg = synth.TUM3 if name == "tum-mask" else (synth.KITTI_STEREO if self.kind == "stereo" else synth.KITTI03_RGBD)
+        self.sensor = fe.SENSOR_STEREO if self.kind == "stereo" else fe.SENSOR_RGBD
+        self.ipl = 2 if self.kind == "stereo" else 1
+        cfg = self.cfg
+        self.W, self.H = cfg["width"], cfg["height"]
+        self.strong = name == "kitti-batch"
+        if self.strong:                              # BASELINE configs[4]: 11 sequences x 256 frames, whole sequences per rank
+            n_seq, length = 11, args.kitti_frames
+            owner = shard_sequences(n_seq, [length] * n_seq, world)
+            self.my_sequences = [s for s in range(n_seq) if owner[s] == rank]
+            self.idle = len(self.my_sequences) == 0
+            # every rank runs the same number of lanes (the gathered records have one size): a rank with fewer sequences repeats one, uncounted
+            self.S = max(sum(1 for s in range(n_seq) if owner[s] == r) for r in range(world))
+            while len(self.my_sequences) < self.S:
+                self.my_sequences.append(self.my_sequences[-1] if self.my_sequences else 0)
+            self.total_frames_all_ranks = n_seq * length
+            self.T = length
+            self.distinct = self.S
+        else:
+            self.S = args.lanes
+            self.my_sequences = list(range(self.S))
+            self.idle = False
+            self.distinct = min(args.distinct, self.S)
+        self.ex = fe.ORBextractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+        self.trk = fe.Tracker(self.ex, cfg, self.sensor, self.S, channels=3, rgb_order=True, track_last=True)
+        self.batch = self.trk.batch
+        self.main = torch.cuda.current_stream()
+        self.det = None
+        if self.detector:
+            layers, anchors = pkg.yolo.v3_layers()
+            self.det = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=self.S)
+            self.det.load_weights(pkg.yolo.synth_weights(layers, seed=3)[0])
+            self.det_stream = torch.cuda.Stream(device=dev)
+            self.det_in_flight = -1
+            self.lookahead = True             # the next frame's forward pass is launched before this frame's front end
+        self.frames = []          # per timestep: dict(images, depth, boxes, n_boxes, stamps)
+        self.t = 0
+        self.n_boxes_seen = []
+
+    def prepare(self, n_steps):
+        """Generate `n_steps` more time steps and park them in HBM (distinct sequences on the host, replicated to the lanes on the device)."""
+        torch, synth, cfg = self.torch, self.synth, self.cfg
+        S, D = self.S, self.distinct
+        reps = (S + D - 1) // D
+        base = len(self.frames)
+        for t in range(base, base + n_steps):
+            per = [synth_timestep(synth, self.kind, cfg, (10 + self.my_sequences[d]) if self.strong else (10 + 37 * self.rank + d), t) for d in range(D)]
+            img = torch.from_numpy(np.stack([p["images"] for p in per])).to(self.dev)                  # [D, ipl, H, W, 3]
+            img = img.repeat((reps, 1, 1, 1, 1))[:S].contiguous()
+            dep = None
+            if self.kind == "rgbd":
+                dep = torch.from_numpy(np.stack([p["depth"] for p in per]).view(np.int16)).to(self.dev).repeat((reps, 1, 1))[:S].contiguous()
+            bx = np.zeros((S, 32, 4), np.float64); nb = np.full(S, -1, np.int32)
+            if self.with_boxes and not self.detector:
+                for l in range(S):
+                    b = per[l % D]["boxes"]; nb[l] = len(b); bx[l, :len(b)] = b
+            self.frames.append(dict(images=img, depth=dep, boxes=bx, n_boxes=nb, stamps=np.full(S, per[0]["stamp"], np.float64)))
+
+    def step(self):
+        fe, torch = self.fe, self.torch
+        fr = self.frames[self.t]
+        W, H, S = self.W, self.H, self.S
+        boxes, n_boxes = (fr["boxes"], fr["n_boxes"]) if self.with_boxes else (None, None)
+        if self.det is not None:
+            ds = self.det_stream.cuda_stream
+            pitch = self.ipl * W * H * 3
+            if self.det_in_flight != self.t:      # first step: nothing was launched ahead
+                self.det.forward_device(fr["images"].data_ptr(), W, H, W * 3, pitch, S, 0.5, ds)       # yolo->Segmentation_(imLeft), stereo_kitti.cc:107
+            dets = self.det.boxes_batch(S, W, H, stream=ds)                                          # one synchronisation (detector stream)
+            if self.lookahead and self.t + 1 < len(self.frames):     # the next frame's forward pass overlaps with this frame's front end
+                self.det.forward_device(self.frames[self.t + 1]["images"].data_ptr(), W, H, W * 3, pitch, S, 0.5, ds)
+                self.det_in_flight = self.t + 1
+            boxes = np.zeros((S, 32, 4), np.float64); n_boxes = np.zeros(S, np.int32)
+            for l in range(S):
+                b = dets[l][0][:16]               # boxTrack may re-inject as many again: keep within SD_MAX_BOXES
+                n_boxes[l] = len(b); boxes[l, :len(b)] = b
+        res = self.trk.track(fr["images"].data_ptr(), W * 3, W * H * 3, fr["stamps"], boxes=boxes, n_boxes=n_boxes,
+                             d_depth=fr["depth"].data_ptr() if fr["depth"] is not None else 0, depth_stride=W, depth_pitch=W * H,
+                             stream=self.main.cuda_stream)
+        self.t += 1
+        return res
+
+    def close(self):
+        self.trk.close()
+        if self.det is not None:
+            self.det.close()
+
+
+def run_workload(name, args, rank, world, dev, pkg, dist, headline):
+    """-> dict with the measured figures of one workload (rank 0 fills everything, other ranks only take part)."""
+    import torch
+    fe = pkg.frontend
+    wl = Workload(name, args, rank, world, dev, pkg, dist)
+    steps, warm = (args.steps, args.warmup) if headline else (args.extra_steps, 1)
+    prof_steps = 3 if (headline and not args.no_profile) else 0
+    if wl.strong:
+        steps, warm, prof_steps = wl.T - 1, 0, 0
+    wl.prepare(1 + warm + steps + prof_steps + 1)
+    batch = wl.batch
+    cap = batch.cap
+    gatherer, rec_parts, layout = None, None, None
+    if dist is not None:
+        import ctypes as C
+        kp_p, desc_p, cnt_p, _ = batch.results_device()
+        ur_p, dep_p = C.c_void_p(), C.c_void_p(); cc = C.c_int()
+        fe.check(fe.lib().sd_batch_stereo_device(batch.h, C.byref(ur_p), C.byref(dep_p), C.byref(cc)))
+        fb_bytes = fe.FRAME_BOXES_BYTES
+        fb_p = fe.batch_boxes_device(batch)
+        layout = record_layout(cap, fb_bytes)
+        stride = layout["_stride"]
+        S, ipl = wl.S, wl.ipl
+        gatherer = ResultGather(dist, world, rank, S * stride, dev)
+        stage2d = gatherer.stage.view(S, stride)
+        srcs = {"count": (cnt_p, 4), "fb": (fb_p, fb_bytes), "kp": (kp_p, cap * 28), "desc": (desc_p, cap * 32), "uright": (ur_p.value, cap * 4), "depth": (dep_p.value, cap * 4)}
+        rec_parts = []
+        for k in RECORD_FIELDS:
+            ptr, nbytes = srcs[k]
+            src = fe.as_torch_u8(ptr, S * ipl * nbytes).view(S * ipl, nbytes)[::ipl]        # the lanes' current (left) slots
+            o, n = layout[k]
+            rec_parts.append((stage2d[:, o:o + n], src))
+
+    def one_step():
+        r = wl.step()
+        if gatherer is not None:
+            gatherer.submit(rec_parts)
+        return r
+
+    one_step()                               # priming: frame 0 of every lane (initialisation, untimed)
+    for _ in range(warm):
+        one_step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = one_step()
+    if gatherer is not None:
+        gatherer.finish()                    # the last step's gather is inside the timed region
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = max_over_ranks(dist, time.perf_counter() - t0, dev)
+
+    out = None
+    if rank == 0:
+        frames = wl.total_frames_all_ranks - 11 if wl.strong else world * wl.S * steps       # strong: frame 0 of every sequence is the priming step
+        value = frames / elapsed
+        R = res[0]
+        out = {"workload": name, "value": round(value, 2), "ms_per_step": round(elapsed / steps * 1e3, 4), "steps": steps, "frames": frames,
+               "timed_s": round(elapsed, 3), "lanes_per_gpu": wl.S, "images_per_frame": wl.ipl,
+               "lane0_last_frame": {"N": R.N, "N_s": R.N_s, "N_d": R.N_d, "n_boxes": R.n_boxes, "track_flag": R.track_flag, "separate_ret": R.separate_ret,
+                                    "n_track_matches": R.n_track_matches, "n_last_matches": R.n_last_matches}}
+        if gatherer is not None:               # rank 0 decodes a record it received from the LAST rank: the gather carries usable data
+            rec = gatherer.recv[world - 1].view(wl.S, layout["_stride"])[0].cpu().numpy()
+            d = decode_record(rec, layout, cap)
+            out["gathered_record_check"] = {"from_rank": world - 1, "N": d["N"], "N_s": d["N_s"], "n_boxes": d["n_boxes"],
+                                            "bytes_per_frame": layout["_stride"], "finite_depths": int(np.isfinite(d["depth"]).sum())}
+    # ---- separate, untimed pass: per-kernel durations (hipEvents on the kernels' own stream) for the roofline
+    if prof_steps:
+        batch.set_profiling(True); batch.reset_kernel_times()
+        det_ms = None
+        if wl.det is not None:                 # the detector alone, nothing else on the GPU: the MFMA block
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(wl.det_stream):
+                fr = wl.frames[wl.t]
+                wl.det.forward_device(fr["images"].data_ptr(), wl.W, wl.H, wl.W * 3, wl.ipl * wl.W * wl.H * 3, wl.S, 0.5, wl.det_stream.cuda_stream)
+                wl.det_stream.synchronize()
+                e0.record(wl.det_stream)
+                for _ in range(3):
+                    wl.det.forward_device(fr["images"].data_ptr(), wl.W, wl.H, wl.W * 3, wl.ipl * wl.W * wl.H * 3, wl.S, 0.5, wl.det_stream.cuda_stream)
+                e1.record(wl.det_stream)
+                wl.det_stream.synchronize()
+            det_ms = e0.elapsed_time(e1) / 3
+            wl.det_in_flight = -1
+            wl.lookahead = False               # the front-end kernels of the profiled steps run alone
+        for _ in range(prof_steps):
+            if wl.det is not None:
+                wl.det_stream.synchronize()
+            wl.step()
+            torch.cuda.synchronize()           # front-end kernels of a step run alone (the next detector pass is held back by the sync above)
+        batch.sync()
+        kt = batch.kernel_times()
+        batch.set_profiling(False)
+        if rank == 0:
+            cfg = wl.cfg
+            alg = algorithmic_bytes(wl.W, wl.H, wl.ex.mvInvScaleFactor, cfg["n_features"], channels=3)
+            n_img = wl.S * wl.ipl
+            hbm = {k: v for k, v in kt.items() if v[1] > 0 and alg.get(k, 0) > 0}
+            dom = max(hbm, key=lambda k: hbm[k][0])
+            ms, launches = hbm[dom]
+            per_step_launches = launches / prof_steps
+            per_launch = alg[dom] * n_img / per_step_launches
+            avg_ms = ms / launches
+            achieved = per_launch / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    e = json.load(open(pmc)).get(dom)
+                    if e and e.get("batch_images") == n_img:
+                        traffic = e.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            fe_ms = sum(v[0] for v in kt.values()) / prof_steps
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "algorithmic_bytes_per_launch": int(per_launch),
+                    "avg_launch_ms": round(avg_ms, 4), "images_per_launch": int(n_img / per_step_launches),
+                    "kernels_ms_per_step": {k: round(v[0] / prof_steps, 4) for k, v in kt.items() if v[1] > 0},
+                    "front_end_kernels_ms_per_step": round(fe_ms, 4),
+                    "front_end_algorithmic_GBs_while_running": round(alg["image_total"] * n_img / (fe_ms * 1e-3) / 1e9, 2),
+                    "pipeline_achieved_GBs": round(alg["image_total"] * wl.ipl * out["value"] / world / 1e9, 2),
+                    "measured": "separate untimed pass of %d steps with hipEvents around every kernel on its own stream" % prof_steps}
+            if det_ms is not None:
+                fl = wl.det.flops()
+                prec = pkg.yolo.detector_precision() if hasattr(pkg.yolo, "detector_precision") else "f16"
+                tf = fl * wl.S / (det_ms * 1e-3) / 1e12
+                roof["detector"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS[prec], "unit": "TFLOP/s",
+                                    "frac": round(tf / MFMA_PEAK_TFLOPS[prec], 4), "operands": prec, "images_per_s": round(wl.S / (det_ms * 1e-3), 1),
+                                    "gflop_per_image": round(fl / 1e9, 2), "ms_per_batch": round(det_ms, 3), "batch": wl.S,
+                                    "weights": "synthetic (yolov3.weights is a download that never was in the reference)"}
+            out["roofline"] = roof
+    wl.close()
+    return out, wl
+
+
+WORKLOAD_TEXT = {
+    "stereo-yolo": "KITTI stereo 1241x376 colour pairs, 2000 feat/image: YOLOv3 (640x480, synthetic weights) on the left image -> boxes -> TrackStereo = "
+                   "cvtColor + 2x ORB extract + stereo match + boxTrack + firstSeparate + TrackHomo (SearchByProjection vs the queued frame > 0.2 s back, H/F fit) + "
+                   "Separate + UpdateFrame + SearchByProjection vs the last frame (BASELINE configs[2])",
+    "stereo": "KITTI stereo 1241x376 colour pairs, 2000 feat/image: cvtColor + 2x ORB extract + stereo match + projection match vs the last frame, no detector / boxes",
+    "rgbd": "KITTI-03 RGB-D 1241x376, 2000 feat/frame: cvtColor + ORB extract + RGB-D stereo + projection match vs the last frame, no semantic mask (BASELINE configs[1])",
+    "rgbd-cull": "KITTI-03 RGB-D 1241x376, 2000 feat/frame, 3 given boxes per frame: extract + match + boxTrack + firstSeparate + TrackHomo + Separate + UpdateFrame",
+    "tum-mask": "TUM3 RGB-D 640x480, 1000 feat/frame, DepthMapFactor 5000, 30 fps, mask + 3 boxes per frame: extract + match + cull (BASELINE configs[3])",
+    "kitti-batch": "11 synthetic KITTI stereo sequences x %d frames with 3 boxes per frame, whole sequences per rank (BASELINE configs[4]); cull on, detector off",
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
-    ap.add_argument("--workload", choices=["rgbd", "stereo", "rgbd-cull", "rgbd-bow", "stereo-yolo"], default="rgbd")
-    ap.add_argument("--cpu-frames", type=int, default=320, help="frames of the bounded CPU-baseline sample (0 = skip)")
-    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="split the per-GPU batch over this many HIP streams (latency-bound kernels of one stream overlap "
-                         "with throughput-bound kernels of another)")
+    ap.add_argument("--lanes", "--batch", type=int, default=128, dest="lanes", help="independent camera streams per GPU = frames per step per GPU")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic sequences generated on the host (replicated over the lanes on the device)")
+    ap.add_argument("--workload", choices=WORKLOADS, default="stereo-yolo")
+    ap.add_argument("--extra", default="auto", help="comma-separated workloads also run (short) and reported under 'extra'; 'auto' = stereo,rgbd,rgbd-cull at N=1, none otherwise; 'none'")
+    ap.add_argument("--extra-steps", type=int, default=8)
+    ap.add_argument("--kitti-frames", type=int, default=256)
+    ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of host time for the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the separate per-kernel pass (no roofline block)")
     args = ap.parse_args()
 
-    import torch
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:                    # start the ranks ourselves, before anything touches the GPU
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    world = int(world_env or "1")
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+
+    import torch
     if os.environ.get("SD_BENCH_SINGLE_DEVICE"):     # rehearsal only: several ranks share cuda:0 (gloo backend)
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit("--gpus %d but only %d HIP devices are visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    rccl_ranks = 1
     if world > 1 or os.environ.get("SD_BENCH_FORCE_DIST"):     # FORCE_DIST: one-rank RCCL group, rehearses the collective calls on a 1-GPU box
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -226,63 +591,17 @@ def main():
         else:
             dist_mod.init_process_group(backend, rank=rank, world_size=world)
         dist = dist_mod
+        rccl_ranks = dist.get_world_size()
+        if rccl_ranks != args.gpus:
+            raise SystemExit("only %d of %d ranks joined" % (rccl_ranks, args.gpus))
 
     pkg = graft.load_package()
     fe, synth = pkg.frontend, pkg.synth
     if fe.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
 
-    B = args.batch
-    S = max(1, args.streams)
-    if B % S:
-        raise SystemExit("--batch must be a multiple of --streams")
-    Bs = B // S
-    cull = args.workload == "rgbd-cull"
-    bow = args.workload == "rgbd-bow"
-    yolo_wl = args.workload == "stereo-yolo"
-    if cull or bow:
-        args.workload = "rgbd"
-    if yolo_wl:
-        args.workload = "stereo"
-        if args.streams != 1:
-            raise SystemExit("--workload stereo-yolo runs on one stream")
-    if args.workload == "rgbd":
-        cfg = synth.KITTI03_RGBD
-        workload_name = "KITTI-03 RGB-D 1241x376, 2000 feat/frame, ORB extract+match, no semantic mask (BASELINE configs[1])"
-        if cull:
-            workload_name = ("RGB-D 1241x376, 2000 feat/frame, extract + match + dynamic cull with 3 given boxes/frame "
-                             "(firstSeparate, Separate vs the frame 0.2 s back, UpdateFrame); detector off (BASELINE configs[3] data path)")
-        if bow:
-            workload_name = ("RGB-D 1241x376, 2000 feat/frame, extract + projection match + Frame::ComputeBoW (k=10, L=6 vocabulary) + "
-                             "SearchByBoW against the previous frame (TrackReferenceKeyFrame's matcher)")
-        imgs_per_frame, th = 1, 15.0
-    else:
-        cfg = synth.KITTI_STEREO
-        workload_name = "KITTI stereo 1241x376, 2000 feat/frame, 2x ORB extract + stereo match + projection match, detector off (BASELINE configs[2] minus YOLOv3)"
-        if yolo_wl:
-            workload_name = ("KITTI stereo 1241x376, 2000 feat/frame: YOLOv3 (640x480, synthetic weights) on the left image -> boxes -> boxTrack -> "
-                             "2x ORB extract + stereo match + firstSeparate + TrackHomo (projection match vs the frame 0.2 s back, H/F fit) + "
-                             "Separate + UpdateFrame + projection match vs the last frame (BASELINE configs[2])")
-        imgs_per_frame, th = 2, 7.0
-    W, H = cfg["width"], cfg["height"]
-
-    # ---- synthetic inputs, resident in HBM before the timed region
-    seq = 10 + rank
-    if args.workload == "rgbd":
-        fr = [synth.rgbd_frame(seq + 100 * (t // 128), t % 128, cfg) for t in range(B)]      # a synthetic sequence is valid for ~128 frames (zoom 1.01^t)
-        d_rgb = torch.from_numpy(np.stack([f[0] for f in fr])).to(dev)
-        d_depth = torch.from_numpy(np.stack([f[1] for f in fr]).view(np.int16)).to(dev)
-        Wg = (W + 63) // 64 * 64                        # the gray plane is this pipeline's own intermediate: 64-byte aligned rows
-        d_gray = torch.empty((B, H, Wg), dtype=torch.uint8, device=dev)
-    else:
-        fr = [synth.stereo_frame(seq + 100 * (t // 128), t % 128, cfg) for t in range(B)]
-        Wg = W                                           # stereo inputs arrive as tight 8-bit images
-        d_gray = torch.from_numpy(np.stack([im for f in fr for im in (f[0], f[1])])).to(dev)
-    del fr
-
     # ---- start-up collective: the packed ORB vocabulary (synthetic k=10, L=6 tree in ORBvoc.txt's shape; the real file
-    # is a download that never was in the reference), rank 0 -> all over RCCL; every rank adopts the received buffer
-    # (sd_vocab_from_packed_device) and Frame::ComputeBoW / SearchByBoW read it from HBM.
+    # is a download that never was in the reference), rank 0 -> all over RCCL; every rank adopts the received buffer.
     voc_ms = None
     if rank == 0:
         voc0 = fe.Vocabulary.from_nodes(synth.vocabulary(k=10, L=6, seed=1234))
@@ -304,249 +623,54 @@ def main():
         vocab = voc0
     assert vocab.info()["n_nodes"] == int(n_nodes_t.item()) and vocab.info()["k"] == 10 and vocab.info()["L"] == 6
 
-    ex = fe.ORBextractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
-    n_img = Bs * imgs_per_frame                     # images per stream
-    cam = fe.make_camera(cfg)
-    main_stream = torch.cuda.current_stream()
-    streams = [main_stream] + [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
-    batches = [fe.Batch(ex, W, H, n_img + 1) for _ in range(S)]     # + 1 slot: mLastFrame carried across steps
-    batch = batches[0]
-    I = np.tile(np.eye(4, dtype=np.float32), (Bs, 1, 1))
-    cur_idx = np.arange(Bs, dtype=np.int32) * imgs_per_frame
-    last_idx = np.concatenate([[n_img], cur_idx[:-1]]).astype(np.int32)
-    depth_factor = float(np.float32(1.0) / np.float32(cfg.get("depth_map_factor", 1.0)))
-    cull_state = None
-    if cull:
-        # detector boxes per frame: precomputed (boxTrack is host code on a per-sequence recurrence; ids are stable here)
-        bl, il = [], []
-        for t in range(B):
-            rows = synth.boxes_for_frame(seq, t, cfg)
-            bl.append(synth.rows_to_rects(rows)); il.append(np.arange(len(rows), dtype=np.int32))
-        dt = 2                                                    # reference frame = 0.2 s older at 10 fps
-        sc = 1.01 ** dt
-        Hm = np.array([[sc, 0, (3.0 * dt - cfg["cx"]) * sc + cfg["cx"]], [0, sc, -cfg["cy"] * sc + cfg["cy"]], [0, 0, 1]], np.float32)
-        cull_state = []
-        for k in range(S):
-            f0 = k * Bs
-            packed = fe.Batch.pack_boxes(bl[f0:f0 + Bs], il[f0:f0 + Bs])
-            npair = Bs - dt
-            li = np.zeros((npair, fe.MAXB), np.int32); ls = np.full((npair, fe.MAXB), -1, np.int32); nl = np.full(npair, 3, np.int32)
-            li[:, :3] = np.arange(3)
-            cull_state.append(dict(packed=packed, slots=np.arange(Bs, dtype=np.int32), cur=np.arange(dt, Bs, dtype=np.int32),
-                                   ref=np.arange(0, Bs - dt, dtype=np.int32), H=np.tile(Hm.reshape(1, 9), (npair, 1)),
-                                   flag=np.ones(npair, np.int32), last=(li, ls, nl)))
-    det = None
-    if yolo_wl:
-        layers, anchors = pkg.yolo.v3_layers()
-        det = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=B)
-        det.load_weights(pkg.yolo.synth_weights(layers, seed=3)[0])
-        d_bgr = d_gray.view(B, 2, H, W)[:, 0].unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()      # the left image as 3 channels
-        yolo_state = dict(last=None, n_boxes=0, in_flight=False)
-        det_stream = torch.cuda.Stream(device=dev)
-    recs, gatherer = None, None
-    if dist is not None:
-        recs = []
-        for bt in batches:
-            kp_p, desc_p, cnt_p, cap = bt.results_device()
-            recs += [fe.as_torch_u8(kp_p, n_img * cap * 28), fe.as_torch_u8(desc_p, n_img * cap * 32)]
-        gatherer = ResultGather(dist, world, rank, sum(r.numel() for r in recs), dev)
-
-    def run_yolo_step(first):
-        """BASELINE configs[2], one batch of B consecutive stereo frames (frame i's reference frame is frame i-2, 0.2 s back)."""
-        bt, st = batch, main_stream.cuda_stream
-        # The detector (MFMA-bound) runs on its own stream, one batch AHEAD of the front end (VALU / latency-bound kernels + the
-        # host's boxTrack recurrence): the boxes of this batch were requested during the previous step, the next batch's
-        # forward pass is launched as soon as they are downloaded, and everything below overlaps with it.
-        if not yolo_state["in_flight"]:
-            det.forward_device(d_bgr.data_ptr(), W, H, W * 3, W * H * 3, B, 0.5, det_stream.cuda_stream)  # yolo->Segmentation_(imLeft)
-        dets = det.boxes_batch(B, W, H, stream=det_stream.cuda_stream)                      # one synchronisation per batch
-        det.forward_device(d_bgr.data_ptr(), W, H, W * 3, W * H * 3, B, 0.5, det_stream.cuda_stream)      # the next batch
-        yolo_state["in_flight"] = True
-        bt.extract_device(d_gray.data_ptr(), W, W * H, n_img, st)
-        bt.stereo_match(B, cfg["bf"], cfg["fx"], st)
-        # Frame::boxTrack is a host recurrence over the sequence (f64, a handful of boxes)
-        bl, il = [], []
-        lo, li_, lm, lv = np.zeros((0, 4)), np.zeros(0, np.int32), np.zeros(0, np.uint8), np.zeros((0, 2))
-        for i in range(B):
-            bx, idx, omit, vel = fe.box_track(dets[i][0][:fe.MAXB // 2], lo, li_, lm, lv, W, H)
-            bl.append(bx); il.append(idx)
-            lo, li_, lm, lv = bx, idx, omit, vel
-        yolo_state["n_boxes"] = int(np.mean([len(x) for x in bl]))
-        bt.first_separate(cur_idx, None, None, stream=st, packed=fe.Batch.pack_boxes(bl, il))
-        bt.assign_grid(n_img, cam, st)
-        bt.unproject(imgs_per_frame, B, cam, I, st)
-        # Tracking::TrackHomo against the frame 0.2 s back, then Separate / UpdateFrame
-        bt.search_by_projection(cur_idx[2:], cur_idx[:-2], I[2:], I[2:], cam, th, False, True, stream=st)
-        bt.estimate_motion(st)
-        npair = B - 2
-        lidx = np.zeros((npair, fe.MAXB), np.int32); lst = np.full((npair, fe.MAXB), -1, np.int32); nl = np.zeros(npair, np.int32)
-        for p in range(npair):
-            m = min(len(il[p + 1]), fe.MAXB); nl[p] = m; lidx[p, :m] = il[p + 1][:m]         # mLastFrame = frame p+1
-        bt.separate(cur_idx[2:], cur_idx[:-2], None, None, None, None, stream=st, packed_last=(lidx, lst, nl))
-        bt.update_frame(True, st)
-        bt.assign_grid(n_img, cam, st)
-        # TrackWithMotionModel's matcher against the last frame
-        if first:
-            bt.search_by_projection(cur_idx[1:], last_idx[1:], I[1:], I[1:], cam, th, False, True, stream=st)
-        else:
-            bt.search_by_projection(cur_idx, last_idx, I, I, cam, th, False, True, stream=st)
-        bt.copy_frame(int(cur_idx[-1]), n_img, st)
-
-    def run_stream(k, first):
-        bt, st = batches[k], streams[k].cuda_stream
-        f0 = k * Bs
-        g0 = d_gray[f0 * imgs_per_frame:]
-        if args.workload == "rgbd":            # GrabImageRGBD's cvtColor runs inside the level-0 copy of the extractor (same results as the two calls)
-            bt.extract_color_device(d_rgb[f0:].data_ptr(), W * 3, W * H * 3, n_img, True, st)
-        else:
-            bt.extract_device(g0.data_ptr(), Wg, Wg * H, n_img, st)
-        if args.workload == "rgbd":
-            bt.rgbd_from_u16(d_depth[f0:].data_ptr(), W, W * H, Bs, depth_factor, cfg["bf"], st)
-        else:
-            bt.stereo_match(Bs, cfg["bf"], cfg["fx"], st)
-        if cull:
-            cs = cull_state[k]
-            bt.first_separate(cs["slots"], None, None, stream=st, packed=cs["packed"])
-        bt.assign_grid(n_img, cam, st)
-        bt.unproject(imgs_per_frame, Bs, cam, I, st)
-        if first:
-            bt.search_by_projection(cur_idx[1:], last_idx[1:], I[1:], I[1:], cam, th, False, True, stream=st)
-        else:
-            bt.search_by_projection(cur_idx, last_idx, I, I, cam, th, False, True, stream=st)
-        if cull:
-            cs = cull_state[k]
-            bt.separate(cs["cur"], cs["ref"], cs["H"], cs["flag"], None, None, stream=st, packed_last=cs["last"])
-            bt.update_frame(True, st)
-            bt.assign_grid(n_img, cam, st)                       # UpdateFeaturesToGrid
-        if bow:
-            bt.compute_bow(vocab, cur_idx, 4, st)
-            bt.search_by_bow(cur_idx[:-1], cur_idx[1:], 0.7, True, stream=st)
-        bt.copy_frame(int(cur_idx[-1]), n_img, st)
-
-    def step(first=False):
-        if yolo_wl:
-            run_yolo_step(first)
-            if dist is not None:
-                gatherer.submit(recs)
-            return
-        for k in range(S):
-            run_stream(k, first)
-        if S > 1:                                   # join the side streams into the main one
-            for k in range(1, S):
-                main_stream.wait_stream(streams[k])
-        if dist is not None:
-            gatherer.submit(recs)
-        if S > 1:                                   # next step's side-stream work must not overtake the gather
-            for k in range(1, S):
-                streams[k].wait_stream(main_stream)
-
-    step(first=True)                      # priming: fills the carried mLastFrame slot (setup, untimed)
-    for _ in range(args.warmup):
-        step()
-    for bt in batches:
-        bt.sync()
-    torch.cuda.synchronize()
-    if not args.no_profile:
-        for bt in batches:
-            bt.set_profiling(True)
-            bt.reset_kernel_times()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if gatherer is not None:
-        gatherer.finish()                          # the last step's gather is inside the timed region
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(dist, elapsed, dev)
-    for bt in batches:
-        bt.sync()
-
-    kt = {}
-    if not args.no_profile:
-        for bt in batches:
-            for k, (ms, n) in bt.kernel_times().items():
-                a, c = kt.get(k, (0.0, 0))
-                kt[k] = (a + ms, c + n)
-    counts = batch.counts(n_img)
-    m, pairs, nm = batch.download_matches(Bs - 2 if bow else Bs - 1)      # rgbd-bow: the last SearchByBoW pair
+    head, wl = run_workload(args.workload, args, rank, world, dev, pkg, dist, headline=True)
+    extras = {}
+    names = []
+    if args.extra == "auto":
+        names = [w for w in ("stereo", "rgbd", "rgbd-cull", "tum-mask") if w != args.workload] if world == 1 else []
+    elif args.extra != "none":
+        names = [w for w in args.extra.split(",") if w]
+    for w in names:
+        if w not in WORKLOADS:
+            raise SystemExit("unknown workload " + w)
+        o, _ = run_workload(w, args, rank, world, dev, pkg, dist, headline=False)
+        if rank == 0:
+            extras[w] = {"value": o["value"], "unit": "frames/s", "ms_per_step": o["ms_per_step"], "steps": o["steps"], "lanes_per_gpu": o["lanes_per_gpu"],
+                         "scaling": "strong" if w == "kitti-batch" else "weak",
+                         "workload": WORKLOAD_TEXT[w] % args.kitti_frames if w == "kitti-batch" else WORKLOAD_TEXT[w], "lane0_last_frame": o["lane0_last_frame"]}
 
     if rank == 0:
-        total_frames = world * B * args.steps
-        value = total_frames / elapsed
-        alg = algorithmic_bytes(W, H, ex.mvInvScaleFactor, cfg["n_features"])
-        roof = None
-        if kt:
-            dom = max((k for k in kt if kt[k][1] > 0), key=lambda k: kt[k][0])
-            ms, launches = kt[dom]
-            avg_ms = ms / launches
-            per_launch = {"k_pyr_level": alg["k_pyr_level"] / 7.0}.get(dom, alg.get(dom, 0)) * n_img   # images per launch
-            achieved = per_launch / (avg_ms * 1e-3) / 1e9
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc):
-                try:
-                    j = json.load(open(pmc))
-                    e = j.get(dom) or j.get({"k_fast_cells": "k_fast_cells_staged", "k_blur": "k_blur_wide"}.get(dom, dom))      # in-library ids vs kernel symbols
-                    if e and e.get("batch_images") == n_img:
-                        traffic = e.get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": int(per_launch), "avg_launch_ms": round(avg_ms, 4),
-                    "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in kt.items() if v[1] > 0},
-                    "streams": S,
-                    "pipeline_achieved_GBs": round(alg["image_total"] * imgs_per_frame * value / 1e9, 2)}
         cpu = None
-        if world == 1 and args.cpu_frames > 0:
-            v, dt = cpu_baseline(args.workload, cfg, args.cpu_frames, seq)
-            cpu = {"value": round(v, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-                   "sample": "%d frames (64 distinct, cycled) of the same synthetic workload through the CPU oracle (oracle/), "
-                             "1 thread, %.1f s; host has %d logical cores" % (args.cpu_frames, dt, os.cpu_count() or 0)}
-            nthr = max(1, min(32, (os.cpu_count() or 1) // 2))
-            va, dta = cpu_baseline_all_cores(args.workload if args.workload in ("rgbd", "stereo") else "rgbd", cfg, seq, nthr)
-            cpu["all_cores"] = {"value": round(va, 2), "unit": "frames/s", "threads": nthr,
-                                "sample": "%d independent streams x 48 frames, %.1f s" % (nthr, dta)}
+        if world == 1 and args.cpu_budget > 0:
+            P_SENSOR = {"stereo": 1, "rgbd": 2}[wl.kind]
+            cpu = cpu_baseline(args.workload, wl.cfg, wl.kind, P_SENSOR, wl.with_boxes or wl.detector, wl.detector, pkg, budget_s=args.cpu_budget)
+            nthr = max(1, min(os.cpu_count() or 1, 64))
+            cpu["all_cores"] = cpu_all_cores(wl.cfg, wl.kind, P_SENSOR, wl.with_boxes or wl.detector, pkg, nthr)
+        text = WORKLOAD_TEXT[args.workload] % args.kitti_frames if args.workload == "kitti-batch" else WORKLOAD_TEXT[args.workload]
+        cull = wl.with_boxes
         out = {
-            "metric": "tracking frames/sec (extract+match+dynamic-cull), KITTI 1241x376",
-            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "metric": "tracking frames/sec (extract+match%s), %s %dx%d" % ("+dynamic-cull" if cull else "", "KITTI" if wl.cfg is not synth.TUM3 else "TUM3", wl.W, wl.H),
+            "value": head["value"], "unit": "frames/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": head["steps"], "warmup": args.warmup if not wl.strong else 0,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong" if wl.strong else "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": workload_name, "frames_per_step_per_gpu": B, "images_per_frame": imgs_per_frame,
-                       "features_per_image": int(np.mean(counts)), ("bow_matches_last_pair" if bow else "projection_matches_last_pair"): int(nm),
-                       "sharding": "independent frame batches per rank, no data-path collective; per-step async gather of results to rank 0"
-                       if world > 1 else "single GPU"},
-            "roofline": roof, "cpu_baseline": cpu,
+            "config": {"workload": text, "lanes_per_gpu": head["lanes_per_gpu"], "frames_per_step_per_gpu": head["lanes_per_gpu"], "images_per_frame": wl.ipl,
+                       "distinct_sequences_per_gpu": wl.distinct, "timed_seconds": head["timed_s"], "frames_timed": head["frames"],
+                       "detector_operands": (pkg.yolo.detector_precision() if hasattr(pkg.yolo, "detector_precision") else "f16") if wl.detector else None,
+                       "lane0_last_frame": head["lane0_last_frame"],
+                       "sharding": ("independent lanes per rank, no data-path collective; per-step async gather of the result records to rank 0"
+                                    if world > 1 else "single GPU")},
+            "roofline": head.get("roofline"), "cpu_baseline": cpu, "extra": extras,
         }
-        if yolo_wl:                               # the detector alone (the MFMA path), timed after the run
-            torch.cuda.synchronize(); t1 = time.perf_counter()
-            for _ in range(5):
-                det.forward_device(d_bgr.data_ptr(), W, H, W * 3, W * H * 3, B, 0.5, main_stream.cuda_stream)
-            torch.cuda.synchronize(); dt_det = (time.perf_counter() - t1) / 5
-            fl = det.flops()
-            out["detector"] = {"bound": "mfma", "images_per_s": round(B / dt_det, 1), "achieved": round(fl * B / dt_det / 1e12, 1), "peak": 2500.0,
-                               "unit": "TFLOP/s", "frac": round(fl * B / dt_det / 2.5e15, 4), "gflop_per_image": round(fl / 1e9, 2),
-                               "ms_per_batch": round(dt_det * 1e3, 3), "boxes_per_frame_after_boxTrack": yolo_state["n_boxes"],
-                               "weights": "synthetic (yolov3.weights is a download that never was in the reference)"}
-        # the broadcast vocabulary's consumer, outside the timed region: Frame::ComputeBoW of frame 0
-        batch.compute_bow(vocab, [0], 4)
-        b0 = batch.download_bow(0)
-        out["vocabulary"] = {"nodes": vocab.info()["n_nodes"], "words": vocab.info()["n_words"], "packed_bytes": int(voc_bytes),
-                             "frame0_bow_words": int(len(b0["word"])), "frame0_feature_vector_nodes": int(len(np.unique(b0["fv_node"])))}
+        if "gathered_record_check" in head:
+            out["gathered_record_check"] = head["gathered_record_check"]
+        out["vocabulary"] = {"nodes": vocab.info()["n_nodes"], "words": vocab.info()["n_words"], "packed_bytes": int(voc_bytes)}
         if voc_ms is not None:
             out["vocabulary_broadcast_ms"] = round(voc_ms, 3)
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    for bt in batches:
-        bt.close()
 
 
 if __name__ == "__main__":

@@ -274,6 +274,16 @@ int sd_batch_first_separate(sd_batch* b, int n_frames, const int32_t* slots, con
 int sd_batch_download_boxes(sd_batch* b, int slot, int* nb, double* boxes, int32_t* box_idx, int32_t* box_status,
                             int32_t* kept_orig, int32_t* box_start, int32_t* box_items, int items_cap, int* n_all,
                             int* n_static);
+/* The per-slot record behind sd_batch_download_boxes as it lies in HBM ([max_images] of them): what a multi-GPU job gathers
+ * beside the keypoint arrays (objects, box_idx, box_status, N_s = n_static, N_d = n_dynamic). */
+typedef struct sd_frame_boxes {
+    int32_t nb, n_all, n_static, n_dynamic;
+    double boxes[SD_MAX_BOXES][4];
+    int32_t box_idx[SD_MAX_BOXES], box_status[SD_MAX_BOXES], kept_orig[SD_MAX_BOXES];
+    int32_t box_start[SD_MAX_BOXES + 1];
+    int32_t pad_;
+} sd_frame_boxes;
+int sd_batch_boxes_device(sd_batch* b, sd_frame_boxes** d_frame_boxes);
 /* The dynamic keypoints of a slot (class_id = index before the split), their descriptors, mvuRight and mvDepth. */
 int sd_batch_download_dynamic(sd_batch* b, int slot, sd_keypoint* kp, uint8_t* desc, float* uright, float* depth, int cap, int* n);
 /* Tracking::Separate(HorF, flag, dynStatus) (src/Tracking.cc:1093-1239) for n_pairs (current, reference) slots:

@@ -29,16 +29,29 @@ def build(force=False):
     return so
 
 
+def _load(so):
+    L = C.CDLL(so)
+    L.orc_extractor_create.restype = C.c_void_p
+    L.orc_extractor_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+    L.orc_extractor_destroy.argtypes = [C.c_void_p]
+    L.orc_fast_atan2.restype = C.c_float
+    L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+    return L
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        so = build()
-        _LIB = C.CDLL(so)
-        _LIB.orc_extractor_create.restype = C.c_void_p
-        _LIB.orc_extractor_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
-        _LIB.orc_extractor_destroy.argtypes = [C.c_void_p]
-        _LIB.orc_fast_atan2.restype = C.c_float
-        _LIB.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        _LIB = _load(build())
+    return _LIB
+
+
+def use_native():
+    """bench.py's cpu_baseline leg: the same sources built with -march=native on the box that runs them (BASELINE.md section 2;
+    the portable libsd_oracle.so is -march=x86-64-v3 because it travels between machines)."""
+    global _LIB
+    subprocess.check_call(["make", "-C", _HERE, "-s", "native"])
+    _LIB = _load(os.path.join(_HERE, "_native", "libsd_oracle_native.so"))
     return _LIB
 
 

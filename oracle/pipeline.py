@@ -45,8 +45,9 @@ class FrameState:
 class SequenceOracle:
     """One camera stream through Tracking's front end, frame by frame."""
 
-    def __init__(self, orc, cfg, sensor, rgb_order=True, track_last=True):
+    def __init__(self, orc, cfg, sensor, rgb_order=True, track_last=True, threads=1):
         self.orc, self.cfg, self.sensor = orc, cfg, sensor
+        self.threads = threads               # 2: left / right extraction in two threads, as Frame.cc:87-90 / 151-154
         mk = lambda: orc.Extractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
         self.exL = mk()
         self.exR = mk() if sensor == SENSOR_STEREO else None
@@ -74,11 +75,19 @@ class SequenceOracle:
         F = FrameState()
         F.mnId = self.n_frames
         F.mTimeStamp = float(timestamp)
-        gray = self._gray(im)
-        kp, desc = self.exL(gray)
+        if self.sensor == SENSOR_STEREO and self.threads >= 2:
+            import threading
+            box = {}
+            th = threading.Thread(target=lambda: box.update(r=self.exR(self._gray(im2))))
+            th.start()
+            kp, desc = self.exL(self._gray(im))
+            th.join()
+            kpR, descR = box["r"]
+        else:
+            kp, desc = self.exL(self._gray(im))
+            if self.sensor == SENSOR_STEREO:
+                kpR, descR = self.exR(self._gray(im2))
         N = len(kp)
-        if self.sensor == SENSOR_STEREO:
-            kpR, descR = self.exR(self._gray(im2))
         if N == 0:                                            # `if(mvKeys.empty()) return;`
             F.kp, F.desc, F.ur, F.dep = kp, desc, np.zeros(0, np.float32), np.zeros(0, np.float32)
             F.cells = np.zeros(0, np.int32)

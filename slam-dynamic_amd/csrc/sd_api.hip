@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cstddef>
 #include <cmath>
 #include <string>
 #include <vector>
@@ -1712,6 +1713,15 @@ int sd_batch_download_boxes(sd_batch* b, int slot, int* nb, double* boxes, int32
         if (n > items_cap) return set_err(SD_ERR_CAPACITY, "box item buffer too small");
         if (n > 0) HIPCHK(hipMemcpy(box_items, b->d_boxItems + (size_t)slot * b->itemsCap, (size_t)n * 4, hipMemcpyDeviceToHost));
     }
+    return SD_OK;
+}
+
+static_assert(sizeof(sd_frame_boxes) == sizeof(SdFrameBoxes) && offsetof(sd_frame_boxes, box_status) == offsetof(SdFrameBoxes, box_status) &&
+              offsetof(sd_frame_boxes, box_start) == offsetof(SdFrameBoxes, boxStart), "sd_frame_boxes is the public face of SdFrameBoxes");
+int sd_batch_boxes_device(sd_batch* b, sd_frame_boxes** d_frame_boxes)
+{
+    if (!b || !d_frame_boxes) return SD_ERR_INVALID;
+    *d_frame_boxes = (sd_frame_boxes*)b->d_fb;
     return SD_OK;
 }
 

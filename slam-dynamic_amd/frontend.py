@@ -110,6 +110,7 @@ def lib():
         L.sd_tracker_batch.argtypes = [vp, C.POINTER(vp)]
         L.sd_tracker_track.argtypes = [vp, vp, sz, sz, vp, sz, sz, vp, vp, vp, vp, vp, vp, vp]
         L.sd_batch_copy_frames.argtypes = [vp, i, vp, vp, vp]
+        L.sd_batch_boxes_device.argtypes = [vp, C.POINTER(vp)]
         _lib = L
     return _lib
 
@@ -601,6 +602,16 @@ def depth_to_f32_device(d_src, width, height, src_stride_elems, factor, d_dst, n
 def hamming_matrix_device(d_a, na, d_b, nb, d_out, stream=None):
     check(lib().sd_hamming_matrix_device(C.c_void_p(d_a), na, C.c_void_p(d_b), nb, C.c_void_p(d_out),
                                          C.c_void_p(stream or 0)))
+
+
+FRAME_BOXES_BYTES = 16 + 32 * 32 + 3 * 32 * 4 + 33 * 4 + 4        # sizeof(sd_frame_boxes)
+
+
+def batch_boxes_device(batch):
+    """Device pointer of the per-slot sd_frame_boxes records."""
+    p = C.c_void_p()
+    check(lib().sd_batch_boxes_device(batch.h, C.byref(p)))
+    return p.value
 
 
 class _DevBytes:

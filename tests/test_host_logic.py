@@ -82,6 +82,54 @@ def test_multi_rank_gather_and_timing_gloo():
         assert tuple(shape) == (2, 5, 7) and means == [1, 2] and t == 2.0 and vsum == sum(range(100))
 
 
+def test_result_record_layout_roundtrip(fe):
+    """The per-frame record a rank gathers to rank 0 (N, keypoints, descriptors, uRight, depth, boxes / box_status, N_s)."""
+    cap = 2064
+    lay = bench.record_layout(cap, fe.FRAME_BOXES_BYTES)
+    assert lay["_stride"] % 16 == 0 and lay["kp"][1] == cap * 28 and lay["fb"][1] == 1560
+    rec = np.zeros(lay["_stride"], np.uint8)
+    N, Ns = 1800, 1750
+    rec[lay["count"][0]:lay["count"][0] + 4] = np.array([N], np.int32).view(np.uint8)
+    fb = np.zeros(1560, np.uint8)
+    fb[:16] = np.array([2, 2000, Ns, 250], np.int32).view(np.uint8)
+    fb[16 + 1024:16 + 1024 + 8] = np.array([7, 9], np.int32).view(np.uint8)
+    fb[16 + 1024 + 128:16 + 1024 + 136] = np.array([2, -1], np.int32).view(np.uint8)
+    rec[lay["fb"][0]:lay["fb"][0] + 1560] = fb
+    ur = np.arange(cap, dtype=np.float32)
+    rec[lay["uright"][0]:lay["uright"][0] + cap * 4] = ur.view(np.uint8)
+    d = bench.decode_record(rec, lay, cap)
+    assert (d["N"], d["N_s"], d["N_d"], d["n_boxes"]) == (N, Ns, 250, 2)
+    assert d["box_idx"].tolist() == [7, 9] and d["box_status"].tolist() == [2, -1]
+    assert np.array_equal(d["uright"], ur[:N]) and int(d["readmitted"].sum()) == N - Ns and d["desc"].shape == (N, 32)
+
+
+_RANK_SCRIPT = """
+import json, os, sys
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+t = torch.tensor([rank + 1.0])
+dist.all_reduce(t)
+if rank == 0:
+    print(json.dumps({"rccl_ranks": dist.get_world_size(), "sum": float(t.item()), "local_rank": int(os.environ["LOCAL_RANK"])}))
+dist.barrier(); dist.destroy_process_group()
+sys.exit(int(sys.argv[1]) if rank == 1 else 0)
+"""
+
+
+def test_self_launcher_starts_all_ranks(tmp_path, capfd):
+    """`python bench.py --gpus N` without a torch.distributed environment: bench.spawn_ranks starts N ranks (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1), rank 0's JSON line passes through, any failing rank fails the run."""
+    import json
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    assert bench.spawn_ranks(2, ["0"], script=str(script)) == 0
+    out = capfd.readouterr().out.strip().splitlines()
+    j = json.loads(out[-1])
+    assert j == {"rccl_ranks": 2, "sum": 3.0, "local_rank": 0}
+    assert bench.spawn_ranks(2, ["3"], script=str(script)) != 0
+
+
 def test_oracle_local_map_best_second_ratio():
     """ORBmatcher::SearchByProjection(Frame, MapPoints) (ORBmatcher.cc:45-129) on a hand-made case: the ratio test only
     applies when best and second best share a level; a keypoint taken by an earlier point with observations is skipped."""
