@@ -343,6 +343,14 @@ class Workload:
             self.det_stream = torch.cuda.Stream(device=dev)
             self.det_in_flight = -1
             self.lookahead = True             # the next frame's forward pass is launched before this frame's front end
+        self.cloud = name == "tum-mask"          # PointCloudMapping::generatePointCloud on every frame: the consumer of the semantic mask
+        if self.cloud:
+            self.cap_pts = ((self.W + 2) // 3) * ((self.H + 2) // 3)
+            self.d_pts = torch.zeros((self.S, self.cap_pts, 16), dtype=torch.uint8, device=dev)
+            self.d_cnt = torch.zeros((self.S, 2), dtype=torch.int32, device=dev)
+            self.Twc64 = np.tile(np.eye(4), (self.S, 1, 1))
+            self.cam = fe.make_camera(cfg)
+            self.depth_factor = float(np.float32(1.0) / np.float32(cfg["depth_map_factor"]))
         self.frames = []          # per timestep: dict(images, depth, boxes, n_boxes, stamps)
         self.t = 0
         self.n_boxes_seen = []
@@ -364,7 +372,10 @@ class Workload:
             if self.with_boxes and not self.detector:
                 for l in range(S):
                     b = per[l % D]["boxes"]; nb[l] = len(b); bx[l, :len(b)] = b
-            self.frames.append(dict(images=img, depth=dep, boxes=bx, n_boxes=nb, stamps=np.full(S, per[0]["stamp"], np.float64)))
+            msk = None
+            if self.cloud:
+                msk = torch.from_numpy(np.stack([p["mask"] for p in per])).to(self.dev).repeat((reps, 1, 1))[:S].contiguous()
+            self.frames.append(dict(images=img, depth=dep, mask=msk, boxes=bx, n_boxes=nb, stamps=np.full(S, per[0]["stamp"], np.float64)))
 
     def step(self):
         fe, torch = self.fe, self.torch
@@ -387,6 +398,10 @@ class Workload:
         res = self.trk.track(fr["images"].data_ptr(), W * 3, W * H * 3, fr["stamps"], boxes=boxes, n_boxes=n_boxes,
                              d_depth=fr["depth"].data_ptr() if fr["depth"] is not None else 0, depth_stride=W, depth_pitch=W * H,
                              stream=self.main.cuda_stream)
+        if self.cloud:
+            self.batch.backproject_dense(np.arange(S, dtype=np.int32), fr["images"].data_ptr(), W * 3, W * H * 3, fr["depth"].data_ptr(), W, W * H,
+                                         self.depth_factor, fr["mask"].data_ptr(), W, W * H, self.cam, self.Twc64, self.d_pts.data_ptr(), self.cap_pts,
+                                         self.d_cnt.data_ptr(), stream=self.main.cuda_stream)
         self.t += 1
         return res
 
@@ -543,7 +558,8 @@ WORKLOAD_TEXT = {
     "stereo": "KITTI stereo 1241x376 colour pairs, 2000 feat/image: cvtColor + 2x ORB extract + stereo match + projection match vs the last frame, no detector / boxes",
     "rgbd": "KITTI-03 RGB-D 1241x376, 2000 feat/frame: cvtColor + ORB extract + RGB-D stereo + projection match vs the last frame, no semantic mask (BASELINE configs[1])",
     "rgbd-cull": "KITTI-03 RGB-D 1241x376, 2000 feat/frame, 3 given boxes per frame: extract + match + boxTrack + firstSeparate + TrackHomo + Separate + UpdateFrame",
-    "tum-mask": "TUM3 RGB-D 640x480, 1000 feat/frame, DepthMapFactor 5000, 30 fps, mask + 3 boxes per frame: extract + match + cull (BASELINE configs[3])",
+    "tum-mask": "TUM3 RGB-D 640x480, 1000 feat/frame, DepthMapFactor 5000, 30 fps, mask + 3 boxes per frame: extract + match + cull + dense back-projection of the "
+                "pixels outside (dynamic box AND mask) (BASELINE configs[3])",
     "kitti-batch": "11 synthetic KITTI stereo sequences x %d frames with 3 boxes per frame, whole sequences per rank (BASELINE configs[4]); cull on, detector off",
 }
 

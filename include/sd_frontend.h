@@ -385,6 +385,21 @@ int sd_tracker_track(sd_tracker* t, const uint8_t* d_images, size_t stride, size
 /* Batch copy of frame slots (Frame's copy constructor, src/Frame.cc:39-63) in one launch: slot src[i] -> dst[i]. */
 int sd_batch_copy_frames(sd_batch* b, int n, const int32_t* src, const int32_t* dst, void* stream);
 
+/* ---- dense RGB-D back-projection with the dynamic mask ----
+ * PointCloudMapping::generatePointCloud(kf, color, depth, mask, dyn_obj) (src/pointcloudmapping.cc:59-103) for n_frames frame
+ * slots: every third row / column; a pixel is skipped when it lies inside a dynamic box AND mask != 0, or when its depth is
+ * outside [0.01, 5]; dyn_obj = the slot's objects whose box_status is 0 or 2 (Tracking::CreateNewKeyFrame, src/Tracking.cc:
+ * 1999-2007).  d_color: 8-bit 3-channel image as handed to TrackRGBD (bytes 0, 1, 2 of a pixel become b, g, r); d_depth: CV_16U
+ * with depth_factor = 1 / DepthMapFactor (the imDepth of Tracking.cc:271-272); d_mask: the 8-bit mask image (0 = background;
+ * the reference converts it to CV_32F and tests != 0), may be NULL (nothing is masked).  Twc_host: [n_frames][16] row-major f64,
+ * the T.inverse().matrix() of the key frame pose.  Output: d_points [n_frames][cap_points] in the reference's push_back order
+ * (pcl::PointXYZRGBA payload), d_counts [n_frames][2] = {cloud size, masked_num}.  cap_points >= ceil(W/3) * ceil(H/3). */
+typedef struct sd_cloud_point { float x, y, z; uint8_t b, g, r, a; } sd_cloud_point;
+int sd_batch_backproject_dense(sd_batch* b, int n_frames, const int32_t* slots, const uint8_t* d_color, size_t color_stride,
+                               size_t color_pitch, const uint16_t* d_depth, size_t depth_stride_elems, size_t depth_pitch_elems,
+                               float depth_factor, const uint8_t* d_mask, size_t mask_stride, size_t mask_pitch, const sd_camera* cam,
+                               const double* Twc_host, sd_cloud_point* d_points, int cap_points, int32_t* d_counts, void* stream);
+
 /* ---- detector: yolov3Segment (include/yolo.h:22-48, src/yolo.cc, src/yolo/yolov3.cfg) ----
  * cv::dnn's Darknet importer + Net::forward + the reference's post-processing, on MFMA (f16 operands, f32
  * accumulation).  The network is given as a layer list (the five layer types of yolov3.cfg); weights are the

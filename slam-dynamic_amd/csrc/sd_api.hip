@@ -15,6 +15,7 @@
 #include "k_motion.h"
 #include "k_cull.h"
 #include "k_tracker.h"
+#include "k_cloud.h"
 #include "sd_yolo.h"
 #include "sd_vocab.h"
 
@@ -113,6 +114,7 @@ struct sd_batch {
     int* d_dynStart = nullptr; int* d_dynStatus = nullptr; int* d_sepMatches = nullptr; int* d_sepRet = nullptr;
     int2* d_sepPairs = nullptr;
     int2* d_copyPairs = nullptr;
+    unsigned long long* d_cloudBits = nullptr; int* d_cloudRows = nullptr; double* d_cloudT = nullptr; int* d_cloudSlots = nullptr; size_t cloudCap = 0;
     int itemsCap = 0;
     int nSepPairs = 0;
     const int* sepActive = nullptr;          // active mask of the last separate (tracker mode), applied by update_frame too
@@ -231,7 +233,7 @@ static void batch_free(sd_batch* b)
                     b->d_sepPairs, b->d_kpD, b->d_descD, b->d_urD, b->d_depD, b->d_rowIdx, b->d_rowStart,
                     b->d_lmCand, b->d_lmN, b->d_lmOvf, b->d_lmIdx, b->d_bowWordF, b->d_bowWF, b->d_bowNidF, b->d_fvNode, b->d_fvFeat,
                     b->d_fvRunStart, b->d_fvRunNode, b->d_bowWord, b->d_bowVal, b->d_bowMeta, b->d_bowImg,
-                    b->d_moPts, b->d_moNorm, b->d_moCounts, b->d_moMaskH, b->d_moMaskF, b->d_moRes, b->d_pyrExt, b->d_copyPairs};
+                    b->d_moPts, b->d_moNorm, b->d_moCounts, b->d_moMaskH, b->d_moMaskF, b->d_moRes, b->d_pyrExt, b->d_copyPairs, b->d_cloudBits, b->d_cloudRows, b->d_cloudT, b->d_cloudSlots};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& r : b->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : b->pool) (void)hipEventDestroy(e);
@@ -2421,6 +2423,48 @@ int sd_batch_reset_kernel_times(sd_batch* b)
     if (!b) return SD_ERR_INVALID;
     drain_profile(b);
     for (int i = 0; i < K_COUNT; i++) { b->totalMs[i] = 0; b->launches[i] = 0; }
+    return SD_OK;
+}
+
+// PointCloudMapping::generatePointCloud (src/pointcloudmapping.cc:59-103) for frame slots of the batch
+int sd_batch_backproject_dense(sd_batch* b, int n_frames, const int32_t* slots, const uint8_t* d_color, size_t color_stride,
+                               size_t color_pitch, const uint16_t* d_depth, size_t depth_stride_elems, size_t depth_pitch_elems,
+                               float depth_factor, const uint8_t* d_mask, size_t mask_stride, size_t mask_pitch, const sd_camera* cam,
+                               const double* Twc_host, sd_cloud_point* d_points, int cap_points, int32_t* d_counts, void* stream_)
+{
+    if (!b || n_frames < 0 || n_frames > b->maxImages || !cam_ok(cam) || (n_frames > 0 && (!slots || !d_color || !d_depth || !Twc_host || !d_points || !d_counts)))
+        return set_err(SD_ERR_INVALID, "bad backproject_dense arguments");
+    const int W = b->plan.W, H = b->plan.H;
+    const int cols3 = (W + 2) / 3, rows3 = (H + 2) / 3, words = (cols3 + 63) / 64;
+    if (cap_points < cols3 * rows3) return set_err(SD_ERR_CAPACITY, "cap_points must be at least ceil(W/3) * ceil(H/3)");
+    if (words > 64) return set_err(SD_ERR_UNSUPPORTED, "image wider than 12288 pixels");
+    if (color_stride < (size_t)3 * W || depth_stride_elems < (size_t)W || (d_mask && mask_stride < (size_t)W)) return set_err(SD_ERR_INVALID, "stride smaller than width");
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
+    b->lastStream = s;
+    if (n_frames == 0) return SD_OK;
+    for (int f = 0; f < n_frames; f++) if (!slot_ok(b, slots[f])) return set_err(SD_ERR_STATE, "backproject_dense: slot holds no frame");
+    const size_t need = (size_t)b->maxImages * rows3 * words;
+    if (b->cloudCap < need) {
+        HIPCHK(hipStreamSynchronize(s));
+        if (b->d_cloudBits) { (void)hipFree(b->d_cloudBits); (void)hipFree(b->d_cloudRows); (void)hipFree(b->d_cloudT); (void)hipFree(b->d_cloudSlots); b->d_cloudBits = nullptr; b->d_cloudRows = nullptr; b->d_cloudT = nullptr; b->d_cloudSlots = nullptr; }
+        HIPCHK(hipMalloc((void**)&b->d_cloudBits, need * 8));
+        HIPCHK(hipMalloc((void**)&b->d_cloudRows, (size_t)b->maxImages * rows3 * 2 * 4));
+        HIPCHK(hipMalloc((void**)&b->d_cloudT, (size_t)b->maxImages * 16 * 8));
+        HIPCHK(hipMalloc((void**)&b->d_cloudSlots, (size_t)b->maxImages * 4));
+        b->cloudCap = need;
+    }
+    HIPCHK(hipMemcpyAsync(b->d_cloudT, Twc_host, (size_t)n_frames * 128, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->d_cloudSlots, slots, (size_t)n_frames * 4, hipMemcpyHostToDevice, s));
+    SdCloudArgs A;
+    A.fb = b->d_fb; A.slots = b->d_cloudSlots; A.color = d_color; A.colorStride = color_stride; A.colorPitch = color_pitch;
+    A.depth = d_depth; A.depthStride = depth_stride_elems; A.depthPitch = depth_pitch_elems; A.depthFactor = depth_factor;
+    A.mask = d_mask; A.maskStride = mask_stride; A.maskPitch = mask_pitch; A.fx = cam->fx; A.fy = cam->fy; A.cx = cam->cx; A.cy = cam->cy;
+    A.Twc = b->d_cloudT; A.W = W; A.H = H; A.cols3 = cols3; A.rows3 = rows3; A.words = words; A.bits = b->d_cloudBits; A.rowCount = b->d_cloudRows;
+    A.points = (sd_cloud_point_dev*)d_points; A.capPoints = cap_points; A.counts = d_counts;
+    hipLaunchKernelGGL(k_cloud_mark, dim3(rows3, n_frames), dim3(256), 0, s, A);
+    LAUNCH_CHECK("k_cloud_mark");
+    hipLaunchKernelGGL(k_cloud_emit, dim3(rows3, n_frames), dim3(256), 0, s, A);
+    LAUNCH_CHECK("k_cloud_emit");
     return SD_OK;
 }
 

@@ -111,6 +111,7 @@ def lib():
         L.sd_tracker_track.argtypes = [vp, vp, sz, sz, vp, sz, sz, vp, vp, vp, vp, vp, vp, vp]
         L.sd_batch_copy_frames.argtypes = [vp, i, vp, vp, vp]
         L.sd_batch_boxes_device.argtypes = [vp, C.POINTER(vp)]
+        L.sd_batch_backproject_dense.argtypes = [vp, i, vp, vp, sz, sz, vp, sz, sz, f, vp, sz, sz, vp, vp, vp, i, vp, vp]
         _lib = L
     return _lib
 
@@ -427,6 +428,15 @@ class Batch:
     def update_frame(self, only_if_static=True, stream=None):
         check(lib().sd_batch_update_frame(self.h, int(only_if_static), C.c_void_p(stream or 0)))
 
+    # -- PointCloudMapping::generatePointCloud
+    def backproject_dense(self, slots, d_color, color_stride, color_pitch, d_depth, depth_stride, depth_pitch, depth_factor, d_mask, mask_stride,
+                          mask_pitch, cam, Twc, d_points, cap_points, d_counts, stream=None):
+        sl = np.ascontiguousarray(slots, np.int32); c = camera_array(cam)
+        T = np.ascontiguousarray(Twc, np.float64).reshape(len(sl), 16)
+        check(lib().sd_batch_backproject_dense(self.h, len(sl), _p(sl), C.c_void_p(d_color), color_stride, color_pitch, C.c_void_p(d_depth), depth_stride,
+                                               depth_pitch, C.c_float(depth_factor), C.c_void_p(d_mask or 0), mask_stride, mask_pitch, _p(c), _p(T),
+                                               C.c_void_p(d_points), cap_points, C.c_void_p(d_counts), C.c_void_p(stream or 0)))
+
     # -- profiling
     def set_profiling(self, on):
         check(lib().sd_batch_set_profiling(self.h, int(bool(on))))
@@ -445,6 +455,7 @@ class Batch:
         return out
 
 
+CLOUD_POINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("b", "u1"), ("g", "u1"), ("r", "u1"), ("a", "u1")])     # sd_cloud_point
 MAXB = 32
 SENSOR_MONOCULAR, SENSOR_STEREO, SENSOR_RGBD = 0, 1, 2
 
