@@ -422,6 +422,14 @@ int sd_yolo_v3_layers(sd_yolo_layer* layers, int cap, int* n, float anchors[18])
 /* yolov3Segment::yolov3Segment (yolo.cc:15-31); net_w x net_h = inpWidth x inpHeight (yolo.h:26-27). */
 int sd_yolo_create(sd_yolo** out, const sd_yolo_layer* layers, int n_layers, const float anchors[18], int classes, int net_w,
                    int net_h, int max_batch);
+/* The same with the arithmetic chosen: SD_YOLO_F16 = f16 operands, f32 accumulation on v_mfma_f32_32x32x16_f16 (default, the
+ * throughput mode); SD_YOLO_F32 = f32 operands and accumulation on v_mfma_f32_32x32x2_f32, i.e. the reference's own arithmetic
+ * (cv::dnn computes in f32, src/yolo.cc:29), at 1/16 of the MFMA rate.  In F32 mode sd_yolo_download_layer returns floats. */
+#define SD_YOLO_F16 0
+#define SD_YOLO_F32 1
+int sd_yolo_create_prec(sd_yolo** out, const sd_yolo_layer* layers, int n_layers, const float anchors[18], int classes, int net_w,
+                        int net_h, int max_batch, int precision);
+int sd_yolo_precision(const sd_yolo* y, int* precision);
 int sd_yolo_destroy(sd_yolo* y);
 int sd_yolo_weight_count(const sd_yolo* y, size_t* n_floats);
 int sd_yolo_load_darknet_weights(sd_yolo* y, const float* payload, size_t n_floats);
@@ -433,7 +441,7 @@ int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int heig
                            float conf_threshold, void* stream);
 /* Test access: layer output (f16, NHWC, dense) of one image; region-layer rows [total_rows][5 + classes] of image 0
  * (only after a forward with n == 1). */
-int sd_yolo_download_layer(sd_yolo* y, int layer, int image, uint16_t* f16_nhwc_out);
+int sd_yolo_download_layer(sd_yolo* y, int layer, int image, uint16_t* f16_nhwc_out); /* float* in SD_YOLO_F32 mode */
 int sd_yolo_download_region(sd_yolo* y, float* rows, int* total_rows);
 /* Host-image forms for a per-frame caller (`yolo->Segmentation_(imLeft)`, stereo_kitti.cc:107): upload + forward of one
  * 8-bit BGR image, and yolov3Segment::Segmentation's mask in host memory (image 0 of the last forward). */

@@ -686,7 +686,8 @@ __global__ void __launch_bounds__(256) k_upsample_concat(const _Float16* __restr
 // Rows are numbered as cv::dnn emits them: head by head, then (y, x, anchor).  Surviving rows are appended to a
 // compact list; their order is restored on the host before NMSBoxes (it needs the original row order for ties).
 struct SdDet { int row; int cls; float conf; float cx, cy, w, h; };   // 28 B
-__global__ void __launch_bounds__(256) k_region_decode(const _Float16* __restrict__ head, int hs /*channel stride*/,
+template <typename T>
+__global__ void __launch_bounds__(256) k_region_decode(const T* __restrict__ head, int hs /*channel stride*/,
                                                        int gh, int gw, int N, float aw0, float ah0, float aw1,
                                                        float ah1, float aw2, float ah2, int netW, int netH,
                                                        float confThreshold, int rowBase, SdDet* __restrict__ dets,
@@ -700,7 +701,7 @@ __global__ void __launch_bounds__(256) k_region_decode(const _Float16* __restric
     const int n = ii / perImg, r = ii - n * perImg;
     const int a = r % 3, cell = r / 3;
     const int y = cell / gw, x = cell - y * gw;
-    const _Float16* t = head + ((size_t)n * gh * gw + cell) * hs + a * 85;
+    const T* t = head + ((size_t)n * gh * gw + cell) * hs + a * 85;
     auto sig = [](float v) { return 1.f / (1.f + expf(-v)); };
     const float obj = valid ? sig((float)t[4]) : 0.f;
     // class scores are obj * sigmoid(.) <= obj (a product with a factor <= 1 never rounds above obj), so a row whose
@@ -717,7 +718,7 @@ __global__ void __launch_bounds__(256) k_region_decode(const _Float16* __restric
         const int si = __shfl(ii, src);
         const float sobj = __shfl(obj, src);
         const int sn = si / perImg, sr = si - sn * perImg;
-        const _Float16* st = head + ((size_t)sn * gh * gw + sr / 3) * hs + (sr % 3) * 85 + 5;
+        const T* st = head + ((size_t)sn * gh * gw + sr / 3) * hs + (sr % 3) * 85 + 5;
         float p0 = sobj * sig((float)st[lane]);
         if (!(p0 > 0.001f)) p0 = 0.f;                 // region layer `thresh`
         float p1 = 0.f;

@@ -1,0 +1,164 @@
+// The detector in the reference's own arithmetic: f32 operands, f32 accumulation, on v_mfma_f32_32x32x2_f32 (dense peak
+// 157.3 TFLOP/s, 1/16 of the f16 rate).  cv::dnn runs YOLOv3 in f32 on the CPU (src/yolo.cc:29 DNN_TARGET_CPU); this mode
+// exists so that the box sets can be compared with an f32 forward pass instead of being explained away by a tolerance, and
+// so that the f16 mode's disagreements can be counted against it (tests/test_gpu_yolo.py).  Activations NHWC f32, weights
+// [coutPad][taps][cin] f32 with batch-norm folded in f32.
+//   k_blob_from_image_f32   blobFromImage -> NHWC f32 x 8 channels (3 + 5 zeros: one K-chunk of the MFMA loop)
+//   k_conv_f32<BK>          implicit-GEMM convolution, 1x1 / 3x3, stride 1 / 2, + bias + leaky ReLU + shortcut
+// One f32 MFMA is 64 cycles for 4096 FLOPs and needs ONE float per operand per lane, so the kernel is MFMA-bound with a
+// plain structure: 128 filters x 256 pixels per workgroup (8 waves of 64 x 64), K walked in steps of BK channels of one
+// filter tap, the next step's tiles prefetched into registers while the 64 MFMAs of the current step run.  A lane reads
+// its fragments as 16-byte pieces: half h of the wave takes floats [4h, 4h + 4) of an 8-wide K chunk, MFMA j of the chunk
+// uses element j on both operands -- which k a (half, j) pair stands for is immaterial as long as A and B agree.
+#pragma once
+#include "k_yolo.h"
+
+typedef float sd_f4 __attribute__((ext_vector_type(4)));
+
+struct SdConvArgsF {
+    const float* in; const float* wgt; const float* bias; const float* res; float* out;
+    int N, H, W, cin, cinStride;
+    int Ho, Wo, cout, outStride, resStride;
+    int ksize, stride, pad, leaky;
+};
+
+#define SD_F32_BM 128
+#define SD_F32_BN 256
+
+template <int BK>
+__global__ void __launch_bounds__(512, 1) k_conv_f32(SdConvArgsF A)
+{
+    constexpr int LD = BK + 4;                          // LDS row length in floats (16-byte aligned rows, 2-way conflicts at worst)
+    constexpr int CPR = BK / 4;                         // 16-byte chunks per row
+    constexpr int XC = (SD_F32_BN * CPR + 511) / 512;   // activation chunks per thread per step
+    constexpr int WC = (SD_F32_BM * CPR + 511) / 512;
+    extern __shared__ __align__(16) float smemf[];
+    float* sW = smemf;                                  // [128][LD]
+    float* sX = smemf + SD_F32_BM * LD;                 // [256][LD]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r32 = lane & 31, h = lane >> 5;
+    const int wm = wv & 1, wn = wv >> 1;                // wave tile: filters [64 wm, +64), pixels [64 wn, +64)
+    const int pix0 = blockIdx.x * SD_F32_BN, co0 = blockIdx.y * SD_F32_BM;
+    const int npix = A.N * A.Ho * A.Wo;
+    int pyi[XC], pxi[XC];
+    size_t pbase[XC];
+    bool pok[XC];
+#pragma unroll
+    for (int i = 0; i < XC; i++) {
+        const int chunk = tid + 512 * i;
+        const int p = pix0 + chunk / CPR;
+        pok[i] = chunk < SD_F32_BN * CPR && p < npix;
+        const int pp = pok[i] ? p : 0;
+        const int n = pp / (A.Ho * A.Wo), r = pp - n * (A.Ho * A.Wo);
+        const int yo = r / A.Wo, xo = r - yo * A.Wo;
+        pyi[i] = yo * A.stride - A.pad; pxi[i] = xo * A.stride - A.pad;
+        pbase[i] = (size_t)n * A.H * A.W;
+    }
+    const int taps = A.ksize * A.ksize;
+    const int ksteps = taps * (A.cin / BK);
+    sd_f16v acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+    sd_f4 xr[XC], wr[WC];
+    int t = 0, c0 = 0, kh = 0, kw = 0;
+    auto fetch = [&]() {
+#pragma unroll
+        for (int i = 0; i < WC; i++) {
+            const int chunk = tid + 512 * i;
+            wr[i] = sd_f4{0.f, 0.f, 0.f, 0.f};
+            if (chunk < SD_F32_BM * CPR) wr[i] = *(const sd_f4*)(A.wgt + ((size_t)(co0 + chunk / CPR) * taps + t) * A.cin + c0 + 4 * (chunk % CPR));
+        }
+#pragma unroll
+        for (int i = 0; i < XC; i++) {
+            const int chunk = tid + 512 * i;
+            const int yi = pyi[i] + kh, xi = pxi[i] + kw;
+            xr[i] = sd_f4{0.f, 0.f, 0.f, 0.f};
+            if (pok[i] && yi >= 0 && yi < A.H && xi >= 0 && xi < A.W)
+                xr[i] = *(const sd_f4*)(A.in + (pbase[i] + (size_t)yi * A.W + xi) * A.cinStride + c0 + 4 * (chunk % CPR));
+        }
+        c0 += BK;
+        if (c0 == A.cin) { c0 = 0; t++; kw++; if (kw == A.ksize) { kw = 0; kh++; } }
+    };
+    fetch();
+    for (int ks = 0; ks < ksteps; ks++) {
+#pragma unroll
+        for (int i = 0; i < WC; i++) { const int chunk = tid + 512 * i; if (chunk < SD_F32_BM * CPR) *(sd_f4*)(sW + (chunk / CPR) * LD + 4 * (chunk % CPR)) = wr[i]; }
+#pragma unroll
+        for (int i = 0; i < XC; i++) { const int chunk = tid + 512 * i; if (chunk < SD_F32_BN * CPR) *(sd_f4*)(sX + (chunk / CPR) * LD + 4 * (chunk % CPR)) = xr[i]; }
+        __syncthreads();
+        if (ks + 1 < ksteps) fetch();                   // in flight during the MFMAs below
+#pragma unroll
+        for (int kc = 0; kc < BK / 8; kc++) {
+            sd_f4 a[2], b[2];
+#pragma unroll
+            for (int m = 0; m < 2; m++) a[m] = *(const sd_f4*)(sW + (64 * wm + 32 * m + r32) * LD + 8 * kc + 4 * h);
+#pragma unroll
+            for (int n = 0; n < 2; n++) b[n] = *(const sd_f4*)(sX + (64 * wn + 32 * n + r32) * LD + 8 * kc + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int n = 0; n < 2; n++)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][j], b[n][j], acc[m][n], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: D column = pixel (lane & 31), rows = filters (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+        const int p = pix0 + 64 * wn + 32 * n + r32;
+        if (p >= npix) continue;
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int co = co0 + 64 * wm + 32 * m + 8 * g + 4 * h;
+                if (co >= A.cout) continue;
+                sd_f4 v;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float x = acc[m][n][4 * g + e] + A.bias[co + e];            // bias rows are padded to the filter tile
+                    if (A.leaky) x = x > 0.f ? x : 0.1f * x;
+                    v[e] = x;
+                }
+                if (A.res) {
+                    const sd_f4 rr = *(const sd_f4*)(A.res + (size_t)p * A.resStride + co);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] += rr[e];
+                }
+                float* dst = A.out + (size_t)p * A.outStride + co;
+                if (co + 3 < A.cout) *(sd_f4*)dst = v;
+                else for (int e = 0; e < 4 && co + e < A.cout; e++) dst[e] = v[e];
+            }
+    }
+}
+
+// blobFromImage as k_blob_from_image, NHWC f32 with 8 channels (R, G, B after swapRB, then zeros)
+__global__ void __launch_bounds__(256) k_blob_from_image_f32(const uint8_t* __restrict__ src, int sw, int sh, size_t sstride, size_t spitch,
+                                                             const short4* __restrict__ ct, const short4* __restrict__ rt,
+                                                             float* __restrict__ dst, int dw, int dh, int swapRB)
+{
+    const int img = blockIdx.z;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= dw || y >= dh) return;
+    const short4 ce = ct[x], re = rt[y];
+    const int sx = ce.x, sx1 = min(sx + 1, sw - 1);
+    const int r0 = min(max((int)re.x, 0), sh - 1), r1 = min(max((int)re.x + 1, 0), sh - 1);
+    const uint8_t* S0 = src + (size_t)img * spitch + (size_t)r0 * sstride;
+    const uint8_t* S1 = src + (size_t)img * spitch + (size_t)r1 * sstride;
+    float ch[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int h0 = S0[3 * sx + c] * ce.y + S0[3 * sx1 + c] * ce.z;
+        const int h1 = S1[3 * sx + c] * ce.y + S1[3 * sx1 + c] * ce.z;
+        const int v = ((((int)re.y * (h0 >> 4)) >> 16) + (((int)re.z * (h1 >> 4)) >> 16) + 2) >> 2;
+        ch[c] = (float)(v & 255) * (float)(1 / 255.0);
+    }
+    float* o = dst + ((size_t)img * dh * dw + (size_t)y * dw + x) * 8;
+    *(sd_f4*)o = sd_f4{swapRB ? ch[2] : ch[0], ch[1], swapRB ? ch[0] : ch[2], 0.f};
+    *(sd_f4*)(o + 4) = sd_f4{0.f, 0.f, 0.f, 0.f};
+}

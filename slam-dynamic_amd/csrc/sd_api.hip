@@ -1926,8 +1926,15 @@ static void yolo_free(sd_yolo* y)
 int sd_yolo_create(sd_yolo** out, const sd_yolo_layer* layers, int n_layers, const float anchors[18], int classes, int net_w,
                    int net_h, int max_batch)
 {
+    return sd_yolo_create_prec(out, layers, n_layers, anchors, classes, net_w, net_h, max_batch, SD_YOLO_F16);
+}
+
+int sd_yolo_create_prec(sd_yolo** out, const sd_yolo_layer* layers, int n_layers, const float anchors[18], int classes, int net_w,
+                        int net_h, int max_batch, int precision)
+{
     if (!out) return SD_ERR_INVALID;
     *out = nullptr;
+    if (precision != SD_YOLO_F16 && precision != SD_YOLO_F32) return set_err(SD_ERR_INVALID, "precision must be SD_YOLO_F16 or SD_YOLO_F32");
     if (!layers || n_layers < 1 || !anchors || classes != 80 || net_w < 32 || net_h < 32 || (net_w % 32) || (net_h % 32) || max_batch < 1)
         return set_err(SD_ERR_INVALID, "bad detector arguments (classes must be 80, net size a multiple of 32)");
     int ndev = 0;
@@ -1936,6 +1943,8 @@ int sd_yolo_create(sd_yolo** out, const sd_yolo_layer* layers, int n_layers, con
     y->L.assign(layers, layers + n_layers);
     y->R.resize(n_layers);
     y->netW = net_w; y->netH = net_h; y->classes = classes; y->maxBatch = max_batch;
+    y->f32 = precision == SD_YOLO_F32;
+    const size_t eb = y->f32 ? 4 : 2;                     // bytes per activation element
     memcpy(y->anchors, anchors, sizeof(y->anchors));
     // ---- shapes
     int H = net_h, W = net_w, C = 32;      // blob: 3 channels padded to 32
@@ -1992,11 +2001,13 @@ int sd_yolo_create(sd_yolo** out, const sd_yolo_layer* layers, int n_layers, con
     };
     bool ok = true;
     const size_t nB = (size_t)max_batch;
-    ok = ok && alloc((void**)&y->d_blob4, nB * net_h * net_w * 4 * 2);
+    if (y->f32) ok = ok && alloc((void**)&y->d_blob8, nB * net_h * net_w * 8 * 4);
+    else ok = ok && alloc((void**)&y->d_blob4, nB * net_h * net_w * 4 * 2);
     ok = ok && alloc((void**)&y->d_zero, 256);
     if (ok) ok = hipMemset(y->d_zero, 0, 256) == hipSuccess;
 
-    ok = ok && alloc((void**)&y->d_wgt, wOff * 2 + 64);
+    if (y->f32) ok = ok && alloc((void**)&y->d_wgt32, wOff * 4 + 64);
+    else ok = ok && alloc((void**)&y->d_wgt, wOff * 2 + 64);
     ok = ok && alloc((void**)&y->d_bias, bOff * 4 + 64);
     ok = ok && alloc((void**)&y->d_dets, nB * y->detCap * sizeof(SdDet));
     ok = ok && alloc((void**)&y->d_ndet, nB * 4);
@@ -2007,8 +2018,8 @@ int sd_yolo_create(sd_yolo** out, const sd_yolo_layer* layers, int n_layers, con
         const sd_yolo_layer& l = y->L[i];
         sd_yolo::Rt& r = y->R[i];
         if (l.type == SD_YOLO_CONV) {
-            ok = alloc((void**)&r.out, nB * r.H * r.W * r.outC * 2 + 64);
-            if (ok && r.outC != r.C) ok = hipMemset(r.out, 0, nB * r.H * r.W * r.outC * 2) == hipSuccess;
+            ok = alloc((void**)&r.out, nB * r.H * r.W * r.outC * eb + 64);
+            if (ok && r.outC != r.C) ok = hipMemset(r.out, 0, nB * r.H * r.W * r.outC * eb) == hipSuccess;
         } else if (l.type == SD_YOLO_SHORTCUT) {
             // fused into the preceding convolution's epilogue when that output has no other consumer
             bool fuse = i > 0 && y->L[i - 1].type == SD_YOLO_CONV && yolo_resolve(i, l.from[0]) != i - 1;
@@ -2019,11 +2030,11 @@ int sd_yolo_create(sd_yolo** out, const sd_yolo_layer* layers, int n_layers, con
                     for (int k = 0; k < o.nfrom; k++) if (yolo_resolve(j, o.from[k]) == i - 1) fuse = false;
             }
             if (fuse) { r.out = y->R[i - 1].out; r.alias = true; }
-            else ok = alloc((void**)&r.out, nB * r.H * r.W * r.outC * 2 + 64);
+            else ok = alloc((void**)&r.out, nB * r.H * r.W * r.outC * eb + 64);
         } else if (l.type == SD_YOLO_ROUTE && l.nfrom == 1) {
             r.out = y->R[yolo_resolve(i, l.from[0])].out; r.alias = true; r.outC = y->R[yolo_resolve(i, l.from[0])].outC;
         } else if (l.type == SD_YOLO_ROUTE) {
-            ok = alloc((void**)&r.out, nB * r.H * r.W * r.outC * 2 + 64);
+            ok = alloc((void**)&r.out, nB * r.H * r.W * r.outC * eb + 64);
         } else if (l.type == SD_YOLO_UPSAMPLE) {
             // materialised only inside the following 2-input route (k_upsample_concat); stand-alone upsample unsupported
             if (!(i + 1 < n_layers && y->L[i + 1].type == SD_YOLO_ROUTE && y->L[i + 1].nfrom == 2 && yolo_resolve(i + 1, y->L[i + 1].from[0]) == i)) {
@@ -2064,6 +2075,34 @@ int sd_yolo_load_darknet_weights(sd_yolo* y, const float* p, size_t n_floats)
     size_t need = 0;
     sd_yolo_weight_count(y, &need);
     if (n_floats != need) return set_err(SD_ERR_INVALID, "weight payload has " + std::to_string(n_floats) + " floats, the network needs " + std::to_string(need));
+    if (y->f32) {
+        // f32 mode: [coutPad][taps][cinPad] f32 (the first layer's 3 input channels sit in a K chunk of 8), batch-norm folded in f32
+        std::vector<float> w32(y->wTotal, 0.f);
+        std::vector<float> b32(y->bTotal, 0.f);
+        const float* q = p;
+        for (size_t i = 0; i < y->L.size(); i++) {
+            const sd_yolo_layer& l = y->L[i];
+            if (l.type != SD_YOLO_CONV) continue;
+            const sd_yolo::Rt& r = y->R[i];
+            const int cin = i == 0 ? 3 : r.cinPad, cinP = i == 0 ? 8 : r.cinPad, F = l.filters, taps = l.size * l.size;
+            const float* biases = q; q += F;
+            const float *scales = nullptr, *mean = nullptr, *var = nullptr;
+            if (l.batch_normalize) { scales = q; q += F; mean = q; q += F; var = q; q += F; }
+            const float* wt = q; q += (size_t)F * cin * taps;
+            for (int f = 0; f < F; f++) {
+                float sc = 1.f, bias = biases[f];
+                if (l.batch_normalize) { sc = scales[f] / sqrtf(var[f] + 0.000001f); bias = biases[f] - mean[f] * sc; }
+                b32[r.bOff + f] = bias;
+                for (int c = 0; c < cin; c++)
+                    for (int t = 0; t < taps; t++)
+                        w32[r.wOff + ((size_t)f * taps + t) * cinP + c] = wt[((size_t)f * cin + c) * taps + t] * sc;
+            }
+        }
+        HIPCHK(hipMemcpy(y->d_wgt32, w32.data(), y->wTotal * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(y->d_bias, b32.data(), y->bTotal * 4, hipMemcpyHostToDevice));
+        y->weightsLoaded = true;
+        return SD_OK;
+    }
     std::vector<_Float16> w(y->wTotal, (_Float16)0.f);
     std::vector<float> b(y->bTotal, 0.f);
     for (size_t i = 0; i < y->L.size(); i++) {
@@ -2112,6 +2151,67 @@ int sd_yolo_flops(const sd_yolo* y, double* flops_per_image)
     return SD_OK;
 }
 
+// The forward pass in f32 (k_yolo32.h): same graph walk, one generic convolution kernel, f32 activations.
+static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int height, size_t stride, size_t image_pitch, int n,
+                            float conf_threshold, hipStream_t s)
+{
+    {
+        dim3 blk(64, 4), grd((y->netW + 63) / 64, (y->netH + 3) / 4, n);
+        hipLaunchKernelGGL(k_blob_from_image_f32, grd, blk, 0, s, d_bgr, width, height, stride, image_pitch, y->d_ct, y->d_rt, y->d_blob8, y->netW, y->netH, 1);
+    }
+    LAUNCH_CHECK("k_blob_from_image_f32");
+    HIPCHK(hipMemsetAsync(y->d_ndet, 0, (size_t)n * 4, s));
+    const int lds32 = (SD_F32_BM + SD_F32_BN) * 36 * 4, lds8 = (SD_F32_BM + SD_F32_BN) * 12 * 4;
+    if (!y->attrF32) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds32));
+        y->attrF32 = true;
+    }
+    const float* cur = y->d_blob8;
+    int H = y->netH, W = y->netW, Cs = 8;
+    int rowBase = 0;
+    for (size_t i = 0; i < y->L.size(); i++) {
+        const sd_yolo_layer& l = y->L[i];
+        const sd_yolo::Rt& r = y->R[i];
+        if (l.type == SD_YOLO_CONV) {
+            SdConvArgsF A;
+            A.in = cur; A.wgt = y->d_wgt32 + r.wOff; A.bias = y->d_bias + r.bOff; A.res = nullptr; A.out = (float*)r.out;
+            A.N = n; A.H = H; A.W = W; A.cin = i == 0 ? 8 : r.cinPad; A.cinStride = Cs;
+            A.Ho = r.H; A.Wo = r.W; A.cout = l.filters; A.outStride = r.outC; A.resStride = 0;
+            A.ksize = l.size; A.stride = l.stride; A.pad = l.size / 2; A.leaky = l.leaky;
+            if (i + 1 < y->L.size() && y->L[i + 1].type == SD_YOLO_SHORTCUT && y->R[i + 1].alias) {
+                const int f = yolo_resolve((int)i + 1, y->L[i + 1].from[0]);
+                A.res = (const float*)y->R[f].out; A.resStride = y->R[f].outC;
+            }
+            const int npix = n * r.H * r.W;
+            const dim3 grd((npix + SD_F32_BN - 1) / SD_F32_BN, r.coutPad / SD_F32_BM);
+            if (i == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<8>), grd, dim3(512), lds8, s, A);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<32>), grd, dim3(512), lds32, s, A);
+            LAUNCH_CHECK("k_conv_f32");
+        } else if (l.type == SD_YOLO_SHORTCUT) {
+            if (!r.alias) return set_err(SD_ERR_UNSUPPORTED, "unfused [shortcut] is not implemented");
+        } else if (l.type == SD_YOLO_ROUTE && l.nfrom == 2) {
+            const int fa = yolo_resolve((int)i, l.from[0]), fb = yolo_resolve((int)i, l.from[1]);
+            const int src = yolo_resolve(fa, -1);
+            const sd_yolo::Rt& ra = y->R[src]; const sd_yolo::Rt& rb = y->R[fb];
+            if (ra.outC != ra.C || rb.outC != rb.C || (ra.C % 4) || (rb.C % 4)) return set_err(SD_ERR_UNSUPPORTED, "route inputs must be dense, channels % 4 == 0");
+            // the copy kernel moves 16-byte pieces: an f32 channel counts as two halfs
+            hipLaunchKernelGGL(k_upsample_concat, dim3(2048), dim3(256), 0, s, ra.out, 2 * ra.C, ra.H, ra.W, rb.out, 2 * rb.C, r.out, n);
+            LAUNCH_CHECK("k_upsample_concat");
+        } else if (l.type == SD_YOLO_YOLO) {
+            const float* an = y->anchors;
+            const int rows = n * r.H * r.W * 3;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_region_decode<float>), dim3((rows + 255) / 256), dim3(256), 0, s, (const float*)r.out, r.outC, r.H, r.W, n, an[2 * l.mask[0]],
+                               an[2 * l.mask[0] + 1], an[2 * l.mask[1]], an[2 * l.mask[1] + 1], an[2 * l.mask[2]], an[2 * l.mask[2] + 1],
+                               y->netW, y->netH, conf_threshold, rowBase, y->d_dets, y->d_ndet, y->detCap, n == 1 ? y->d_raw : nullptr);
+            LAUNCH_CHECK("k_region_decode");
+            rowBase += r.H * r.W * 3;
+        }
+        if (l.type != SD_YOLO_YOLO && l.type != SD_YOLO_UPSAMPLE) { cur = (const float*)r.out; H = r.H; W = r.W; Cs = r.outC; }
+        if (l.type == SD_YOLO_YOLO) { cur = (const float*)r.out; }
+    }
+    return SD_OK;
+}
+
 int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int height, size_t stride, size_t image_pitch, int n,
                            float conf_threshold, void* stream_)
 {
@@ -2124,6 +2224,13 @@ int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int heig
         HIPCHK(hipMemcpy(y->d_ct, ct.data(), ct.size() * 2, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(y->d_rt, rt.data(), rt.size() * 2, hipMemcpyHostToDevice));
         y->tabW = width; y->tabH = height;
+    }
+    if (y->f32) {
+        int rc = yolo_forward_f32(y, d_bgr, width, height, stride, image_pitch, n, conf_threshold, s);
+        if (rc != SD_OK) return rc;
+        y->lastN = n;
+        if (!stream_) HIPCHK(hipStreamSynchronize(s));
+        return SD_OK;
     }
     {
         dim3 blk(64, 4), grd((y->netW + 63) / 64, (y->netH + 3) / 4, n);
@@ -2200,7 +2307,7 @@ int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int heig
         } else if (l.type == SD_YOLO_YOLO) {
             const float* an = y->anchors;
             const int rows = n * r.H * r.W * 3;
-            hipLaunchKernelGGL(k_region_decode, dim3((rows + 255) / 256), dim3(256), 0, s, r.out, r.outC, r.H, r.W, n, an[2 * l.mask[0]],
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_region_decode<_Float16>), dim3((rows + 255) / 256), dim3(256), 0, s, (const _Float16*)r.out, r.outC, r.H, r.W, n, an[2 * l.mask[0]],
                                an[2 * l.mask[0] + 1], an[2 * l.mask[1]], an[2 * l.mask[1] + 1], an[2 * l.mask[2]], an[2 * l.mask[2] + 1],
                                y->netW, y->netH, conf_threshold, rowBase, y->d_dets, y->d_ndet, y->detCap, n == 1 ? y->d_raw : nullptr);
             LAUNCH_CHECK("k_region_decode");
@@ -2221,12 +2328,20 @@ int sd_yolo_download_layer(sd_yolo* y, int layer, int image, uint16_t* out)
     const sd_yolo::Rt& r = y->R[layer];
     if (!r.out) return set_err(SD_ERR_INVALID, "layer has no materialised output");
     HIPCHK(hipDeviceSynchronize());
-    const size_t pix = (size_t)r.H * r.W;
+    const size_t pix = (size_t)r.H * r.W, eb = y->f32 ? 4 : 2;       // f32 mode: `out` receives floats
+    const unsigned char* src = (const unsigned char*)r.out + (size_t)image * pix * r.outC * eb;
     if (r.outC == r.C) {
-        HIPCHK(hipMemcpy(out, r.out + (size_t)image * pix * r.outC, pix * r.C * 2, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out, src, pix * r.C * eb, hipMemcpyDeviceToHost));
     } else {
-        HIPCHK(hipMemcpy2D(out, (size_t)r.C * 2, r.out + (size_t)image * pix * r.outC, (size_t)r.outC * 2, (size_t)r.C * 2, pix, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy2D(out, (size_t)r.C * eb, src, (size_t)r.outC * eb, (size_t)r.C * eb, pix, hipMemcpyDeviceToHost));
     }
+    return SD_OK;
+}
+
+int sd_yolo_precision(const sd_yolo* y, int* precision)
+{
+    if (!y || !precision) return SD_ERR_INVALID;
+    *precision = y->f32 ? SD_YOLO_F32 : SD_YOLO_F16;
     return SD_OK;
 }
 

@@ -139,7 +139,7 @@ def synth_weights(layers, seed=7):
 class Detector:
     """yolov3Segment (include/yolo.h:22-48) on the GPU."""
 
-    def __init__(self, layers=None, anchors=None, net_w=640, net_h=480, max_batch=1):
+    def __init__(self, layers=None, anchors=None, net_w=640, net_h=480, max_batch=1, precision="f16"):
         L = fe.lib()
         if layers is None:
             layers, anchors = v3_layers()
@@ -147,7 +147,8 @@ class Detector:
         self.net_w, self.net_h = net_w, net_h
         self.h = C.c_void_p()
         vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
-        L.sd_yolo_create.argtypes = [C.POINTER(vp), vp, i, vp, i, i, i, i]
+        L.sd_yolo_create_prec.argtypes = [C.POINTER(vp), vp, i, vp, i, i, i, i, i]
+        self.precision = precision
         L.sd_yolo_destroy.argtypes = [vp]
         L.sd_yolo_weight_count.argtypes = [vp, C.POINTER(sz)]
         L.sd_yolo_load_darknet_weights.argtypes = [vp, vp, sz]
@@ -158,7 +159,8 @@ class Detector:
         L.sd_yolo_download_region.argtypes = [vp, vp, C.POINTER(i)]
         L.sd_yolo_boxes.argtypes = [vp, i, i, i, f, f, vp, vp, vp, i, C.POINTER(i)]
         L.sd_yolo_mask_device.argtypes = [vp, i, i, i, f, f, vp, sz, C.POINTER(i), vp]
-        fe.check(L.sd_yolo_create(C.byref(self.h), fe._p(self.layers), len(self.layers), fe._p(self.anchors), 80, net_w, net_h, max_batch))
+        fe.check(L.sd_yolo_create_prec(C.byref(self.h), fe._p(self.layers), len(self.layers), fe._p(self.anchors), 80, net_w, net_h, max_batch,
+                                       {"f16": 0, "f32": 1}[precision]))
 
     def close(self):
         if self.h:
@@ -191,7 +193,7 @@ class Detector:
 
     def layer_output(self, layer, image=0):
         h, w, c = self.layer_shape(layer)
-        out = np.zeros((h, w, c), np.float16)
+        out = np.zeros((h, w, c), np.float32 if self.precision == "f32" else np.float16)
         fe.check(fe.lib().sd_yolo_download_layer(self.h, layer, image, fe._p(out)))
         return out
 

@@ -6,9 +6,11 @@ import __graft_entry__ as g
 pkg = g.load_package(); synth = pkg.synth
 import torch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+PREC = sys.argv[2] if len(sys.argv) > 2 else "f16"
+PEAK = {"f16": 2500.0, "f32": 157.3}[PREC]
 layers, anchors = pkg.yolo.v3_layers()
 payload, _ = pkg.yolo.synth_weights(layers, seed=3)
-d = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=B)
+d = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=B, precision=PREC)
 d.load_weights(payload)
 cfg = synth.KITTI03_RGBD
 imgs = np.stack([np.ascontiguousarray(synth.rgbd_frame(6, t % 4, cfg)[0][:, :, ::-1]) for t in range(B)])
@@ -18,11 +20,11 @@ st = torch.cuda.current_stream().cuda_stream
 for _ in range(2):
     d.forward_device(dev.data_ptr(), W, H, W * 3, W * H * 3, B, 0.5, st)
 torch.cuda.synchronize()
-K = 20
+K = 20 if PREC == "f16" else 5
 t = time.time()
 for _ in range(K):
     d.forward_device(dev.data_ptr(), W, H, W * 3, W * H * 3, B, 0.5, st)
 torch.cuda.synchronize()
 dt = (time.time() - t) / K
 fl = d.flops()
-print("batch %d: %.2f ms/batch, %.1f images/s, %.1f TFLOP/s (%.1f%% of 2500 dense f16)" % (B, dt * 1e3, B / dt, fl * B / dt / 1e12, fl * B / dt / 2.5e15 * 100))
+print("%s batch %d: %.2f ms/batch, %.1f images/s, %.1f TFLOP/s (%.1f%% of the %.1f TFLOP/s dense %s MFMA peak)" % (PREC, B, dt * 1e3, B / dt, fl * B / dt / 1e12, fl * B / dt / (PEAK * 1e12) * 100, PEAK, PREC))
