@@ -43,7 +43,7 @@ import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming)
 MFMA_PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3}   # dense peaks, MI355X_MICROARCH.md
-WORKLOADS = ["stereo-yolo", "stereo", "rgbd", "rgbd-cull", "tum-mask", "kitti-batch"]
+WORKLOADS = ["stereo-yolo", "stereo-yolo-f16", "stereo", "rgbd", "rgbd-cull", "tum-mask", "kitti-batch"]
 
 
 # --------------------------------------------------------------------------- host logic (also used by CPU tests)
@@ -305,9 +305,10 @@ class Workload:
         self.torch = torch
         fe, synth = pkg.frontend, pkg.synth
         self.fe, self.synth, self.pkg, self.name, self.dev, self.dist, self.rank, self.world = fe, synth, pkg, name, dev, dist, rank, world
-        self.detector = name in ("stereo-yolo",)
-        self.with_boxes = name in ("stereo-yolo", "rgbd-cull", "tum-mask", "kitti-batch")
-        self.kind = "stereo" if name in ("stereo-yolo", "stereo", "kitti-batch") else "rgbd"
+        self.detector = name in ("stereo-yolo", "stereo-yolo-f16")
+        self.det_prec = "f16" if name == "stereo-yolo-f16" else "f32"      # f32 = the reference's arithmetic (cv::dnn on the CPU computes in f32)
+        self.with_boxes = name in ("stereo-yolo", "stereo-yolo-f16", "rgbd-cull", "tum-mask", "kitti-batch")
+        self.kind = "stereo" if name in ("stereo-yolo", "stereo-yolo-f16", "stereo", "kitti-batch") else "rgbd"
         self.cfg = synth.TUM3 if name == "tum-mask" else (synth.KITTI_STEREO if self.kind == "stereo" else synth.KITTI03_RGBD)
         self.sensor = fe.SENSOR_STEREO if self.kind == "stereo" else fe.SENSOR_RGBD
         self.ipl = 2 if self.kind == "stereo" else 1
@@ -338,7 +339,7 @@ class Workload:
         self.det = None
         if self.detector:
             layers, anchors = pkg.yolo.v3_layers()
-            self.det = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=self.S)
+            self.det = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=self.S, precision=self.det_prec)
             self.det.load_weights(pkg.yolo.synth_weights(layers, seed=3)[0])
             self.det_stream = torch.cuda.Stream(device=dev)
             self.det_in_flight = -1
@@ -537,10 +538,12 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline):
                     "front_end_kernels_ms_per_step": round(fe_ms, 4),
                     "front_end_algorithmic_GBs_while_running": round(alg["image_total"] * n_img / (fe_ms * 1e-3) / 1e9, 2),
                     "pipeline_achieved_GBs": round(alg["image_total"] * wl.ipl * out["value"] / world / 1e9, 2),
-                    "measured": "separate untimed pass of %d steps with hipEvents around every kernel on its own stream" % prof_steps}
+                    "measured": "separate untimed pass of %d steps with hipEvents around every kernel on its own stream" % prof_steps,
+                    "note": "the step is bound by the detector (MFMA block below): the front-end kernels run beside it on their own stream"
+                            if wl.det is not None else None}
             if det_ms is not None:
                 fl = wl.det.flops()
-                prec = pkg.yolo.detector_precision() if hasattr(pkg.yolo, "detector_precision") else "f16"
+                prec = wl.det_prec
                 tf = fl * wl.S / (det_ms * 1e-3) / 1e12
                 roof["detector"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS[prec], "unit": "TFLOP/s",
                                     "frac": round(tf / MFMA_PEAK_TFLOPS[prec], 4), "operands": prec, "images_per_s": round(wl.S / (det_ms * 1e-3), 1),
@@ -552,9 +555,11 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline):
 
 
 WORKLOAD_TEXT = {
-    "stereo-yolo": "KITTI stereo 1241x376 colour pairs, 2000 feat/image: YOLOv3 (640x480, synthetic weights) on the left image -> boxes -> TrackStereo = "
-                   "cvtColor + 2x ORB extract + stereo match + boxTrack + firstSeparate + TrackHomo (SearchByProjection vs the queued frame > 0.2 s back, H/F fit) + "
-                   "Separate + UpdateFrame + SearchByProjection vs the last frame (BASELINE configs[2])",
+    "stereo-yolo": "KITTI stereo 1241x376 colour pairs, 2000 feat/image: YOLOv3 (640x480, f32 as the reference's cv::dnn, synthetic weights) on the left image -> "
+                   "boxes -> TrackStereo = cvtColor + 2x ORB extract + stereo match + boxTrack + firstSeparate + TrackHomo (SearchByProjection vs the queued frame "
+                   "> 0.2 s back, H/F fit) + Separate + UpdateFrame + SearchByProjection vs the last frame (BASELINE configs[2])",
+    "stereo-yolo-f16": "the same chain with the detector in its throughput mode (f16 operands, f32 accumulation): its box sets differ from the f32 reference's "
+                       "(tests/test_gpu_yolo.py counts them), so this is NOT the parity configuration",
     "stereo": "KITTI stereo 1241x376 colour pairs, 2000 feat/image: cvtColor + 2x ORB extract + stereo match + projection match vs the last frame, no detector / boxes",
     "rgbd": "KITTI-03 RGB-D 1241x376, 2000 feat/frame: cvtColor + ORB extract + RGB-D stereo + projection match vs the last frame, no semantic mask (BASELINE configs[1])",
     "rgbd-cull": "KITTI-03 RGB-D 1241x376, 2000 feat/frame, 3 given boxes per frame: extract + match + boxTrack + firstSeparate + TrackHomo + Separate + UpdateFrame",
@@ -567,13 +572,13 @@ WORKLOAD_TEXT = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--lanes", "--batch", type=int, default=128, dest="lanes", help="independent camera streams per GPU = frames per step per GPU")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic sequences generated on the host (replicated over the lanes on the device)")
     ap.add_argument("--workload", choices=WORKLOADS, default="stereo-yolo")
     ap.add_argument("--extra", default="auto", help="comma-separated workloads also run (short) and reported under 'extra'; 'auto' = stereo,rgbd,rgbd-cull at N=1, none otherwise; 'none'")
-    ap.add_argument("--extra-steps", type=int, default=8)
+    ap.add_argument("--extra-steps", type=int, default=12)
     ap.add_argument("--kitti-frames", type=int, default=256)
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of host time for the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the separate per-kernel pass (no roofline block)")
@@ -643,7 +648,7 @@ def main():
     extras = {}
     names = []
     if args.extra == "auto":
-        names = [w for w in ("stereo", "rgbd", "rgbd-cull", "tum-mask") if w != args.workload] if world == 1 else []
+        names = [w for w in ("stereo-yolo-f16", "stereo", "rgbd", "rgbd-cull", "tum-mask") if w != args.workload] if world == 1 else []
     elif args.extra != "none":
         names = [w for w in args.extra.split(",") if w]
     for w in names:
@@ -668,10 +673,10 @@ def main():
             "metric": "tracking frames/sec (extract+match%s), %s %dx%d" % ("+dynamic-cull" if cull else "", "KITTI" if wl.cfg is not synth.TUM3 else "TUM3", wl.W, wl.H),
             "value": head["value"], "unit": "frames/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": head["steps"], "warmup": args.warmup if not wl.strong else 0,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong" if wl.strong else "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u8" + ("+" + wl.det_prec if wl.detector else ""), "data": "synthetic",
             "config": {"workload": text, "lanes_per_gpu": head["lanes_per_gpu"], "frames_per_step_per_gpu": head["lanes_per_gpu"], "images_per_frame": wl.ipl,
                        "distinct_sequences_per_gpu": wl.distinct, "timed_seconds": head["timed_s"], "frames_timed": head["frames"],
-                       "detector_operands": (pkg.yolo.detector_precision() if hasattr(pkg.yolo, "detector_precision") else "f16") if wl.detector else None,
+                       "detector_arithmetic": ("%s operands, f32 accumulation (v_mfma_f32_32x32x%s)" % (wl.det_prec, "2_f32" if wl.det_prec == "f32" else "16_f16")) if wl.detector else None,
                        "lane0_last_frame": head["lane0_last_frame"],
                        "sharding": ("independent lanes per rank, no data-path collective; per-step async gather of the result records to rank 0"
                                     if world > 1 else "single GPU")},

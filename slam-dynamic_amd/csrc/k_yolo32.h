@@ -6,8 +6,7 @@
 //   k_blob_from_image_f32   blobFromImage -> NHWC f32 x 8 channels (3 + 5 zeros: one K-chunk of the MFMA loop)
 //   k_conv_f32<BK>          implicit-GEMM convolution, 1x1 / 3x3, stride 1 / 2, + bias + leaky ReLU + shortcut
 // One f32 MFMA is 64 cycles for 4096 FLOPs and needs ONE float per operand per lane, so the kernel is MFMA-bound with a
-// plain structure: 128 filters x 256 pixels per workgroup (8 waves of 64 x 64), K walked in steps of BK channels of one
-// filter tap, the next step's tiles prefetched into registers while the 64 MFMAs of the current step run.  A lane reads
+// plain structure: 8 waves, K walked in steps of BK channels of one filter tap, tiles staged through registers into LDS.  A lane reads
 // its fragments as 16-byte pieces: half h of the wave takes floats [4h, 4h + 4) of an 8-wide K chunk, MFMA j of the chunk
 // uses element j on both operands -- which k a (half, j) pair stands for is immaterial as long as A and B agree.
 #pragma once
@@ -22,22 +21,26 @@ struct SdConvArgsF {
     int ksize, stride, pad, leaky;
 };
 
-#define SD_F32_BM 128
-#define SD_F32_BN 256
-
-template <int BK>
+// Tile shapes: WM waves along the filters x (8 / WM) waves along the pixels, a wave owns MT x 2 MFMA tiles (32 MT filters x 64
+// pixels).  <32, 2, 2>: 128 filters x 256 pixels (every layer with >= 128 filters); <16, 1, 2>: 64 x 512 and <16 | 8, 1, 1>:
+// 32 x 512 for the three 64- / 32-filter layers at 320 x 240 and the first layer, which would waste half or three quarters of a
+// 128-filter tile.  LDS holds TWO stages: while the MFMAs of stage s run, the tiles of stage s + 1 (fetched into registers one
+// step earlier) are written to the other buffer and the global loads of stage s + 2 are issued -- one barrier per step, and
+// neither the address arithmetic of the gather nor the LDS writes sit between two barriers with the MFMA pipe idle.
+template <int BK, int WM, int MT>
 __global__ void __launch_bounds__(512, 1) k_conv_f32(SdConvArgsF A)
 {
+    constexpr int WN = 8 / WM, BM = 32 * MT * WM, BN = 64 * WN;
     constexpr int LD = BK + 4;                          // LDS row length in floats (16-byte aligned rows, 2-way conflicts at worst)
     constexpr int CPR = BK / 4;                         // 16-byte chunks per row
-    constexpr int XC = (SD_F32_BN * CPR + 511) / 512;   // activation chunks per thread per step
-    constexpr int WC = (SD_F32_BM * CPR + 511) / 512;
+    constexpr int XC = (BN * CPR + 511) / 512;          // activation chunks per thread per step
+    constexpr int WC = (BM * CPR + 511) / 512;
+    constexpr int STAGE = (BM + BN) * LD;               // floats per stage
+    constexpr int NCH = BK / 8;                         // 8-wide K chunks per step
     extern __shared__ __align__(16) float smemf[];
-    float* sW = smemf;                                  // [128][LD]
-    float* sX = smemf + SD_F32_BM * LD;                 // [256][LD]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r32 = lane & 31, h = lane >> 5;
-    const int wm = wv & 1, wn = wv >> 1;                // wave tile: filters [64 wm, +64), pixels [64 wn, +64)
-    const int pix0 = blockIdx.x * SD_F32_BN, co0 = blockIdx.y * SD_F32_BM;
+    const int wm = wv % WM, wn = wv / WM;               // wave tile: filters [32 MT wm, +32 MT), pixels [64 wn, +64)
+    const int pix0 = blockIdx.x * BN, co0 = blockIdx.y * BM;
     const int npix = A.N * A.Ho * A.Wo;
     int pyi[XC], pxi[XC];
     size_t pbase[XC];
@@ -46,7 +49,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_f32(SdConvArgsF A)
     for (int i = 0; i < XC; i++) {
         const int chunk = tid + 512 * i;
         const int p = pix0 + chunk / CPR;
-        pok[i] = chunk < SD_F32_BN * CPR && p < npix;
+        pok[i] = chunk < BN * CPR && p < npix;
         const int pp = pok[i] ? p : 0;
         const int n = pp / (A.Ho * A.Wo), r = pp - n * (A.Ho * A.Wo);
         const int yo = r / A.Wo, xo = r - yo * A.Wo;
@@ -55,9 +58,9 @@ __global__ void __launch_bounds__(512, 1) k_conv_f32(SdConvArgsF A)
     }
     const int taps = A.ksize * A.ksize;
     const int ksteps = taps * (A.cin / BK);
-    sd_f16v acc[2][2];
+    sd_f16v acc[MT][2];
 #pragma unroll
-    for (int m = 0; m < 2; m++)
+    for (int m = 0; m < MT; m++)
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
@@ -69,7 +72,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_f32(SdConvArgsF A)
         for (int i = 0; i < WC; i++) {
             const int chunk = tid + 512 * i;
             wr[i] = sd_f4{0.f, 0.f, 0.f, 0.f};
-            if (chunk < SD_F32_BM * CPR) wr[i] = *(const sd_f4*)(A.wgt + ((size_t)(co0 + chunk / CPR) * taps + t) * A.cin + c0 + 4 * (chunk % CPR));
+            if (chunk < BM * CPR) wr[i] = *(const sd_f4*)(A.wgt + ((size_t)(co0 + chunk / CPR) * taps + t) * A.cin + c0 + 4 * (chunk % CPR));
         }
 #pragma unroll
         for (int i = 0; i < XC; i++) {
@@ -82,53 +85,84 @@ __global__ void __launch_bounds__(512, 1) k_conv_f32(SdConvArgsF A)
         c0 += BK;
         if (c0 == A.cin) { c0 = 0; t++; kw++; if (kw == A.ksize) { kw = 0; kh++; } }
     };
+    auto store = [&](int buf) {
+        float* sW = smemf + buf * STAGE;
+        float* sX = sW + BM * LD;
+#pragma unroll
+        for (int i = 0; i < WC; i++) { const int chunk = tid + 512 * i; if (chunk < BM * CPR) *(sd_f4*)(sW + (chunk / CPR) * LD + 4 * (chunk % CPR)) = wr[i]; }
+#pragma unroll
+        for (int i = 0; i < XC; i++) { const int chunk = tid + 512 * i; if (chunk < BN * CPR) *(sd_f4*)(sX + (chunk / CPR) * LD + 4 * (chunk % CPR)) = xr[i]; }
+    };
+    const int aoff = (32 * MT * wm + r32) * LD + 4 * h, boff = BM * LD + (64 * wn + r32) * LD + 4 * h;
+    sd_f4 fa[2][MT], fb[2][2];                          // fragments of two consecutive K chunks: the reads of chunk c + 1 are issued before the MFMAs of chunk c
+    auto frags = [&](int buf, int kc, int slot) {
+        const float* base = smemf + buf * STAGE;
+#pragma unroll
+        for (int m = 0; m < MT; m++) fa[slot][m] = *(const sd_f4*)(base + aoff + 32 * m * LD + 8 * kc);
+#pragma unroll
+        for (int n = 0; n < 2; n++) fb[slot][n] = *(const sd_f4*)(base + boff + 32 * n * LD + 8 * kc);
+    };
+    auto mfmas = [&](int slot) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int n = 0; n < 2; n++)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][m][j], fb[slot][n][j], acc[m][n], 0, 0, 0);
+    };
+    // The two waves that share a SIMD (w and w + 4) do their staging at DIFFERENT K chunks of a step: the ~150 address / LDS-write
+    // instructions of one wave then run under the other wave's MFMAs instead of both leaving the MFMA pipe idle together.
+    const int myslot = NCH >= 4 ? 2 * (wv >> 2) : (NCH == 2 ? (wv >> 2) : 0);
     fetch();
+    store(0);
+    if (ksteps > 1) fetch();
+    __syncthreads();
     for (int ks = 0; ks < ksteps; ks++) {
+        const int cur = ks & 1;
+        frags(cur, 0, 0);
 #pragma unroll
-        for (int i = 0; i < WC; i++) { const int chunk = tid + 512 * i; if (chunk < SD_F32_BM * CPR) *(sd_f4*)(sW + (chunk / CPR) * LD + 4 * (chunk % CPR)) = wr[i]; }
-#pragma unroll
-        for (int i = 0; i < XC; i++) { const int chunk = tid + 512 * i; if (chunk < SD_F32_BN * CPR) *(sd_f4*)(sX + (chunk / CPR) * LD + 4 * (chunk % CPR)) = xr[i]; }
-        __syncthreads();
-        if (ks + 1 < ksteps) fetch();                   // in flight during the MFMAs below
-#pragma unroll
-        for (int kc = 0; kc < BK / 8; kc++) {
-            sd_f4 a[2], b[2];
-#pragma unroll
-            for (int m = 0; m < 2; m++) a[m] = *(const sd_f4*)(sW + (64 * wm + 32 * m + r32) * LD + 8 * kc + 4 * h);
-#pragma unroll
-            for (int n = 0; n < 2; n++) b[n] = *(const sd_f4*)(sX + (64 * wn + 32 * n + r32) * LD + 8 * kc + 4 * h);
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int m = 0; m < 2; m++)
-#pragma unroll
-                    for (int n = 0; n < 2; n++)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][j], b[n][j], acc[m][n], 0, 0, 0);
+        for (int kc = 0; kc < NCH; kc++) {
+            if (kc + 1 < NCH) frags(cur, kc + 1, (kc + 1) & 1);
+            mfmas(kc & 1);
+            if (kc == myslot) {                         // next stage into the other buffer, stage s + 2 requested
+                if (ks + 1 < ksteps) store(cur ^ 1);
+                if (ks + 2 < ksteps) fetch();
+            }
         }
         __syncthreads();
     }
-    // ---- epilogue: D column = pixel (lane & 31), rows = filters (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    // ---- epilogue: D column = pixel (lane & 31), rows = filters (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  All shortcut reads are
+    // requested before the first one is used (one memory round trip, not one per 16-byte piece).
+    sd_f4 rr[2][MT][4];
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+        const int p = pix0 + 64 * wn + 32 * n + r32;
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int co = co0 + 32 * MT * wm + 32 * m + 8 * g + 4 * h;
+                rr[n][m][g] = sd_f4{0.f, 0.f, 0.f, 0.f};
+                if (A.res && p < npix && co < A.cout) rr[n][m][g] = *(const sd_f4*)(A.res + (size_t)p * A.resStride + co);
+            }
+    }
 #pragma unroll
     for (int n = 0; n < 2; n++) {
         const int p = pix0 + 64 * wn + 32 * n + r32;
         if (p >= npix) continue;
 #pragma unroll
-        for (int m = 0; m < 2; m++)
+        for (int m = 0; m < MT; m++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                const int co = co0 + 64 * wm + 32 * m + 8 * g + 4 * h;
+                const int co = co0 + 32 * MT * wm + 32 * m + 8 * g + 4 * h;
                 if (co >= A.cout) continue;
                 sd_f4 v;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     float x = acc[m][n][4 * g + e] + A.bias[co + e];            // bias rows are padded to the filter tile
                     if (A.leaky) x = x > 0.f ? x : 0.1f * x;
-                    v[e] = x;
-                }
-                if (A.res) {
-                    const sd_f4 rr = *(const sd_f4*)(A.res + (size_t)p * A.resStride + co);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] += rr[e];
+                    v[e] = x + rr[n][m][g][e];
                 }
                 float* dst = A.out + (size_t)p * A.outStride + co;
                 if (co + 3 < A.cout) *(sd_f4*)dst = v;
@@ -136,6 +170,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_f32(SdConvArgsF A)
             }
     }
 }
+#define SD_F32_LDS(BK, WM, MT) (2 * (32 * (MT) * (WM) + 64 * (8 / (WM))) * ((BK) + 4) * 4)
 
 // blobFromImage as k_blob_from_image, NHWC f32 with 8 channels (R, G, B after swapRB, then zeros)
 __global__ void __launch_bounds__(256) k_blob_from_image_f32(const uint8_t* __restrict__ src, int sw, int sh, size_t sstride, size_t spitch,

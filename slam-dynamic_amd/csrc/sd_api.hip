@@ -2161,9 +2161,11 @@ static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int hei
     }
     LAUNCH_CHECK("k_blob_from_image_f32");
     HIPCHK(hipMemsetAsync(y->d_ndet, 0, (size_t)n * 4, s));
-    const int lds32 = (SD_F32_BM + SD_F32_BN) * 36 * 4, lds8 = (SD_F32_BM + SD_F32_BN) * 12 * 4;
     if (!y->attrF32) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds32));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<32, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(32, 2, 2)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<16, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(16, 1, 2)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<16, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(16, 1, 1)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<8, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(8, 1, 1)));
         y->attrF32 = true;
     }
     const float* cur = y->d_blob8;
@@ -2183,9 +2185,14 @@ static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int hei
                 A.res = (const float*)y->R[f].out; A.resStride = y->R[f].outC;
             }
             const int npix = n * r.H * r.W;
-            const dim3 grd((npix + SD_F32_BN - 1) / SD_F32_BN, r.coutPad / SD_F32_BM);
-            if (i == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<8>), grd, dim3(512), lds8, s, A);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<32>), grd, dim3(512), lds32, s, A);
+            if (i == 0)                         // 3 (-> 8) input channels, <= 32 filters
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<8, 1, 1>), dim3((npix + 511) / 512, (l.filters + 31) / 32), dim3(512), SD_F32_LDS(8, 1, 1), s, A);
+            else if (l.filters <= 32)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 1>), dim3((npix + 511) / 512, 1), dim3(512), SD_F32_LDS(16, 1, 1), s, A);
+            else if (l.filters <= 64)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 2>), dim3((npix + 511) / 512, 1), dim3(512), SD_F32_LDS(16, 1, 2), s, A);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<32, 2, 2>), dim3((npix + 255) / 256, r.coutPad / 128), dim3(512), SD_F32_LDS(32, 2, 2), s, A);
             LAUNCH_CHECK("k_conv_f32");
         } else if (l.type == SD_YOLO_SHORTCUT) {
             if (!r.alias) return set_err(SD_ERR_UNSUPPORTED, "unfused [shortcut] is not implemented");
