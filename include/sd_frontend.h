@@ -382,6 +382,12 @@ int sd_tracker_batch(sd_tracker* t, sd_batch** b); /* the workspace that holds t
 int sd_tracker_track(sd_tracker* t, const uint8_t* d_images, size_t stride, size_t image_pitch, const uint16_t* d_depth,
                      size_t depth_stride_elems, size_t depth_pitch_elems, const double* boxes, const int32_t* n_boxes,
                      const double* timestamps, const float* Tcw, const float* Twc, sd_lane_result* results, void* stream);
+/* The same from host images (a per-frame caller such as System::TrackStereo): images[s * images_per_lane + k] points to image k
+ * of lane s in host memory (rows `stride` bytes apart), depth[s] to lane s's CV_16U depth image (RGB-D).  Uploads, then
+ * sd_tracker_track. */
+int sd_tracker_track_host(sd_tracker* t, const uint8_t* const* images, size_t stride, const uint16_t* const* depth,
+                          size_t depth_stride_elems, const double* boxes, const int32_t* n_boxes, const double* timestamps,
+                          const float* Tcw, const float* Twc, sd_lane_result* results);
 /* Batch copy of frame slots (Frame's copy constructor, src/Frame.cc:39-63) in one launch: slot src[i] -> dst[i]. */
 int sd_batch_copy_frames(sd_batch* b, int n, const int32_t* src, const int32_t* dst, void* stream);
 

@@ -1,0 +1,291 @@
+// Header-only mirror of the reference's FRAME-LEVEL class API over the C ABI (include/sd_frontend.h, sd_tracker_*):
+//   ORB_SLAM2::Frame      include/Frame.h:46-238   the five constructors' results as the same public data members
+//   ORB_SLAM2::Tracking   include/Tracking.h:65-70 GrabImageStereo / GrabImageRGBD / GrabImageMonocular (+ the overloads with
+//                         boxes / mask), the dynamic block of Track_new (src/Tracking.cc:620-666) and q_frame / mLastFrame
+//   ORB_SLAM2::System     include/System.h:66-79   TrackStereo / TrackRGBD / TrackMonocular with the reference's argument lists
+// What is NOT here is the SLAM back end (pose tracking, local mapping, loop closing): System::Track* returns the pose the
+// caller predicted (identity by default) -- a maintainer keeps their own System / Tracking and swaps the Frame construction
+// and the dynamic block for this front end.
+//
+// Images, rectangles and key points are template parameters with the member names OpenCV uses, so the SAME code path serves
+//   * cv::Mat / cv::Rect2d / cv::KeyPoint in a build that has OpenCV (nothing else is needed: cv::Mat has .data .cols .rows
+//     .step .channels(), cv::Rect2d has .x .y .width .height, cv::KeyPoint is layout-compatible with sd_keypoint), and
+//   * sdfe::Image / sdfe::Rect2d / sd_keypoint in this image, where OpenCV does not exist (tests/cpp/frame_mirror_main.cpp).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "ORBextractor.h"
+
+#define FRAME_GRID_ROWS 48      // include/Frame.h:39-40
+#define FRAME_GRID_COLS 64
+
+namespace sdfe {
+struct Rect2d { double x = 0, y = 0, width = 0, height = 0; };
+struct Point2d { double x = 0, y = 0; };
+struct Image {                  // the subset of cv::Mat this path reads
+    const uint8_t* data = nullptr;
+    int cols = 0, rows = 0, nch = 1;
+    size_t step = 0;            // bytes per row
+    int elem = 1;               // bytes per channel element (2 for a CV_16U depth map)
+    int channels() const { return nch; }
+    bool empty() const { return !data || cols <= 0 || rows <= 0; }
+};
+struct Pose { float m[16]; Pose() { for (int i = 0; i < 16; i++) m[i] = (i % 5 == 0) ? 1.f : 0.f; } bool empty() const { return false; } };
+struct Settings {               // the YAML entries Tracking::Tracking reads (src/Tracking.cc:56-150)
+    float fx = 0, fy = 0, cx = 0, cy = 0, k1 = 0, k2 = 0, p1 = 0, p2 = 0, k3 = 0, bf = 0, fps = 30, ThDepth = 40, DepthMapFactor = 1;
+    int RGB = 1, width = 0, height = 0;
+    int nFeatures = 1000, nLevels = 8, iniThFAST = 20, minThFAST = 7;
+    float scaleFactor = 1.2f;
+};
+}  // namespace sdfe
+
+namespace ORB_SLAM2 {
+
+class Frame {
+public:
+    Frame() {}
+    // Frame members (include/Frame.h:113-210), filled by Tracking::GrabImage* below
+    double mTimeStamp = 0;
+    float fx = 0, fy = 0, cx = 0, cy = 0, invfx = 0, invfy = 0, mbf = 0, mb = 0, mThDepth = 0;
+    std::vector<sdfe::Rect2d> objects;
+    std::vector<int> box_idx, box_status;          // box_status: 0 / 2 dynamic, -1 untouched (Tracking.cc:1093-1239)
+    std::vector<sdfe::Point2d> box_velocity;
+    std::vector<bool> omit;
+    int N = 0, N_ori = 0, N_d = 0;
+    std::vector<sd_keypoint> mvKeys, mvKeysUn;     // cv::KeyPoint layout
+    std::vector<std::vector<sd_keypoint>> mvdynKeys, mvdynKeysUn;
+    std::vector<float> mvuRight, mvDepth;
+    std::vector<std::vector<float>> mvudynRight, mvdynDepth;
+    std::vector<uint8_t> mDescriptors;             // N rows of 32 bytes (cv::Mat N x 32 CV_8U)
+    std::vector<std::vector<uint8_t>> mdynDescriptors;
+    std::vector<bool> mvbOutlier;
+    float mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
+    std::vector<std::size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
+    sdfe::Pose mTcw;
+    long unsigned int mnId = 0;
+    int mnScaleLevels = 0;
+    float mfScaleFactor = 0, mfLogScaleFactor = 0;
+    std::vector<float> mvScaleFactors, mvInvScaleFactors, mvLevelSigma2, mvInvLevelSigma2;
+    float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0;
+    // results of Track_new's dynamic block for this frame
+    int mnTrackHomoFlag = 0, mnSeparateRet = 0, mnRefFrameId = -1, mnTrackMatches = 0, mnLastMatches = -1;
+
+    // Frame::GetFeaturesInArea (src/Frame.cc:735-788) on the host copy of the grid
+    std::vector<size_t> GetFeaturesInArea(const float& x, const float& y, const float& r, const int minLevel = -1, const int maxLevel = -1) const
+    {
+        std::vector<size_t> vIndices;
+        vIndices.reserve(N);
+        const int nMinCellX = std::max(0, (int)std::floor((x - mnMinX - r) * mfGridElementWidthInv));
+        if (nMinCellX >= FRAME_GRID_COLS) return vIndices;
+        const int nMaxCellX = std::min((int)FRAME_GRID_COLS - 1, (int)std::ceil((x - mnMinX + r) * mfGridElementWidthInv));
+        if (nMaxCellX < 0) return vIndices;
+        const int nMinCellY = std::max(0, (int)std::floor((y - mnMinY - r) * mfGridElementHeightInv));
+        if (nMinCellY >= FRAME_GRID_ROWS) return vIndices;
+        const int nMaxCellY = std::min((int)FRAME_GRID_ROWS - 1, (int)std::ceil((y - mnMinY + r) * mfGridElementHeightInv));
+        if (nMaxCellY < 0) return vIndices;
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++)
+                for (size_t j = 0; j < mGrid[ix][iy].size(); j++) {
+                    const sd_keypoint& kpUn = mvKeysUn[mGrid[ix][iy][j]];
+                    if (bCheckLevels) {
+                        if (kpUn.octave < minLevel) continue;
+                        if (maxLevel >= 0 && kpUn.octave > maxLevel) continue;
+                    }
+                    if (std::fabs(kpUn.x - x) < r && std::fabs(kpUn.y - y) < r) vIndices.push_back(mGrid[ix][iy][j]);
+                }
+        return vIndices;
+    }
+    bool isInImage(const float& x, const float& y) const { return x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY; }   // include/Frame.h:93-96
+};
+
+// The per-frame front end of ORB_SLAM2::Tracking (one camera stream = one lane of an sd_tracker).
+class Tracking {
+public:
+    enum { MONOCULAR = 0, STEREO = 1, RGBD = 2 };       // System::eSensor
+    Tracking(const sdfe::Settings& s, int sensor, int channels)
+        : mSensor(sensor), set_(s), ex_(s.nFeatures, s.scaleFactor, s.nLevels, s.iniThFAST, s.minThFAST)
+    {
+        sd_tracker_params p;
+        std::memset(&p, 0, sizeof(p));
+        p.sensor = sensor; p.width = s.width; p.height = s.height; p.channels = channels; p.rgb_order = s.RGB; p.n_lanes = 1; p.track_last = 1;
+        p.cam.fx = s.fx; p.cam.fy = s.fy; p.cam.cx = s.cx; p.cam.cy = s.cy; p.cam.mbf = s.bf; p.cam.mb = s.bf / s.fx;
+        const float K4[4] = {s.fx, s.fy, s.cx, s.cy}, d5[5] = {s.k1, s.k2, s.p1, s.p2, s.k3};
+        float b4[4];
+        sdfe::check(sd_image_bounds(s.width, s.height, K4, d5, b4), "ComputeImageBounds");      // Frame::ComputeImageBounds (Frame.cc:844-872)
+        p.cam.mnMinX = b4[0]; p.cam.mnMaxX = b4[1]; p.cam.mnMinY = b4[2]; p.cam.mnMaxY = b4[3];
+        for (int k = 0; k < 5; k++) p.dist[k] = d5[k];
+        p.fps = s.fps; p.depth_map_factor = s.DepthMapFactor; p.th_depth = s.ThDepth;
+        cam_ = p.cam;
+        sdfe::check(sd_tracker_create(&trk_, ex_.handle(), &p), "Tracking");
+        sdfe::check(sd_tracker_batch(trk_, &batch_), "Tracking");
+    }
+    ~Tracking() { if (trk_) sd_tracker_destroy(trk_); }
+    Tracking(const Tracking&) = delete;
+    Tracking& operator=(const Tracking&) = delete;
+
+    // cv::Mat GrabImageStereo(imRectLeft, imRectRight, boxes, timestamp)   src/Tracking.cc:210-248
+    template <class MatT, class RectT>
+    sdfe::Pose GrabImageStereo(const MatT& imRectLeft, const MatT& imRectRight, std::vector<RectT>& boxes, const double& timestamp)
+    {
+        const uint8_t* im[2] = {(const uint8_t*)imRectLeft.data, (const uint8_t*)imRectRight.data};
+        return grab(im, (size_t)imRectLeft.step, nullptr, 0, &boxes, timestamp);
+    }
+    // cv::Mat GrabImageStereo(imRectLeft, imRectRight, timestamp)          src/Tracking.cc:170-208
+    template <class MatT>
+    sdfe::Pose GrabImageStereo(const MatT& imRectLeft, const MatT& imRectRight, const double& timestamp)
+    {
+        const uint8_t* im[2] = {(const uint8_t*)imRectLeft.data, (const uint8_t*)imRectRight.data};
+        return grab<sdfe::Rect2d>(im, (size_t)imRectLeft.step, nullptr, 0, nullptr, timestamp);
+    }
+    // cv::Mat GrabImageRGBD(imRGB, imD, mask, boxes, timestamp)            src/Tracking.cc:282-314.  The mask is accepted and not read:
+    // Frame::firstSeparate never touches it (Frame.cc:555-604); its consumer is the dense mapper (sd_batch_backproject_dense).
+    template <class MatT, class RectT>
+    sdfe::Pose GrabImageRGBD(const MatT& imRGB, const MatT& imD, const MatT& /*mask*/, std::vector<RectT>& boxes, const double& timestamp)
+    {
+        const uint8_t* im[1] = {(const uint8_t*)imRGB.data};
+        return grab(im, (size_t)imRGB.step, (const uint16_t*)imD.data, (size_t)imD.step / 2, &boxes, timestamp);
+    }
+    // cv::Mat GrabImageRGBD(imRGB, imD, timestamp)                         src/Tracking.cc:251-280
+    template <class MatT>
+    sdfe::Pose GrabImageRGBD(const MatT& imRGB, const MatT& imD, const double& timestamp)
+    {
+        const uint8_t* im[1] = {(const uint8_t*)imRGB.data};
+        return grab<sdfe::Rect2d>(im, (size_t)imRGB.step, (const uint16_t*)imD.data, (size_t)imD.step / 2, nullptr, timestamp);
+    }
+    // cv::Mat GrabImageMonocular(im, timestamp)                            src/Tracking.cc:316-343
+    template <class MatT>
+    sdfe::Pose GrabImageMonocular(const MatT& im, const double& timestamp)
+    {
+        const uint8_t* p[1] = {(const uint8_t*)im.data};
+        return grab<sdfe::Rect2d>(p, (size_t)im.step, nullptr, 0, nullptr, timestamp);
+    }
+
+    Frame mCurrentFrame, mLastFrame;
+    int mSensor;
+    sd_batch* batch() { return batch_; }
+    int current_slot() const { return res_.cur_slot; }
+
+private:
+    template <class RectT>
+    sdfe::Pose grab(const uint8_t* const* images, size_t stride, const uint16_t* depth, size_t depthStrideElems, std::vector<RectT>* boxes,
+                    const double& timestamp)
+    {
+        double bx[SD_MAX_BOXES][4];
+        int32_t nb = -1;
+        if (boxes) {
+            if (boxes->size() > SD_MAX_BOXES) throw std::runtime_error("more than 32 boxes in a frame");
+            nb = (int32_t)boxes->size();
+            for (int j = 0; j < nb; j++) { bx[j][0] = (*boxes)[j].x; bx[j][1] = (*boxes)[j].y; bx[j][2] = (*boxes)[j].width; bx[j][3] = (*boxes)[j].height; }
+        }
+        const uint16_t* dp[1] = {depth};
+        sdfe::check(sd_tracker_track_host(trk_, images, stride, depth ? dp : nullptr, depthStrideElems, boxes ? &bx[0][0] : nullptr, boxes ? &nb : nullptr,
+                                          &timestamp, nullptr, nullptr, &res_), "Tracking::GrabImage");
+        mLastFrame = mCurrentFrame;
+        fill(mCurrentFrame, timestamp);
+        if (boxes) {                                    // boxTrack / firstSeparate rewrite the caller's vector (they take it by reference)
+            boxes->resize(mCurrentFrame.objects.size());
+            for (size_t j = 0; j < boxes->size(); j++) {
+                (*boxes)[j].x = mCurrentFrame.objects[j].x; (*boxes)[j].y = mCurrentFrame.objects[j].y;
+                (*boxes)[j].width = mCurrentFrame.objects[j].width; (*boxes)[j].height = mCurrentFrame.objects[j].height;
+            }
+        }
+        return sdfe::Pose();
+    }
+
+    void fill(Frame& F, double timestamp)
+    {
+        const sd_lane_result& R = res_;
+        const int slot = R.cur_slot;
+        int cap = 0;
+        sd_batch_kp_capacity(batch_, &cap);
+        F = Frame();
+        F.mTimeStamp = timestamp; F.mnId = (long unsigned int)R.frame_id;
+        F.fx = set_.fx; F.fy = set_.fy; F.cx = set_.cx; F.cy = set_.cy; F.invfx = 1.0f / set_.fx; F.invfy = 1.0f / set_.fy;
+        F.mbf = set_.bf; F.mb = set_.bf / set_.fx; F.mThDepth = set_.ThDepth;
+        F.mnMinX = cam_.mnMinX; F.mnMaxX = cam_.mnMaxX; F.mnMinY = cam_.mnMinY; F.mnMaxY = cam_.mnMaxY;
+        F.mfGridElementWidthInv = (float)FRAME_GRID_COLS / (F.mnMaxX - F.mnMinX);
+        F.mfGridElementHeightInv = (float)FRAME_GRID_ROWS / (F.mnMaxY - F.mnMinY);
+        F.mnScaleLevels = ex_.GetLevels(); F.mfScaleFactor = ex_.GetScaleFactor(); F.mfLogScaleFactor = std::log(F.mfScaleFactor);
+        F.mvScaleFactors = ex_.GetScaleFactors(); F.mvInvScaleFactors = ex_.GetInverseScaleFactors();
+        F.mvLevelSigma2 = ex_.GetScaleSigmaSquares(); F.mvInvLevelSigma2 = ex_.GetInverseScaleSigmaSquares();
+        // keypoints, descriptors, stereo coordinates
+        F.mvKeys.resize(cap); F.mDescriptors.resize((size_t)cap * 32); F.mvuRight.resize(cap); F.mvDepth.resize(cap);
+        int n = 0;
+        sdfe::check(sd_batch_download(batch_, slot, F.mvKeys.data(), F.mDescriptors.data(), cap, &n, nullptr), "download");
+        sdfe::check(sd_batch_download_rgbd(batch_, slot, F.mvuRight.data(), F.mvDepth.data(), cap), "download");
+        F.N = n; F.mvKeys.resize(n); F.mDescriptors.resize((size_t)n * 32); F.mvuRight.resize(n); F.mvDepth.resize(n);
+        F.mvKeysUn = F.mvKeys;                         // Camera.k1 == 0 (UndistortKeyPoints, Frame.cc:814-818)
+        F.mvbOutlier.assign(n, false);
+        // boxes and the per-box dynamic sets
+        int nb = 0, nAll = 0, nStatic = 0;
+        double bxs[SD_MAX_BOXES][4];
+        int32_t idx[SD_MAX_BOXES], st[SD_MAX_BOXES], kept[SD_MAX_BOXES], start[SD_MAX_BOXES + 1];
+        std::vector<int32_t> items(2 * (size_t)cap);
+        sdfe::check(sd_batch_download_boxes(batch_, slot, &nb, &bxs[0][0], idx, st, kept, start, items.data(), (int)items.size(), &nAll, &nStatic), "download_boxes");
+        F.N_ori = nStatic; F.N_d = nAll - nStatic;
+        std::vector<sd_keypoint> dk(cap); std::vector<uint8_t> dd((size_t)cap * 32); std::vector<float> du(cap), dz(cap);
+        int nd = 0;
+        sdfe::check(sd_batch_download_dynamic(batch_, slot, dk.data(), dd.data(), du.data(), dz.data(), cap, &nd), "download_dynamic");
+        F.objects.resize(nb); F.box_idx.assign(idx, idx + nb); F.box_status.assign(st, st + nb); F.omit.resize(nb); F.box_velocity.resize(nb);
+        F.mvdynKeys.resize(nb); F.mvdynKeysUn.resize(nb); F.mdynDescriptors.resize(nb); F.mvudynRight.resize(nb); F.mvdynDepth.resize(nb);
+        for (int j = 0; j < nb; j++) {
+            F.objects[j].x = bxs[j][0]; F.objects[j].y = bxs[j][1]; F.objects[j].width = bxs[j][2]; F.objects[j].height = bxs[j][3];
+            F.omit[j] = R.omit[j] != 0; F.box_velocity[j].x = R.box_velocity[j][0]; F.box_velocity[j].y = R.box_velocity[j][1];
+            for (int k = start[j]; k < start[j + 1]; k++) {
+                const int i = items[k];
+                F.mvdynKeys[j].push_back(dk[i]); F.mvdynKeysUn[j].push_back(dk[i]);
+                F.mdynDescriptors[j].insert(F.mdynDescriptors[j].end(), dd.begin() + (size_t)i * 32, dd.begin() + (size_t)i * 32 + 32);
+                F.mvudynRight[j].push_back(du[i]); F.mvdynDepth[j].push_back(dz[i]);
+            }
+        }
+        // the grid (AssignFeaturesToGrid / UpdateFeaturesToGrid): per-cell index lists in keypoint order
+        std::vector<int16_t> cell(cap);
+        sdfe::check(sd_batch_download_grid(batch_, slot, cell.data(), cap), "download_grid");
+        for (int i = 0; i < n; i++)
+            if (cell[i] >= 0) F.mGrid[cell[i] / FRAME_GRID_ROWS][cell[i] % FRAME_GRID_ROWS].push_back((size_t)i);
+        F.mnTrackHomoFlag = R.track_flag; F.mnSeparateRet = R.separate_ret; F.mnRefFrameId = R.ref_frame_id;
+        F.mnTrackMatches = R.n_track_matches; F.mnLastMatches = R.n_last_matches;
+    }
+
+    sdfe::Settings set_;
+    ORBextractor ex_;
+    sd_tracker* trk_ = nullptr;
+    sd_batch* batch_ = nullptr;
+    sd_camera cam_;
+    sd_lane_result res_;
+};
+
+// ORB_SLAM2::System's tracking entry points (include/System.h:66-79, src/System.cc:119-375) with the reference's argument lists.
+class System {
+public:
+    enum eSensor { MONOCULAR = 0, STEREO = 1, RGBD = 2 };
+    System(const sdfe::Settings& settings, const eSensor sensor, int channels = 3) : mSensor(sensor), mpTracker(new Tracking(settings, (int)sensor, channels)) {}
+    ~System() { delete mpTracker; }
+    System(const System&) = delete;
+    System& operator=(const System&) = delete;
+    template <class MatT> sdfe::Pose TrackStereo(const MatT& imLeft, const MatT& imRight, const double& timestamp)
+    { require(STEREO, "TrackStereo"); return mpTracker->GrabImageStereo(imLeft, imRight, timestamp); }
+    template <class MatT, class RectT> sdfe::Pose TrackStereo(const MatT& imLeft, const MatT& imRight, std::vector<RectT>& boxes, const double& timestamp)
+    { require(STEREO, "TrackStereo"); return mpTracker->GrabImageStereo(imLeft, imRight, boxes, timestamp); }
+    template <class MatT> sdfe::Pose TrackRGBD(const MatT& im, const MatT& depthmap, const double& timestamp)
+    { require(RGBD, "TrackRGBD"); return mpTracker->GrabImageRGBD(im, depthmap, timestamp); }
+    template <class MatT, class RectT> sdfe::Pose TrackRGBD(const MatT& im, const MatT& depthmap, const MatT& mask, std::vector<RectT>& boxes, const double& timestamp)
+    { require(RGBD, "TrackRGBD"); return mpTracker->GrabImageRGBD(im, depthmap, mask, boxes, timestamp); }
+    template <class MatT> sdfe::Pose TrackMonocular(const MatT& im, const double& timestamp)
+    { require(MONOCULAR, "TrackMonocular"); return mpTracker->GrabImageMonocular(im, timestamp); }
+    Tracking* GetTracker() { return mpTracker; }
+
+private:
+    void require(eSensor s, const char* what) const
+    {   // the reference prints "ERROR: you called TrackStereo but input sensor was not set to STEREO." and exit(-1)s (System.cc:121-125)
+        if (mSensor != s) throw std::runtime_error(std::string("ERROR: you called ") + what + " but the input sensor was set to another type.");
+    }
+    eSensor mSensor;
+    Tracking* mpTracker;
+};
+
+}  // namespace ORB_SLAM2
