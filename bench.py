@@ -344,6 +344,11 @@ class Workload:
             self.det_stream = torch.cuda.Stream(device=dev)
             self.det_in_flight = -1
             self.lookahead = True             # the next frame's forward pass is launched before this frame's front end
+            S_ = self.S                       # two result slots: forward + NMS + download of frame t + 1 are queued before frame t's boxes are consumed
+            self.det_dev = [dict(b=torch.zeros((S_, 32, 4), dtype=torch.float64, device=dev), c=torch.zeros((S_, 32), dtype=torch.int32, device=dev),
+                                 f=torch.zeros((S_, 32), dtype=torch.float32, device=dev), n=torch.zeros((S_,), dtype=torch.int32, device=dev)) for _ in range(2)]
+            self.det_host = [dict(b=torch.zeros((S_, 32, 4), dtype=torch.float64).pin_memory(), n=torch.zeros((S_,), dtype=torch.int32).pin_memory()) for _ in range(2)]
+            self.det_ev = [torch.cuda.Event(), torch.cuda.Event()]
         self.cloud = name == "tum-mask"          # PointCloudMapping::generatePointCloud on every frame: the consumer of the semantic mask
         if self.cloud:
             self.cap_pts = ((self.W + 2) // 3) * ((self.H + 2) // 3)
@@ -384,18 +389,17 @@ class Workload:
         W, H, S = self.W, self.H, self.S
         boxes, n_boxes = (fr["boxes"], fr["n_boxes"]) if self.with_boxes else (None, None)
         if self.det is not None:
-            ds = self.det_stream.cuda_stream
-            pitch = self.ipl * W * H * 3
             if self.det_in_flight != self.t:      # first step: nothing was launched ahead
-                self.det.forward_device(fr["images"].data_ptr(), W, H, W * 3, pitch, S, 0.5, ds)       # yolo->Segmentation_(imLeft), stereo_kitti.cc:107
-            dets = self.det.boxes_batch(S, W, H, stream=ds)                                          # one synchronisation (detector stream)
-            if self.lookahead and self.t + 1 < len(self.frames):     # the next frame's forward pass overlaps with this frame's front end
-                self.det.forward_device(self.frames[self.t + 1]["images"].data_ptr(), W, H, W * 3, pitch, S, 0.5, ds)
-                self.det_in_flight = self.t + 1
-            boxes = np.zeros((S, 32, 4), np.float64); n_boxes = np.zeros(S, np.int32)
-            for l in range(S):
-                b = dets[l][0][:16]               # boxTrack may re-inject as many again: keep within SD_MAX_BOXES
-                n_boxes[l] = len(b); boxes[l, :len(b)] = b
+                self.enqueue_detector(self.t)
+            k = self.t & 1
+            self.det_ev[k].synchronize()          # yolo->Segmentation_(imLeft) of THIS frame is on the host (stereo_kitti.cc:107)
+            nb_all = self.det_host[k]["n"].numpy()
+            if (nb_all < 0).any():
+                raise RuntimeError("detector post-processing on the device exceeded its capacity")
+            n_boxes = np.minimum(nb_all, 16).astype(np.int32)          # boxTrack may re-inject as many again: keep within SD_MAX_BOXES
+            boxes = self.det_host[k]["b"].numpy().copy()
+            if self.lookahead and self.t + 1 < len(self.frames):     # the next frame's detector pass is queued behind this one's download
+                self.enqueue_detector(self.t + 1)
         res = self.trk.track(fr["images"].data_ptr(), W * 3, W * H * 3, fr["stamps"], boxes=boxes, n_boxes=n_boxes,
                              d_depth=fr["depth"].data_ptr() if fr["depth"] is not None else 0, depth_stride=W, depth_pitch=W * H,
                              stream=self.main.cuda_stream)
@@ -405,6 +409,22 @@ class Workload:
                                          self.d_cnt.data_ptr(), stream=self.main.cuda_stream)
         self.t += 1
         return res
+
+    def enqueue_detector(self, t):
+        """forward + postprocess_ (device NMS) + download of frame t's boxes on the detector stream, nothing waits."""
+        torch = self.torch
+        W, H, S = self.W, self.H, self.S
+        ds = self.det_stream.cuda_stream
+        k = t & 1
+        fr = self.frames[t]
+        self.det.forward_device(fr["images"].data_ptr(), W, H, W * 3, self.ipl * W * H * 3, S, 0.5, ds)
+        d = self.det_dev[k]
+        self.det.boxes_device(S, W, H, d["b"].data_ptr(), d["c"].data_ptr(), d["f"].data_ptr(), d["n"].data_ptr(), stream=ds)
+        with torch.cuda.stream(self.det_stream):
+            self.det_host[k]["b"].copy_(d["b"], non_blocking=True)
+            self.det_host[k]["n"].copy_(d["n"], non_blocking=True)
+            self.det_ev[k].record(self.det_stream)
+        self.det_in_flight = t
 
     def close(self):
         self.trk.close()

@@ -16,6 +16,7 @@ typedef float sd_f4 __attribute__((ext_vector_type(4)));
 
 struct SdConvArgsF {
     const float* in; const float* wgt; const float* bias; const float* res; float* out;
+    const float* zero;       // >= 16 zero bytes: the source of padded taps and of rows beyond the last pixel
     int N, H, W, cin, cinStride;
     int Ho, Wo, cout, outStride, resStride;
     int ksize, stride, pad, leaky;
@@ -65,33 +66,49 @@ __global__ void __launch_bounds__(512, 1) k_conv_f32(SdConvArgsF A)
         for (int n = 0; n < 2; n++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+    // Staging addresses are kept as running pointers: inside a filter tap a step only adds BK floats to each of them; the (y, x)
+    // arithmetic and the bounds test of the im2col gather run once per TAP (every cin / BK steps), and a padded tap reads a zero
+    // page through the same unconditional load.  (The per-step form of this arithmetic, ~150 VALU instructions with 64-bit
+    // multiplies and branches, cost the MFMA pipe a quarter of its time: tools/micro/conv_loop_cost.hip.)
     sd_f4 xr[XC], wr[WC];
-    int t = 0, c0 = 0, kh = 0, kw = 0;
-    auto fetch = [&]() {
+    const float* wptr[WC];
+    const float* xptr[XC];
+    int winc[WC], xinc[XC];
 #pragma unroll
-        for (int i = 0; i < WC; i++) {
-            const int chunk = tid + 512 * i;
-            wr[i] = sd_f4{0.f, 0.f, 0.f, 0.f};
-            if (chunk < BM * CPR) wr[i] = *(const sd_f4*)(A.wgt + ((size_t)(co0 + chunk / CPR) * taps + t) * A.cin + c0 + 4 * (chunk % CPR));
-        }
+    for (int i = 0; i < WC; i++) {
+        const int chunk = tid + 512 * i;
+        const bool on = chunk < BM * CPR;
+        wptr[i] = on ? A.wgt + (size_t)(co0 + chunk / CPR) * taps * A.cin + 4 * (chunk % CPR) : A.zero;
+        winc[i] = on ? BK : 0;                          // (tap, channel) is one contiguous axis of a filter's weights
+    }
+    int c0 = 0, kh = 0, kw = 0;
+    auto retap = [&]() {                                // branch-free: the address of a padded tap is computed and discarded
 #pragma unroll
         for (int i = 0; i < XC; i++) {
             const int chunk = tid + 512 * i;
             const int yi = pyi[i] + kh, xi = pxi[i] + kw;
-            xr[i] = sd_f4{0.f, 0.f, 0.f, 0.f};
-            if (pok[i] && yi >= 0 && yi < A.H && xi >= 0 && xi < A.W)
-                xr[i] = *(const sd_f4*)(A.in + (pbase[i] + (size_t)yi * A.W + xi) * A.cinStride + c0 + 4 * (chunk % CPR));
+            const bool ok = pok[i] && yi >= 0 && yi < A.H && xi >= 0 && xi < A.W;
+            const float* p = A.in + ((ptrdiff_t)pbase[i] + (ptrdiff_t)yi * A.W + xi) * A.cinStride + 4 * (chunk % CPR);
+            xptr[i] = ok ? p : A.zero;
+            xinc[i] = ok ? BK : 0;
         }
+    };
+    retap();
+    auto fetch = [&]() {
+#pragma unroll
+        for (int i = 0; i < WC; i++) { wr[i] = *(const sd_f4*)wptr[i]; wptr[i] += winc[i]; }
+#pragma unroll
+        for (int i = 0; i < XC; i++) { xr[i] = *(const sd_f4*)xptr[i]; xptr[i] += xinc[i]; }
         c0 += BK;
-        if (c0 == A.cin) { c0 = 0; t++; kw++; if (kw == A.ksize) { kw = 0; kh++; } }
+        if (c0 == A.cin) { c0 = 0; kw++; if (kw == A.ksize) { kw = 0; kh++; } retap(); }
     };
     auto store = [&](int buf) {
         float* sW = smemf + buf * STAGE;
         float* sX = sW + BM * LD;
 #pragma unroll
-        for (int i = 0; i < WC; i++) { const int chunk = tid + 512 * i; if (chunk < BM * CPR) *(sd_f4*)(sW + (chunk / CPR) * LD + 4 * (chunk % CPR)) = wr[i]; }
+        for (int i = 0; i < WC; i++) { const int chunk = tid + 512 * i; if ((WC * 512 == BM * CPR) || chunk < BM * CPR) *(sd_f4*)(sW + (chunk / CPR) * LD + 4 * (chunk % CPR)) = wr[i]; }
 #pragma unroll
-        for (int i = 0; i < XC; i++) { const int chunk = tid + 512 * i; if (chunk < BN * CPR) *(sd_f4*)(sX + (chunk / CPR) * LD + 4 * (chunk % CPR)) = xr[i]; }
+        for (int i = 0; i < XC; i++) { const int chunk = tid + 512 * i; if ((XC * 512 == BN * CPR) || chunk < BN * CPR) *(sd_f4*)(sX + (chunk / CPR) * LD + 4 * (chunk % CPR)) = xr[i]; }
     };
     const int aoff = (32 * MT * wm + r32) * LD + 4 * h, boff = BM * LD + (64 * wn + r32) * LD + 4 * h;
     sd_f4 fa[2][MT], fb[2][2];                          // fragments of two consecutive K chunks: the reads of chunk c + 1 are issued before the MFMAs of chunk c
@@ -130,7 +147,11 @@ __global__ void __launch_bounds__(512, 1) k_conv_f32(SdConvArgsF A)
                 if (ks + 2 < ksteps) fetch();
             }
         }
+        // The barrier stays BEHIND the step's last MFMA: hoisted above them (legal, they touch no memory) the two waves of a SIMD
+        // would reach it a staging block apart and the earlier one would sit there with its remaining MFMAs unissued.
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
     }
     // ---- epilogue: D column = pixel (lane & 31), rows = filters (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  All shortcut reads are
     // requested before the first one is used (one memory round trip, not one per 16-byte piece).

@@ -2176,7 +2176,7 @@ static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int hei
         const sd_yolo::Rt& r = y->R[i];
         if (l.type == SD_YOLO_CONV) {
             SdConvArgsF A;
-            A.in = cur; A.wgt = y->d_wgt32 + r.wOff; A.bias = y->d_bias + r.bOff; A.res = nullptr; A.out = (float*)r.out;
+            A.in = cur; A.wgt = y->d_wgt32 + r.wOff; A.bias = y->d_bias + r.bOff; A.res = nullptr; A.out = (float*)r.out; A.zero = (const float*)y->d_zero;
             A.N = n; A.H = H; A.W = W; A.cin = i == 0 ? 8 : r.cinPad; A.cinStride = Cs;
             A.Ho = r.H; A.Wo = r.W; A.cout = l.filters; A.outStride = r.outC; A.resStride = 0;
             A.ksize = l.size; A.stride = l.stride; A.pad = l.size / 2; A.leaky = l.leaky;

@@ -217,6 +217,13 @@ class Detector:
                                               fe._p(cf), fe._p(nb), C.c_void_p(stream or 0)))
         return [(b[i, :nb[i]].copy(), cid[i, :nb[i]].copy(), cf[i, :nb[i]].copy()) for i in range(n_images)]
 
+    def boxes_device(self, n_images, frame_cols, frame_rows, d_boxes, d_cls, d_conf, d_n, conf=0.5, nms=0.4, stream=None):
+        """The same post-processing into caller-owned DEVICE buffers ([n][32][4] f64, [n][32] i32, [n][32] f32, [n] i32), no synchronisation."""
+        L = fe.lib()
+        L.sd_yolo_boxes_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        fe.check(L.sd_yolo_boxes_device(self.h, n_images, frame_cols, frame_rows, conf, nms, C.c_void_p(d_boxes), C.c_void_p(d_cls), C.c_void_p(d_conf),
+                                        C.c_void_p(d_n), C.c_void_p(stream or 0)))
+
     def mask_device(self, image, frame_cols, frame_rows, d_mask_ptr, stride, conf=0.5, nms=0.4, stream=None):
         nt = C.c_int()
         fe.check(fe.lib().sd_yolo_mask_device(self.h, image, frame_cols, frame_rows, conf, nms, C.c_void_p(d_mask_ptr), stride,

@@ -4,12 +4,12 @@
 #include <cstdio>
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4 __attribute__((ext_vector_type(4)));
-template <int LDSREADS>
+template <int LDSREADS, int RANDOM>
 __global__ void __launch_bounds__(512, 1) k(float* out, int iters)
 {
     __shared__ __align__(16) float lds[384 * 36];
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < 384 * 36; i += 512) lds[i] = (float)(i % 13) * 0.01f;
+    for (int i = tid; i < 384 * 36; i += 512) { unsigned h = (unsigned)(i + blockIdx.x * 7919) * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; lds[i] = RANDOM ? ((float)(h & 0xFFFFFF) / 8388608.0f - 1.0f) : (float)(i % 13) * 0.01f; }
     __syncthreads();
     f16v acc[2][2];
     for (int m = 0; m < 2; m++) for (int n = 0; n < 2; n++) for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
@@ -34,17 +34,19 @@ __global__ void __launch_bounds__(512, 1) k(float* out, int iters)
 int main()
 {
     float* d; hipMalloc(&d, 4096 * 512 * 4);
-    const int iters = 4096, grid = 2048;
-    for (int v = 0; v < 2; v++) {
+    const int iters = 8192, grid = 4096;
+    for (int v = 0; v < 3; v++) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         for (int rep = 0; rep < 2; rep++) {
             hipEventRecord(e0);
-            if (v == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(512), 0, 0, d, iters); else hipLaunchKernelGGL(k<1>, dim3(grid), dim3(512), 0, 0, d, iters);
+            if (v == 0) hipLaunchKernelGGL((k<0, 0>), dim3(grid), dim3(512), 0, 0, d, iters);
+            else if (v == 1) hipLaunchKernelGGL((k<1, 0>), dim3(grid), dim3(512), 0, 0, d, iters);
+            else hipLaunchKernelGGL((k<1, 1>), dim3(grid), dim3(512), 0, 0, d, iters);
             hipEventRecord(e1); hipEventSynchronize(e1);
         }
         float ms; hipEventElapsedTime(&ms, e0, e1);
         const double fl = (double)grid * 8 * iters * 16 * 4096.0;
-        printf("%s: %.2f ms, %.1f TFLOP/s\n", v ? "with LDS fragment reads" : "registers only", ms, fl / ms / 1e9);
+        printf("%s: %.2f ms, %.1f TFLOP/s\n", v == 0 ? "registers only, constant operands" : v == 1 ? "LDS fragment reads, low-entropy operands" : "LDS fragment reads, random operands", ms, fl / ms / 1e9);
     }
     return 0;
 }
