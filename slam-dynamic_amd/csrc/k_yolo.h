@@ -764,76 +764,97 @@ __global__ void __launch_bounds__(256) k_region_decode(const T* __restrict__ hea
 // cv::Rect2d (x, y, w, h f64) in kept order, nOut[image] (or -1 - count when a capacity was exceeded).
 #define SD_NMS_MAXDET 4096      // rows above the confidence threshold per image handled on the device
 #define SD_NMS_MAXKEEP 512      // boxes NMS may keep before the class filter
+#define SD_NMS_LDS (SD_NMS_MAXDET * (8 + 16 + 1))
+// Greedy NMS without a barrier per candidate: candidate t survives iff no KEPT earlier candidate overlaps it by more than the
+// threshold, so the workgroup iterates over the kept boxes only (tens) -- next unsuppressed candidate by a block-wide minimum, then
+// every later candidate tests itself against it in parallel -- instead of over all candidates (a thousand with three barriers each).
 __global__ void __launch_bounds__(256) k_yolo_nms(const SdDet* __restrict__ dets, const int* __restrict__ ndet, int detCap, int frameCols,
                                                   int frameRows, float confThreshold, float nmsThreshold, double* __restrict__ boxesOut,
                                                   int* __restrict__ clsOut, float* __restrict__ confOut, int* __restrict__ nOut)
 {
-    __shared__ unsigned long long keys[SD_NMS_MAXDET];
-    __shared__ int s_x[SD_NMS_MAXKEEP], s_y[SD_NMS_MAXKEEP], s_w[SD_NMS_MAXKEEP], s_h[SD_NMS_MAXKEEP], s_kslot[SD_NMS_MAXKEEP];      // kept rects
-    __shared__ int s_idx[SD_NMS_MAXDET];
-    __shared__ int s_reject, s_nk;
-    const int img = blockIdx.x, tid = threadIdx.x;
+    extern __shared__ __align__(16) unsigned char nms_smem[];                                             // SD_NMS_LDS bytes
+    unsigned long long* keys = (unsigned long long*)nms_smem;                                             // [SD_NMS_MAXDET]
+    int* s_x = (int*)(keys + SD_NMS_MAXDET); int* s_y = s_x + SD_NMS_MAXDET; int* s_w = s_y + SD_NMS_MAXDET; int* s_h = s_w + SD_NMS_MAXDET;   // int boxes of the sorted candidates
+    unsigned char* s_dead = (unsigned char*)(s_h + SD_NMS_MAXDET);
+    __shared__ int s_kept[SD_NMS_MAXKEEP];
+    __shared__ int s_next, s_wmin[4];
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nd = ndet[img];
     const SdDet* D = dets + (size_t)img * detCap;
     if (nd > SD_NMS_MAXDET || nd > detCap) { if (tid == 0) nOut[img] = -1 - nd; return; }
     int n2 = 64;
     while (n2 < nd) n2 <<= 1;
-    // sort key: score descending, then cv::dnn row ascending (the stable order of NMSBoxes' input)
+    // sort key: score descending, then cv::dnn row ascending (the stable order of NMSBoxes' input); the slot rides in the low bits
     for (int t = tid; t < n2; t += 256) {
         unsigned long long k = ~0ull;
-        if (t < nd && D[t].conf > confThreshold) k = ((unsigned long long)(~__float_as_uint(D[t].conf)) << 32) | (unsigned)D[t].row;
+        if (t < nd && D[t].conf > confThreshold) k = ((unsigned long long)(~__float_as_uint(D[t].conf)) << 32) | ((unsigned)D[t].row << 13) | (unsigned)t;
         keys[t] = k;
     }
     __syncthreads();
     sd_block_sort64(keys, n2, tid, 256);
-    // row -> slot in the unsorted list: small lists, linear search per sorted entry (done once)
+    int nc = 0;                                                // candidates above the threshold (they sort first)
     for (int t = tid; t < nd; t += 256) {
-        int slot = -1;
-        if (keys[t] != ~0ull) { const int row = (int)(keys[t] & 0xFFFFFFFFu); for (int j = 0; j < nd; j++) if (D[j].row == row) { slot = j; break; } }
-        s_idx[t] = slot;
+        const bool live = keys[t] != ~0ull;
+        if (live) {
+            const SdDet d = D[(int)(keys[t] & 0x1FFFu)];
+            const int centerX = (int)(d.cx * frameCols), centerY = (int)(d.cy * frameRows);
+            const int width = (int)(d.w * frameCols), height = (int)(d.h * frameRows);
+            s_x[t] = centerX - width / 2; s_y[t] = centerY - height / 2; s_w[t] = width; s_h[t] = height;
+        }
+        s_dead[t] = live ? 0 : 1;
+        nc += live;
     }
-    if (tid == 0) s_nk = 0;
     __syncthreads();
-    int nk = 0;
-    for (int t = 0; t < nd; t++) {
-        const int slot = s_idx[t];
-        if (slot < 0) break;                                  // the filtered-out rows sort last
-        const SdDet d = D[slot];
-        const int centerX = (int)(d.cx * frameCols), centerY = (int)(d.cy * frameRows);
-        const int width = (int)(d.w * frameCols), height = (int)(d.h * frameRows);
-        const int rx = centerX - width / 2, ry = centerY - height / 2;
-        if (tid == 0) s_reject = 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nc += __shfl_xor(nc, o, 64);
+    if (lane == 0) s_wmin[wv] = nc;
+    __syncthreads();
+    const int ncand = s_wmin[0] + s_wmin[1] + s_wmin[2] + s_wmin[3];
+    __syncthreads();
+    int nk = 0, from = 0;
+    while (true) {
+        // next unsuppressed candidate at or after `from`
+        int mine = 1 << 30;
+        for (int t = from + tid; t < ncand; t += 256) if (!s_dead[t]) { mine = t; break; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mine = min(mine, __shfl_xor(mine, o, 64));
+        if (lane == 0) s_wmin[wv] = mine;
         __syncthreads();
-        for (int j = tid; j < nk; j += 256) {
-            const double Aa = (double)width * height, Ab = (double)s_w[j] * s_h[j];
+        const int i = min(min(s_wmin[0], s_wmin[1]), min(s_wmin[2], s_wmin[3]));
+        __syncthreads();
+        if (i >= ncand) break;
+        if (nk >= SD_NMS_MAXKEEP) { if (tid == 0) nOut[img] = -1 - nd; return; }       // uniform
+        if (tid == 0) s_kept[nk] = i;
+        nk++;
+        const int rx = s_x[i], ry = s_y[i], width = s_w[i], height = s_h[i];
+        for (int t = i + 1 + tid; t < ncand; t += 256) {
+            if (s_dead[t]) continue;
+            // cv::dnn NMSBoxes: keep t only while overlap(t, kept) <= nms for every kept box; overlap = 1 - jaccardDistance on cv::Rect
+            const double Aa = (double)s_w[t] * s_h[t], Ab = (double)width * height;
             float ov;
             if ((Aa + Ab) <= 2.220446049250313e-16) ov = 1.f;
             else {
-                const int x1 = max(rx, s_x[j]), y1 = max(ry, s_y[j]);
-                const int x2 = min(rx + width, s_x[j] + s_w[j]), y2 = min(ry + height, s_y[j] + s_h[j]);
+                const int x1 = max(s_x[t], rx), y1 = max(s_y[t], ry);
+                const int x2 = min(s_x[t] + s_w[t], rx + width), y2 = min(s_y[t] + s_h[t], ry + height);
                 const double Aab = (x2 > x1 && y2 > y1) ? (double)(x2 - x1) * (y2 - y1) : 0.0;
                 ov = (float)(1. - (1. - Aab / (Aa + Ab - Aab)));
             }
-            if (!(ov <= nmsThreshold)) s_reject = 1;
+            if (!(ov <= nmsThreshold)) s_dead[t] = 1;
         }
-        __syncthreads();
-        if (!s_reject) {
-            if (nk >= SD_NMS_MAXKEEP) { if (tid == 0) nOut[img] = -1 - nd; return; }       // uniform
-            if (tid == 0) { s_x[nk] = rx; s_y[nk] = ry; s_w[nk] = width; s_h[nk] = height; s_kslot[nk] = slot; }
-            nk++;
-        }
+        from = i + 1;
         __syncthreads();
     }
     if (tid == 0) {
         int n = 0;
         for (int k = 0; k < nk; k++) {
-            const SdDet d = D[s_kslot[k]];
+            const int t = s_kept[k];
+            const SdDet d = D[(int)(keys[t] & 0x1FFFu)];
             const int c = d.cls;
             if (!(c == 0 || c == 1 || c == 2 || c == 5 || c == 7)) continue;
             if (n >= 32) { n = -1 - nk; break; }
-            const double sw = -0.2 * (double)s_w[k], sh = 0.6 * (double)s_h[k];
+            const double sw = -0.2 * (double)s_w[t], sh = 0.6 * (double)s_h[t];
             double* o = boxesOut + ((size_t)img * 32 + n) * 4;
-            o[0] = (double)s_x[k] - sw / 2.0; o[1] = (double)s_y[k] - sh / 2.0; o[2] = (double)s_w[k] + sw; o[3] = (double)s_h[k] + sh;
+            o[0] = (double)s_x[t] - sw / 2.0; o[1] = (double)s_y[t] - sh / 2.0; o[2] = (double)s_w[t] + sw; o[3] = (double)s_h[t] + sh;
             clsOut[img * 32 + n] = c; confOut[img * 32 + n] = d.conf;
             n++;
         }

@@ -2487,7 +2487,8 @@ int sd_yolo_boxes_device(sd_yolo* y, int n_images, int frame_cols, int frame_row
         return set_err(SD_ERR_INVALID, "bad yolo_boxes_device arguments");
     if (n_images == 0) return SD_OK;
     hipStream_t s = stream_ ? (hipStream_t)stream_ : y->stream;
-    hipLaunchKernelGGL(k_yolo_nms, dim3(n_images), dim3(256), 0, s, y->d_dets, y->d_ndet, y->detCap, frame_cols, frame_rows, conf_threshold,
+    if (!y->attrNms) { HIPCHK(hipFuncSetAttribute((const void*)k_yolo_nms, hipFuncAttributeMaxDynamicSharedMemorySize, SD_NMS_LDS)); y->attrNms = true; }
+    hipLaunchKernelGGL(k_yolo_nms, dim3(n_images), dim3(256), SD_NMS_LDS, s, y->d_dets, y->d_ndet, y->detCap, frame_cols, frame_rows, conf_threshold,
                        nms_threshold, d_boxes, d_class_ids, d_confidences, d_n_boxes);
     LAUNCH_CHECK("k_yolo_nms");
     return SD_OK;

@@ -16,7 +16,7 @@ struct sd_yolo {
     std::vector<Rt> R;
     int netW = 0, netH = 0, classes = 80, maxBatch = 0, nconv = 0;
     int f32 = 0;                   // SD_YOLO_F32: activations / weights / arithmetic in f32 (k_yolo32.h); the `out` pointers then hold floats
-    float* d_blob8 = nullptr; float* d_wgt32 = nullptr; bool attrF32 = false;
+    float* d_blob8 = nullptr; float* d_wgt32 = nullptr; bool attrF32 = false, attrNms = false;
     float anchors[18];
     _Float16* d_blob4 = nullptr;   // network input, NHWC f16 x 4 channels
     _Float16* d_wgt = nullptr; float* d_bias = nullptr; _Float16* d_zero = nullptr;
