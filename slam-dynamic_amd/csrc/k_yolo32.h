@@ -28,14 +28,15 @@ struct SdConvArgsF {
 // 128-filter tile.  LDS holds TWO stages: while the MFMAs of stage s run, the tiles of stage s + 1 (fetched into registers one
 // step earlier) are written to the other buffer and the global loads of stage s + 2 are issued -- one barrier per step, and
 // neither the address arithmetic of the gather nor the LDS writes sit between two barriers with the MFMA pipe idle.
-template <int BK, int WM, int MT>
-__global__ void __launch_bounds__(512, 1) k_conv_f32(SdConvArgsF A)
+template <int BK, int WM, int MT, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) k_conv_f32(SdConvArgsF A)
 {
-    constexpr int WN = 8 / WM, BM = 32 * MT * WM, BN = 64 * WN;
+    constexpr int NT = 64 * NW;                         // NW = 8: one workgroup per CU; NW = 4: two independent workgroups per CU
+    constexpr int WN = NW / WM, BM = 32 * MT * WM, BN = 64 * WN;
     constexpr int LD = BK + 4;                          // LDS row length in floats (16-byte aligned rows, 2-way conflicts at worst)
     constexpr int CPR = BK / 4;                         // 16-byte chunks per row
-    constexpr int XC = (BN * CPR + 511) / 512;          // activation chunks per thread per step
-    constexpr int WC = (BM * CPR + 511) / 512;
+    constexpr int XC = (BN * CPR + NT - 1) / NT;        // activation chunks per thread per step
+    constexpr int WC = (BM * CPR + NT - 1) / NT;
     constexpr int STAGE = (BM + BN) * LD;               // floats per stage
     constexpr int NCH = BK / 8;                         // 8-wide K chunks per step
     extern __shared__ __align__(16) float smemf[];
@@ -48,7 +49,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_f32(SdConvArgsF A)
     bool pok[XC];
 #pragma unroll
     for (int i = 0; i < XC; i++) {
-        const int chunk = tid + 512 * i;
+        const int chunk = tid + NT * i;
         const int p = pix0 + chunk / CPR;
         pok[i] = chunk < BN * CPR && p < npix;
         const int pp = pok[i] ? p : 0;
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_f32(SdConvArgsF A)
     int winc[WC], xinc[XC];
 #pragma unroll
     for (int i = 0; i < WC; i++) {
-        const int chunk = tid + 512 * i;
+        const int chunk = tid + NT * i;
         const bool on = chunk < BM * CPR;
         wptr[i] = on ? A.wgt + (size_t)(co0 + chunk / CPR) * taps * A.cin + 4 * (chunk % CPR) : A.zero;
         winc[i] = on ? BK : 0;                          // (tap, channel) is one contiguous axis of a filter's weights
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_f32(SdConvArgsF A)
     auto retap = [&]() {                                // branch-free: the address of a padded tap is computed and discarded
 #pragma unroll
         for (int i = 0; i < XC; i++) {
-            const int chunk = tid + 512 * i;
+            const int chunk = tid + NT * i;
             const int yi = pyi[i] + kh, xi = pxi[i] + kw;
             const bool ok = pok[i] && yi >= 0 && yi < A.H && xi >= 0 && xi < A.W;
             const float* p = A.in + ((ptrdiff_t)pbase[i] + (ptrdiff_t)yi * A.W + xi) * A.cinStride + 4 * (chunk % CPR);
@@ -106,9 +107,9 @@ __global__ void __launch_bounds__(512, 1) k_conv_f32(SdConvArgsF A)
         float* sW = smemf + buf * STAGE;
         float* sX = sW + BM * LD;
 #pragma unroll
-        for (int i = 0; i < WC; i++) { const int chunk = tid + 512 * i; if ((WC * 512 == BM * CPR) || chunk < BM * CPR) *(sd_f4*)(sW + (chunk / CPR) * LD + 4 * (chunk % CPR)) = wr[i]; }
+        for (int i = 0; i < WC; i++) { const int chunk = tid + NT * i; if ((WC * NT == BM * CPR) || chunk < BM * CPR) *(sd_f4*)(sW + (chunk / CPR) * LD + 4 * (chunk % CPR)) = wr[i]; }
 #pragma unroll
-        for (int i = 0; i < XC; i++) { const int chunk = tid + 512 * i; if ((XC * 512 == BN * CPR) || chunk < BN * CPR) *(sd_f4*)(sX + (chunk / CPR) * LD + 4 * (chunk % CPR)) = xr[i]; }
+        for (int i = 0; i < XC; i++) { const int chunk = tid + NT * i; if ((XC * NT == BN * CPR) || chunk < BN * CPR) *(sd_f4*)(sX + (chunk / CPR) * LD + 4 * (chunk % CPR)) = xr[i]; }
     };
     const int aoff = (32 * MT * wm + r32) * LD + 4 * h, boff = BM * LD + (64 * wn + r32) * LD + 4 * h;
     sd_f4 fa[2][MT], fb[2][2];                          // fragments of two consecutive K chunks: the reads of chunk c + 1 are issued before the MFMAs of chunk c
@@ -130,7 +131,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_f32(SdConvArgsF A)
     };
     // The two waves that share a SIMD (w and w + 4) do their staging at DIFFERENT K chunks of a step: the ~150 address / LDS-write
     // instructions of one wave then run under the other wave's MFMAs instead of both leaving the MFMA pipe idle together.
-    const int myslot = NCH >= 4 ? 2 * (wv >> 2) : (NCH == 2 ? (wv >> 2) : 0);
+    const int myslot = NW == 8 ? (NCH >= 4 ? 2 * (wv >> 2) : (NCH == 2 ? (wv >> 2) : 0)) : 0;
     fetch();
     store(0);
     if (ksteps > 1) fetch();
@@ -191,7 +192,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_f32(SdConvArgsF A)
             }
     }
 }
-#define SD_F32_LDS(BK, WM, MT) (2 * (32 * (MT) * (WM) + 64 * (8 / (WM))) * ((BK) + 4) * 4)
+#define SD_F32_LDS(BK, WM, MT, NW) (2 * (32 * (MT) * (WM) + 64 * ((NW) / (WM))) * ((BK) + 4) * 4)
 
 // blobFromImage as k_blob_from_image, NHWC f32 with 8 channels (R, G, B after swapRB, then zeros)
 __global__ void __launch_bounds__(256) k_blob_from_image_f32(const uint8_t* __restrict__ src, int sw, int sh, size_t sstride, size_t spitch,
