@@ -88,8 +88,9 @@ class SequenceOracle:
             if self.sensor == SENSOR_STEREO:
                 kpR, descR = self.exR(self._gray(im2))
         N = len(kp)
-        if N == 0:                                            # `if(mvKeys.empty()) return;`
+        if N == 0:                                            # `if(mvKeys.empty()) return;`: no boxTrack, no members
             F.kp, F.desc, F.ur, F.dep = kp, desc, np.zeros(0, np.float32), np.zeros(0, np.float32)
+            F.dyn_kp, F.dyn_desc, F.dyn_ur, F.dyn_dep = kp[:0], desc[:0], np.zeros(0, np.float32), np.zeros(0, np.float32)
             F.cells = np.zeros(0, np.int32)
             return F
         # stereo association (per keypoint: its order relative to the split is immaterial)

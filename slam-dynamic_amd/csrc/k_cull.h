@@ -62,6 +62,11 @@ __global__ void __launch_bounds__(256) k_box_separate(SdCullPtrs A, const int* _
     SdFrameBoxes& F = A.fb[slot];
     const int N = A.count[slot], nb = F.nb;
     const size_t base = (size_t)slot * A.cap;
+    if (N == 0) {                                   // `if(mvKeys.empty()) return;` (Frame.cc:160-161, 320-321): the constructor ends BEFORE boxTrack, objects stays empty
+        __syncthreads();
+        if (tid == 0) { F.nb = 0; F.nAll = 0; F.nOri = 0; F.nDyn = 0; F.boxStart[0] = 0; }
+        return;
+    }
     if (tid == 0) s_has = 0;
     if (tid < nb) { s_box[tid][0] = F.boxes[tid][0]; s_box[tid][1] = F.boxes[tid][1]; s_box[tid][2] = F.boxes[tid][2]; s_box[tid][3] = F.boxes[tid][3]; }
     __syncthreads();

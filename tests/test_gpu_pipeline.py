@@ -193,3 +193,15 @@ def test_mono_chain_tum3(gpu, fe, orc, synth):
     T = 3
     lanes = [dict(frames=lambda t: (synth.rgbd_frame(33, t, cfg)[0], None), boxes=lambda t: None, stamps=[t / 30.0 for t in range(T)])]
     _run_chain(fe, orc, synth, cfg, fe.SENSOR_MONOCULAR, lanes, T, channels=3)
+
+
+@pytest.mark.parametrize("kind,seed", [("stereo", 11), ("rgbd", 12)])
+def test_randomised_sequences(gpu, kind, seed):
+    """3 fixed draws per sensor of tools/fuzz_tracker.py: random box sets (none / empty / overlapping / partly outside / erased), jittered and
+    jumping time stamps, blank frames (the constructor's `mvKeys.empty()` return), scene cuts -- every frame of every lane identical to the
+    frame-level oracle.  (When written: 16 + 80 draws of 3 lanes x 8 frames were run; the sweep found the blank-frame case, where the
+    reference's constructor returns before boxTrack and leaves `objects` empty.)"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_tracker", os.path.join(graft.ROOT, "tools", "fuzz_tracker.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    assert m.run(3, seed, kind) == 0
