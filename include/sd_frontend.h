@@ -238,9 +238,18 @@ int sd_batch_download_motion(sd_batch* b, int pair, double* H, double* F, uint8_
  * Camera.k1 is not zero (TUM1 / TUM2 / EuRoC settings): cv::undistortPoints(pts, mK, mDistCoef, Mat(), mK).  K4 = fx, fy,
  * cx, cy; dist5 = k1, k2, p1, p2, k3 (Tracking.cc:76-90).  sd_batch_undistort_keypoints writes the mvKeysUn records of the
  * first n_images slots to d_keys_un ([n_images][cap] sd_keypoint; a plain copy when k1 == 0, as the reference does).
- * The matchers of this library read the batch's own keypoints, i.e. they implement the k1 == 0 case of every shipped
- * KITTI / TUM3 setting; sd_image_bounds gives mnMinX, mnMaxX, mnMinY, mnMaxY for sd_camera. */
+ * sd_image_bounds gives mnMinX, mnMaxX, mnMinY, mnMaxY for sd_camera. */
 int sd_undistort_points_device(const float* d_pts, int n, const float* K4, const float* dist5, float* d_out, void* stream);
+/* mvKeysUn as a second key-point array of the batch (cameras with Camera.k1 != 0: TUM1 / TUM2 / EuRoC settings).  After
+ * sd_batch_set_distortion every consumer that reads mvKeysUn in the reference does so here: the grid (PosInGrid / GetFeaturesInArea),
+ * both SearchByProjection overloads, ComputeStereoFromRGBD's `kpU.pt.x - mbf/d` (Frame.cc:1069), UnprojectStereo, the point pairs of
+ * TrackHomo and classifyH / classifyF (mvdynKeysUn); box membership, the depth lookup and the stereo matcher keep reading mvKeys.
+ * sd_batch_undistort (re)computes the arrays of the listed slots -- call it after an extraction, after sd_batch_first_separate
+ * (it permutes mvKeys) and after sd_batch_update_frame (it appends); sd_tracker_* does.  dist5[0] == 0 switches it off again. */
+int sd_batch_set_distortion(sd_batch* b, const float* K4, const float* dist5);
+int sd_batch_undistort(sd_batch* b, int n_slots, const int32_t* slots, void* stream);
+int sd_batch_download_keys_un(sd_batch* b, int image, sd_keypoint* kp, int cap, int* n);
+int sd_batch_download_dynamic_keys_un(sd_batch* b, int slot, sd_keypoint* kp, int cap, int* n); /* mvdynKeysUn, indexed like sd_batch_download_dynamic */
 int sd_batch_undistort_keypoints(sd_batch* b, int n_images, const float* K4, const float* dist5, sd_keypoint* d_keys_un, void* stream);
 int sd_image_bounds(int cols, int rows, const float* K4, const float* dist5, float* bounds4);
 
@@ -348,7 +357,7 @@ typedef struct sd_tracker_params {
     int32_t track_last;     /* != 0: also match against mLastFrame */
     int32_t reserved;
     sd_camera cam;          /* Camera.fx .. Camera.bf and the image bounds */
-    float dist[5];          /* Camera.k1, k2, p1, p2, k3; must be zero (SD_ERR_UNSUPPORTED otherwise) */
+    float dist[5];          /* Camera.k1, k2, p1, p2, k3 (k1 == 0: mvKeysUn == mvKeys, as Frame.cc:814-818) */
     float fps;              /* Camera.fps = mMaxFrames (Tracking.cc:93-98) */
     float depth_map_factor; /* DepthMapFactor (Tracking.cc:141-146); RGB-D only */
     float th_depth;         /* ThDepth (kept for the caller; not used on this path) */

@@ -27,7 +27,8 @@ class FrameState:
     def __init__(self):
         self.mnId = -1
         self.mTimeStamp = 0.0
-        self.kp = None; self.desc = None; self.ur = None; self.dep = None      # mvKeys(Un), mDescriptors, mvuRight, mvDepth  [N]
+        self.kp = None; self.desc = None; self.ur = None; self.dep = None      # mvKeys, mDescriptors, mvuRight, mvDepth  [N]
+        self.kpUn = None; self.dyn_kpUn = None                                  # mvKeysUn, mvdynKeysUn (== kp / dyn_kp when Camera.k1 == 0)
         self.N = 0
         self.dyn_kp = None; self.dyn_desc = None; self.dyn_ur = None; self.dyn_dep = None   # the N_d keypoints inside boxes
         self.objects = np.zeros((0, 4)); self.box_idx = np.zeros(0, np.int32); self.box_status = np.zeros(0, np.int32)
@@ -52,7 +53,10 @@ class SequenceOracle:
         self.exL = mk()
         self.exR = mk() if sensor == SENSOR_STEREO else None
         fx = np.float32(cfg["fx"]); bf = np.float32(cfg["bf"])
-        self.cam10 = np.array([fx, cfg["fy"], cfg["cx"], cfg["cy"], bf, np.float32(bf / fx), 0, cfg["width"], 0, cfg["height"]], np.float32)
+        self.K4 = np.array([fx, cfg["fy"], cfg["cx"], cfg["cy"]], np.float32)
+        self.dist5 = np.array([cfg.get(k, 0.0) for k in ("k1", "k2", "p1", "p2", "k3")], np.float32)
+        b = orc.image_bounds(cfg["width"], cfg["height"], self.K4, self.dist5)        # Frame::ComputeImageBounds (Frame.cc:844-872)
+        self.cam10 = np.array([fx, cfg["fy"], cfg["cx"], cfg["cy"], bf, np.float32(bf / fx), b[0], b[1], b[2], b[3]], np.float32)
         self.rgb_order = rgb_order
         self.track_last = track_last
         self.depth_factor = float(np.float32(1.0) / np.float32(cfg.get("depth_map_factor", 1.0)))   # Tracking.cc:141-146
@@ -61,6 +65,14 @@ class SequenceOracle:
         self.mMaxFrames = cfg["fps"]         # Tracking.cc:93-98: mMaxFrames = fps
         self.n_frames = 0
         self.I = np.eye(4, dtype=np.float32)
+
+    def _undistort(self, kp):
+        """Frame::UndistortKeyPoints (Frame.cc:812-842): a copy when k1 == 0, cv::undistortPoints on the positions otherwise."""
+        out = kp.copy()
+        if self.dist5[0] != 0 and len(kp):
+            u = self.orc.undistort_points(np.stack([kp["x"], kp["y"]], 1), self.K4, self.dist5)
+            out["x"] = u[:, 0]; out["y"] = u[:, 1]
+        return out
 
     # ------------------------------------------------------------------ Frame::Frame
     def _gray(self, im):
@@ -91,6 +103,7 @@ class SequenceOracle:
         if N == 0:                                            # `if(mvKeys.empty()) return;`: no boxTrack, no members
             F.kp, F.desc, F.ur, F.dep = kp, desc, np.zeros(0, np.float32), np.zeros(0, np.float32)
             F.dyn_kp, F.dyn_desc, F.dyn_ur, F.dyn_dep = kp[:0], desc[:0], np.zeros(0, np.float32), np.zeros(0, np.float32)
+            F.kpUn, F.dyn_kpUn = kp[:0], kp[:0]
             F.cells = np.zeros(0, np.int32)
             return F
         # stereo association (per keypoint: its order relative to the split is immaterial)
@@ -98,7 +111,10 @@ class SequenceOracle:
             ur, dep, _, _ = orc.stereo_matches(self.exL, self.exR, kp, desc, kpR, descR, cfg["bf"], cfg["fx"])
         elif self.sensor == SENSOR_RGBD:
             dep32 = orc.depth_to_f32(im2, self.depth_factor)
-            ur, dep = orc.stereo_from_rgbd(kp, dep32, cfg["bf"])
+            ur, dep = orc.stereo_from_rgbd(kp, dep32, cfg["bf"])           # depth looked up at the DISTORTED position (Frame.cc:1062-1065)
+            if self.dist5[0] != 0:                                         # mvuRight[i] = kpU.pt.x - mbf / d (Frame.cc:1069), f32
+                kun = self._undistort(kp)
+                ur = np.where(dep > 0, kun["x"] - np.float32(cfg["bf"]) / np.where(dep > 0, dep, np.float32(1)), np.float32(-1)).astype(np.float32)
         else:
             ur = np.full(N, -1, np.float32); dep = np.full(N, -1, np.float32)
         if boxes is not None and self.sensor != SENSOR_MONOCULAR:
@@ -122,7 +138,8 @@ class SequenceOracle:
             F.dyn_kp = kp[:0]; F.dyn_desc = desc[:0]; F.dyn_ur = ur[:0]; F.dyn_dep = dep[:0]
             F.N_s, F.N_d = N, 0
         F.N = len(F.kp)
-        F.cells = orc.grid_cells(F.kp, self.cam10)
+        F.kpUn, F.dyn_kpUn = self._undistort(F.kp), self._undistort(F.dyn_kp)
+        F.cells = orc.grid_cells(F.kpUn, self.cam10)
         return F
 
     # ------------------------------------------------------------------ Tracking::TrackHomo
@@ -130,15 +147,15 @@ class SequenceOracle:
         orc = self.orc
         th = 7.0 if self.sensor == SENSOR_STEREO else 15.0
         mono = self.sensor == SENSOR_MONOCULAR
-        args = (F.kp, F.desc, F.ur, R.kp, R.desc, R.xw, R.mp_flags, Tcw, Trw, self.cam10, self.exL.scale)
+        args = (F.kpUn, F.desc, F.ur, R.kpUn, R.desc, R.xw, R.mp_flags, Tcw, Trw, self.cam10, self.exL.scale)
         match, pairs, nm = orc.search_by_projection(*args, th, mono, True)
         if nm < 20:
             match, pairs, nm = orc.search_by_projection(*args, 2 * th, mono, True)
         F.n_track_matches, F.pairs = nm, pairs
         if nm < 20:
             return 0
-        pl = np.stack([R.kp["x"][pairs[:, 0]], R.kp["y"][pairs[:, 0]]], 1)
-        pc = np.stack([F.kp["x"][pairs[:, 1]], F.kp["y"][pairs[:, 1]]], 1)
+        pl = np.stack([R.kpUn["x"][pairs[:, 0]], R.kpUn["y"][pairs[:, 0]]], 1)         # LastFrame.mvKeysUn[i].pt (ORBmatcher.cc:505)
+        pc = np.stack([F.kpUn["x"][pairs[:, 1]], F.kpUn["y"][pairs[:, 1]]], 1)
         F.motion = orc.estimate_motion(pl, pc)
         return F.motion["flag"]
 
@@ -164,8 +181,8 @@ class SequenceOracle:
                 F.ref_id = R.mnId
                 if flag != 0:
                     F.track_flag = flag
-                    cur = dict(kp=F.dyn_kp, desc=F.dyn_desc, boxStart=F.boxStart, boxItems=F.boxItems, box_idx=F.box_idx)
-                    ref = dict(kp=R.dyn_kp, desc=R.dyn_desc, boxStart=R.boxStart, boxItems=R.boxItems, box_idx=R.box_idx)
+                    cur = dict(kp=F.dyn_kpUn, desc=F.dyn_desc, boxStart=F.boxStart, boxItems=F.boxItems, box_idx=F.box_idx)      # mvdynKeysUn
+                    ref = dict(kp=R.dyn_kpUn, desc=R.dyn_desc, boxStart=R.boxStart, boxItems=R.boxItems, box_idx=R.box_idx)
                     L = self.mLastFrame
                     ret, sc, ds, dyn, mt = orc.separate(F.motion["HorF"], flag, cur, ref, L.box_idx, L.box_status, F.box_status)
                     F.separate_ret, F.box_status, F.dynStart, F.dynStatus, F.sep_matches = ret, sc, ds, dyn, mt
@@ -175,7 +192,8 @@ class SequenceOracle:
                         F.kp = np.concatenate([F.kp, F.dyn_kp[app]]); F.desc = np.concatenate([F.desc, F.dyn_desc[app]])
                         F.ur = np.concatenate([F.ur, F.dyn_ur[app]]); F.dep = np.concatenate([F.dep, F.dyn_dep[app]])
                         F.N = len(F.kp)
-                        F.cells = orc.grid_cells(F.kp, self.cam10)                  # UpdateFeaturesToGrid
+                        F.kpUn = np.concatenate([F.kpUn, F.dyn_kpUn[app]])
+                        F.cells = orc.grid_cells(F.kpUn, self.cam10)                # UpdateFeaturesToGrid
                     break
                 if len(self.q_frame) == 1:
                     break
@@ -185,12 +203,12 @@ class SequenceOracle:
         if self.sensor == SENSOR_MONOCULAR or F.N == 0:
             F.xw = np.zeros((F.N, 3), np.float32); F.mp_flags = np.zeros(F.N, np.uint8)
         else:
-            F.xw, F.mp_flags = orc.unproject(F.kp, F.dep, self.cam10, Twc)
+            F.xw, F.mp_flags = orc.unproject(F.kpUn, F.dep, self.cam10, Twc)
         # TrackWithMotionModel's matcher against mLastFrame (Tracking.cc:1714-1741): th 7 stereo / 15 otherwise
         if self.track_last and self.mLastFrame is not None and F.N > 0 and self.mLastFrame.N > 0:
             L = self.mLastFrame
             th = 7.0 if self.sensor == SENSOR_STEREO else 15.0
-            F.last_match, _, F.n_last_matches = orc.search_by_projection(F.kp, F.desc, F.ur, L.kp, L.desc, L.xw, L.mp_flags, F.Tcw, L.Tcw,
+            F.last_match, _, F.n_last_matches = orc.search_by_projection(F.kpUn, F.desc, F.ur, L.kpUn, L.desc, L.xw, L.mp_flags, F.Tcw, L.Tcw,
                                                                          self.cam10, self.exL.scale, th, self.sensor == SENSOR_MONOCULAR, True)
         # mState == OK: queue + mLastFrame (Tracking.cc:952-959; both are copies)
         if len(self.q_frame) >= self.mMaxFrames * 0.3:

@@ -27,6 +27,7 @@ struct SdCullPtrs {
     sd_keypoint* kp; uint8_t* desc; float* uright; float* depth; int* count;
     sd_keypoint* kpT; uint8_t* descT; float* urT; float* depT;      // staging rows [maxImages][cap]
     sd_keypoint* kpD; uint8_t* descD; float* urD; float* depD;      // the dynamic keypoints of a frame (mvdynKeys...), [maxImages][cap]
+    const sd_keypoint* kpDUn;                                        // mvdynKeysUn (== kpD for a camera without distortion)
     SdFrameBoxes* fb; int* boxItems;                                 // [maxImages], [maxImages][itemsCap]
     int cap, itemsCap;
     int* errFlag;
@@ -381,7 +382,7 @@ __global__ void __launch_bounds__(256) k_separate(SdCullPtrs A, SdSepArgs G)
         int mine = 0;
         for (int m = tid; m < ng; m += 256) {
             const int qi = mt[2 * (pos + m)], ti = mt[2 * (pos + m) + 1];
-            const sd_keypoint kc = A.kpD[baseC + itemsC[q0 + qi]], kr = A.kpD[baseR + itemsR[t0 + ti]];
+            const sd_keypoint kc = A.kpDUn[baseC + itemsC[q0 + qi]], kr = A.kpDUn[baseR + itemsR[t0 + ti]];      // classifyH / classifyF run on mvdynKeysUn (Tracking.cc:1131-1133)
             const bool st = sd_classify_one(s_M, s_Mi, flag, kr.x, kr.y, kc.x, kc.y);
             dyn[pos + m] = st ? qi : -1;
             mine += st;

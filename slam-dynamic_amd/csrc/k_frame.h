@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) k_stereo_filter(const int* __restrict__ c
 // Frame::ComputeStereoFromRGBD with mvKeysUn == mvKeys (zero distortion).  T = uint16_t fuses the
 // convertTo(CV_32F, factor) of Tracking.cc:271-272 into the lookup; T = float reads a converted map.
 template <typename T>
-__global__ void __launch_bounds__(256) k_rgbd(const sd_keypoint* __restrict__ kp, const int* __restrict__ count,
+__global__ void __launch_bounds__(256) k_rgbd(const sd_keypoint* __restrict__ kp, const sd_keypoint* __restrict__ kpUn, const int* __restrict__ count,
                                               const T* __restrict__ depth, size_t strideE, size_t pitchE, float factor,
                                               float mbf, float* __restrict__ uRight, float* __restrict__ depthOut,
                                               const SdDevPlan* __restrict__ PP)
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(256) k_rgbd(const sd_keypoint* __restrict__ kp
     float d;
     if (sizeof(T) == 2) d = (float)raw * factor; else d = (float)raw;
     float ur = -1.f, dd = -1.f;
-    if (d > 0) { dd = d; ur = k.x - mbf / d; }
+    if (d > 0) { dd = d; ur = kpUn[(size_t)img * P.kpCap + i].x - mbf / d; }      // kpU.pt.x - mbf / d (Frame.cc:1069); the lookup above is at the DISTORTED position
     uRight[(size_t)img * P.kpCap + i] = ur;
     depthOut[(size_t)img * P.kpCap + i] = dd;
 }
@@ -1156,4 +1156,23 @@ __global__ void __launch_bounds__(256) k_undistort_keypoints(const sd_keypoint* 
     sd_keypoint k = kp[(size_t)img * cap + i];
     if (!identity) { float uo, vo; sd_undistort_pt(D, k.x, k.y, uo, vo); k.x = uo; k.y = vo; }
     kpUn[(size_t)img * cap + i] = k;
+}
+
+// Frame::UndistortKeyPoints for a list of frame slots, the static key points (mvKeys -> mvKeysUn) and the per-box dynamic ones
+// (mvdynKeys -> mvdynKeysUn): a pure function of the key point, so it is simply re-run whenever the arrays were permuted
+// (firstSeparate) or extended (UpdateFrame).  blockIdx.z = 0: static, 1: dynamic.
+__global__ void __launch_bounds__(256) k_undistort_slots(const sd_keypoint* __restrict__ kp, const sd_keypoint* __restrict__ kpD, const int* __restrict__ count,
+                                                         const int* __restrict__ nDynOf /* &fb[0].nDyn, stride fbStrideInts */, int fbStrideInts,
+                                                         const int* __restrict__ slots, int cap, SdDistortion D, sd_keypoint* __restrict__ kpUn,
+                                                         sd_keypoint* __restrict__ kpDUn)
+{
+    const int slot = slots[blockIdx.y], i = blockIdx.x * 256 + threadIdx.x;
+    const bool dyn = blockIdx.z != 0;
+    const int n = dyn ? nDynOf[(size_t)slot * fbStrideInts] : count[slot];
+    if (i >= n) return;
+    sd_keypoint k = (dyn ? kpD : kp)[(size_t)slot * cap + i];
+    float uo, vo;
+    sd_undistort_pt(D, k.x, k.y, uo, vo);
+    k.x = uo; k.y = vo;
+    (dyn ? kpDUn : kpUn)[(size_t)slot * cap + i] = k;
 }

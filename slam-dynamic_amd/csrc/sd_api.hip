@@ -74,6 +74,7 @@ struct sd_batch {
     uint32_t* d_lvlKp = nullptr;
     float2* d_rot = nullptr;
     sd_keypoint* d_kp = nullptr;
+    sd_keypoint* d_kpUn = nullptr; sd_keypoint* d_kpDUn = nullptr; SdDistortion dist; bool hasDist = false; int* d_unSlots = nullptr;   // mvKeysUn / mvdynKeysUn (sd_batch_set_distortion)
     uint8_t* d_desc = nullptr;
     int* d_count = nullptr;
     int* d_err = nullptr;
@@ -132,6 +133,10 @@ struct sd_batch {
     double totalMs[K_COUNT] = {0};
     int64_t launches[K_COUNT] = {0};
 };
+
+// mvKeysUn of the batch: the key points themselves unless a distortion was set (Frame.cc:814-818)
+#define KPUN(b) ((b)->hasDist ? (b)->d_kpUn : (b)->d_kp)
+#define KPDUN(b) ((b)->hasDist ? (b)->d_kpDUn : (b)->d_kpD)
 
 extern "C" {
 
@@ -233,7 +238,7 @@ static void batch_free(sd_batch* b)
                     b->d_sepPairs, b->d_kpD, b->d_descD, b->d_urD, b->d_depD, b->d_rowIdx, b->d_rowStart,
                     b->d_lmCand, b->d_lmN, b->d_lmOvf, b->d_lmIdx, b->d_bowWordF, b->d_bowWF, b->d_bowNidF, b->d_fvNode, b->d_fvFeat,
                     b->d_fvRunStart, b->d_fvRunNode, b->d_bowWord, b->d_bowVal, b->d_bowMeta, b->d_bowImg,
-                    b->d_moPts, b->d_moNorm, b->d_moCounts, b->d_moMaskH, b->d_moMaskF, b->d_moRes, b->d_pyrExt, b->d_copyPairs, b->d_cloudBits, b->d_cloudRows, b->d_cloudT, b->d_cloudSlots};
+                    b->d_moPts, b->d_moNorm, b->d_moCounts, b->d_moMaskH, b->d_moMaskF, b->d_moRes, b->d_pyrExt, b->d_copyPairs, b->d_kpUn, b->d_kpDUn, b->d_unSlots, b->d_cloudBits, b->d_cloudRows, b->d_cloudT, b->d_cloudSlots};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& r : b->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : b->pool) (void)hipEventDestroy(e);
@@ -802,7 +807,7 @@ int sd_batch_rgbd_from_u16(sd_batch* b, const uint16_t* d_depth, size_t stride_e
     {
         ProfScope ps(b, s, K_RGBD);
         dim3 grd((b->plan.kpCap + 255) / 256, n_images);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rgbd<uint16_t>), grd, dim3(256), 0, s, b->d_kp, b->d_count, d_depth, stride_elems,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rgbd<uint16_t>), grd, dim3(256), 0, s, b->d_kp, KPUN(b), b->d_count, d_depth, stride_elems,
                            image_pitch_elems, depth_factor, mbf, b->d_uright, b->d_depth, b->d_plan);
     }
     LAUNCH_CHECK("k_rgbd");
@@ -820,7 +825,7 @@ int sd_batch_rgbd_from_f32(sd_batch* b, const float* d_depth, size_t stride_elem
     {
         ProfScope ps(b, s, K_RGBD);
         dim3 grd((b->plan.kpCap + 255) / 256, n_images);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rgbd<float>), grd, dim3(256), 0, s, b->d_kp, b->d_count, d_depth, stride_elems,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rgbd<float>), grd, dim3(256), 0, s, b->d_kp, KPUN(b), b->d_count, d_depth, stride_elems,
                            image_pitch_elems, 1.0f, mbf, b->d_uright, b->d_depth, b->d_plan);
     }
     LAUNCH_CHECK("k_rgbd");
@@ -931,7 +936,7 @@ static int assign_grid_impl(sd_batch* b, int n_images, int image_step, const sd_
     {
         ProfScope ps(b, s, K_GRID);
         dim3 grd((b->plan.kpCap + 255) / 256, n_images);
-        hipLaunchKernelGGL(k_grid_cells, grd, dim3(256), 0, s, b->d_kp, b->d_count, b->d_cellOf, to_cam(cam), b->plan.kpCap, image_step);
+        hipLaunchKernelGGL(k_grid_cells, grd, dim3(256), 0, s, KPUN(b), b->d_count, b->d_cellOf, to_cam(cam), b->plan.kpCap, image_step);
     }
     LAUNCH_CHECK("k_grid_cells");
     const size_t gridLds = (size_t)(SD_GRID_CELLS + 8) * 4 + (size_t)SD_GRID_CELLS * 4 + (size_t)b->plan.kpCap * 2 + 16;
@@ -970,7 +975,7 @@ int sd_batch_unproject(sd_batch* b, int first_image, int image_step, int n_frame
     {
         ProfScope ps(b, s, K_UNPROJ);
         dim3 grd((b->plan.kpCap + 255) / 256, n_frames);
-        hipLaunchKernelGGL(k_unproject, grd, dim3(256), 0, s, b->d_kp, b->d_count, b->d_depth, b->d_pose, b->d_xw, b->d_flags,
+        hipLaunchKernelGGL(k_unproject, grd, dim3(256), 0, s, KPUN(b), b->d_count, b->d_depth, b->d_pose, b->d_xw, b->d_flags,
                            to_cam(cam), b->plan.kpCap, image_step);
     }
     LAUNCH_CHECK("k_unproject");
@@ -1062,7 +1067,7 @@ static int search_by_projection_impl(sd_batch* b, int pairBase, int n_pairs, con
         ProfScope ps(b, s, K_PROJ_A);
         dim3 grd((cap + 15) / 16, n_pairs);                 // 16 points per workgroup: four per wave, 16 lanes each
         SdProjArgs pa;
-        pa.kp = b->d_kp; pa.desc = b->d_desc; pa.uRight = b->d_uright; pa.count = b->d_count; pa.cellOf = b->d_cellOf;
+        pa.kp = KPUN(b); pa.desc = b->d_desc; pa.uRight = b->d_uright; pa.count = b->d_count; pa.cellOf = b->d_cellOf;
         pa.sortedIdx = b->d_sortedIdx; pa.cellStart = b->d_cellStart; pa.xw = b->d_xw; pa.flags = b->d_flags;
         pa.dmp = d_mp_desc ? d_mp_desc : b->d_desc; pa.Tcw = dTc; pa.Tlw = dTl; pa.cand = b->d_pcand + pOff * SD_PROJ_K; pa.ncand = b->d_pncand + pOff;
         pa.errFlag = b->d_err; pa.P = b->d_plan; pa.cam = to_cam(cam); pa.th = th; pa.bMono = bMono; pa.pairIdx = dIdx;
@@ -1076,7 +1081,7 @@ static int search_by_projection_impl(sd_batch* b, int pairBase, int n_pairs, con
         size_t lds = capA * (4 + 4 + 4 + 2 + 1 + 1 + 1) + 16;
         if (lds > 160 * 1024 - 256) return set_err(SD_ERR_UNSUPPORTED, "too many keypoints per image for the projection matcher's LDS tables");
         if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_proj_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_proj_resolve, dim3(n_pairs), dim3(64), lds, s, b->d_kp, b->d_count, b->d_flags, b->d_pcand + pOff * SD_PROJ_K, b->d_pncand + pOff,
+        hipLaunchKernelGGL(k_proj_resolve, dim3(n_pairs), dim3(64), lds, s, KPUN(b), b->d_count, b->d_flags, b->d_pcand + pOff * SD_PROJ_K, b->d_pncand + pOff,
                            d_occupied, b->d_match + pOff, b->d_pairs + pOff * 2, b->d_npairs + pairBase, b->d_nmatch + pairBase, b->d_plan, checkOrientation,
                            dIdx, d_active, redoBelow);
     }
@@ -1129,7 +1134,7 @@ int sd_batch_search_local_map(sd_batch* b, int n_frames, const int32_t* frame_in
     const int cap = b->plan.kpCap;
     if (maxM > 0) {
         ProfScope ps(b, s, K_LOCAL_A);
-        hipLaunchKernelGGL(k_local_candidates, dim3((maxM + 3) / 4, n_frames), dim3(256), 0, s, b->d_kp, b->d_desc, b->d_uright, b->d_count,
+        hipLaunchKernelGGL(k_local_candidates, dim3((maxM + 3) / 4, n_frames), dim3(256), 0, s, KPUN(b), b->d_desc, b->d_uright, b->d_count,
                            b->d_cellOf, b->d_sortedIdx, b->d_cellStart, (const SdMapPoint*)d_points, d_point_desc, dFrameOf, dOff, dT,
                            (SdTrack*)d_track, b->d_lmCand, b->d_lmN, b->d_lmOvf, b->d_plan, to_cam(cam), th, viewing_cos_limit);
         LAUNCH_CHECK("k_local_candidates");
@@ -1137,7 +1142,7 @@ int sd_batch_search_local_map(sd_batch* b, int n_frames, const int32_t* frame_in
     {
         ProfScope ps(b, s, K_LOCAL_B);
         const size_t lds = (size_t)cap * 4 + cap + 16;
-        hipLaunchKernelGGL(k_local_resolve, dim3(n_frames), dim3(64), lds, s, b->d_kp, b->d_count, (const SdMapPoint*)d_points, dFrameOf, dOff,
+        hipLaunchKernelGGL(k_local_resolve, dim3(n_frames), dim3(64), lds, s, KPUN(b), b->d_count, (const SdMapPoint*)d_points, dFrameOf, dOff,
                            b->d_lmCand, b->d_lmN, b->d_lmOvf, d_occupied, d_point_match, d_kp_match, d_nmatches, b->d_err, b->d_plan, nnratio);
         LAUNCH_CHECK("k_local_resolve");
     }
@@ -1407,7 +1412,7 @@ static int estimate_motion_impl(sd_batch* b, int n_pairs, void* stream_, const i
     }
     {
         ProfScope ps(b, s, K_MOTION_P);
-        hipLaunchKernelGGL(k_motion_prepare, dim3(n_pairs), dim3(256), cap * 16, s, b->d_kp, b->d_pairs, b->d_npairs, b->d_pairIdx, (int)cap, b->d_moPts, b->d_moNorm,
+        hipLaunchKernelGGL(k_motion_prepare, dim3(n_pairs), dim3(256), cap * 16, s, KPUN(b), b->d_pairs, b->d_npairs, b->d_pairIdx, (int)cap, b->d_moPts, b->d_moNorm,
                            d_active, minMatches > 0 ? (const int*)b->d_nmatch : (const int*)nullptr, minMatches);
         LAUNCH_CHECK("k_motion_prepare");
     }
@@ -1476,6 +1481,65 @@ int sd_batch_undistort_keypoints(sd_batch* b, int n_images, const float* K4, con
     return SD_OK;
 }
 
+// mvKeysUn as a second key-point array of the batch: with a distortion set, grid, projection / local-map matchers, the RGB-D
+// right coordinate, UnprojectStereo, the motion fit's point pairs and classifyH / classifyF read the undistorted key points, exactly
+// where the reference reads mvKeysUn; box membership, the depth lookup and the stereo matcher keep reading mvKeys.
+int sd_batch_set_distortion(sd_batch* b, const float* K4, const float* dist5)
+{
+    if (!b || !K4 || !dist5) return SD_ERR_INVALID;
+    if (dist5[0] == 0.0f) { b->hasDist = false; return SD_OK; }       // mDistCoef.at<float>(0) == 0.0 -> mvKeysUn = mvKeys (Frame.cc:814-818)
+    const size_t nI = b->maxImages, cap = b->plan.kpCap;
+    if (!b->d_kpUn) {
+        HIPCHK(hipMalloc((void**)&b->d_kpUn, nI * cap * sizeof(sd_keypoint)));
+        HIPCHK(hipMalloc((void**)&b->d_kpDUn, nI * cap * sizeof(sd_keypoint)));
+        HIPCHK(hipMalloc((void**)&b->d_unSlots, nI * 4));
+    }
+    b->dist = to_distortion(K4, dist5);
+    b->hasDist = true;
+    return SD_OK;
+}
+
+int sd_batch_undistort(sd_batch* b, int n_slots, const int32_t* slots, void* stream_)
+{
+    if (!b || n_slots < 0 || n_slots > b->maxImages || (n_slots > 0 && !slots)) return set_err(SD_ERR_INVALID, "bad undistort arguments");
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
+    b->lastStream = s;
+    if (!b->hasDist || n_slots == 0) return SD_OK;
+    for (int i = 0; i < n_slots; i++) if (slots[i] < 0 || slots[i] >= b->maxImages) return set_err(SD_ERR_INVALID, "bad undistort slot");
+    HIPCHK(hipMemcpyAsync(b->d_unSlots, slots, (size_t)n_slots * 4, hipMemcpyHostToDevice, s));
+    const int cap = b->plan.kpCap;
+    hipLaunchKernelGGL(k_undistort_slots, dim3((cap + 255) / 256, n_slots, 2), dim3(256), 0, s, b->d_kp, b->d_kpD, b->d_count, &b->d_fb[0].nDyn,
+                       (int)(sizeof(SdFrameBoxes) / 4), b->d_unSlots, cap, b->dist, b->d_kpUn, b->d_kpDUn);
+    LAUNCH_CHECK("k_undistort_slots");
+    return SD_OK;
+}
+
+int sd_batch_download_keys_un(sd_batch* b, int image, sd_keypoint* kp, int cap, int* n)
+{
+    if (!b || !n || !slot_ok(b, image)) return SD_ERR_INVALID;
+    int rc = sd_batch_sync(b);
+    if (rc != SD_OK) return rc;
+    int cnt = 0;
+    HIPCHK(hipMemcpy(&cnt, b->d_count + image, 4, hipMemcpyDeviceToHost));
+    *n = cnt;
+    if (cnt > cap) return set_err(SD_ERR_CAPACITY, "keypoint buffer too small");
+    if (cnt > 0 && kp) HIPCHK(hipMemcpy(kp, KPUN(b) + (size_t)image * b->plan.kpCap, (size_t)cnt * sizeof(sd_keypoint), hipMemcpyDeviceToHost));
+    return SD_OK;
+}
+
+int sd_batch_download_dynamic_keys_un(sd_batch* b, int slot, sd_keypoint* kp, int cap, int* n)
+{
+    if (!b || !n || !slot_ok(b, slot)) return SD_ERR_INVALID;
+    int rc = sd_batch_sync(b);
+    if (rc != SD_OK) return rc;
+    SdFrameBoxes h;
+    HIPCHK(hipMemcpy(&h, b->d_fb + slot, sizeof(h), hipMemcpyDeviceToHost));
+    *n = h.nDyn;
+    if (h.nDyn > cap) return set_err(SD_ERR_CAPACITY, "dynamic keypoint buffer too small");
+    if (h.nDyn > 0 && kp) HIPCHK(hipMemcpy(kp, KPDUN(b) + (size_t)slot * b->plan.kpCap, (size_t)h.nDyn * sizeof(sd_keypoint), hipMemcpyDeviceToHost));
+    return SD_OK;
+}
+
 // Four corner points, once per camera: host arithmetic (double, the same expression order as the kernel).
 int sd_image_bounds(int cols, int rows, const float* K4, const float* dist5, float* bounds4)
 {
@@ -1521,6 +1585,7 @@ int sd_batch_copy_frame(sd_batch* b, int src, int dst, void* stream_)
     CP(b->d_kp, sizeof(sd_keypoint)); CP(b->d_desc, 32); CP(b->d_uright, 4); CP(b->d_depth, 4); CP(b->d_sad, 4);
     CP(b->d_cellOf, 2); CP(b->d_xw, 12); CP(b->d_flags, 1); CP(b->d_sortedIdx, 2);
     CP(b->d_kpD, sizeof(sd_keypoint)); CP(b->d_descD, 32); CP(b->d_urD, 4); CP(b->d_depD, 4);
+    if (b->hasDist) { CP(b->d_kpUn, sizeof(sd_keypoint)); CP(b->d_kpDUn, sizeof(sd_keypoint)); }
 #undef CP
 #define CPX(ptr, elems, elemBytes) do { if (nseg < 24) { segs.src[nseg] = (const char*)((ptr) + (size_t)src * (elems)); segs.dst[nseg] = (char*)((ptr) + (size_t)dst * (elems)); segs.bytes[nseg] = (unsigned)((elems) * (elemBytes)); nseg++; } } while (0)
     CPX(b->d_cellStart, SD_GRID_CELLS + 8, 2);
@@ -1571,7 +1636,7 @@ static SdCullPtrs cull_ptrs(sd_batch* b)
     SdCullPtrs A;
     A.kp = b->d_kp; A.desc = b->d_desc; A.uright = b->d_uright; A.depth = b->d_depth; A.count = b->d_count;
     A.kpT = b->d_kpT; A.descT = b->d_descT; A.urT = b->d_urT; A.depT = b->d_depT;
-    A.kpD = b->d_kpD; A.descD = b->d_descD; A.urD = b->d_urD; A.depD = b->d_depD;
+    A.kpD = b->d_kpD; A.descD = b->d_descD; A.urD = b->d_urD; A.depD = b->d_depD; A.kpDUn = KPDUN(b);
     A.fb = b->d_fb; A.boxItems = b->d_boxItems; A.cap = b->plan.kpCap; A.itemsCap = b->itemsCap; A.errFlag = b->d_err;
     return A;
 }

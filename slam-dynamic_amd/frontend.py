@@ -111,6 +111,10 @@ def lib():
         L.sd_tracker_track.argtypes = [vp, vp, sz, sz, vp, sz, sz, vp, vp, vp, vp, vp, vp, vp]
         L.sd_batch_copy_frames.argtypes = [vp, i, vp, vp, vp]
         L.sd_batch_boxes_device.argtypes = [vp, C.POINTER(vp)]
+        L.sd_batch_set_distortion.argtypes = [vp, vp, vp]
+        L.sd_batch_undistort.argtypes = [vp, i, vp, vp]
+        L.sd_batch_download_keys_un.argtypes = [vp, i, vp, i, C.POINTER(i)]
+        L.sd_image_bounds.argtypes = [i, i, vp, vp, vp]
         L.sd_batch_backproject_dense.argtypes = [vp, i, vp, vp, sz, sz, vp, sz, sz, f, vp, sz, sz, vp, vp, vp, i, vp, vp]
         _lib = L
     return _lib
@@ -226,6 +230,21 @@ class Batch:
         n = C.c_int()
         check(lib().sd_batch_download(self.h, image, _p(kp), _p(desc), self.cap, C.byref(n), _p(per_level)))
         return kp[:n.value].copy(), desc[:n.value].copy(), per_level
+
+    def download_keys_un(self, image):
+        """mvKeysUn of a slot (== mvKeys unless sd_batch_set_distortion was called with Camera.k1 != 0)."""
+        kp = np.zeros(self.cap, KP_DTYPE)
+        n = C.c_int()
+        check(lib().sd_batch_download_keys_un(self.h, image, _p(kp), self.cap, C.byref(n)))
+        return kp[:n.value].copy()
+
+    def set_distortion(self, K4, dist5):
+        k = np.ascontiguousarray(K4, np.float32); d = np.ascontiguousarray(dist5, np.float32)
+        check(lib().sd_batch_set_distortion(self.h, _p(k), _p(d)))
+
+    def undistort(self, slots, stream=None):
+        sl = np.ascontiguousarray(slots, np.int32)
+        check(lib().sd_batch_undistort(self.h, len(sl), _p(sl), C.c_void_p(stream or 0)))
 
     def pyramid(self, image, level):
         w, h = self.ex.level_size(self.W, self.H, level)
@@ -585,12 +604,29 @@ def box_track(boxes, last_objects, last_box_idx, last_omit, last_velocity, img_c
     return bx[:m].copy(), idx[:m].copy(), om[:m].copy(), vel[:m].copy()
 
 
+def image_bounds(cols, rows, K4, dist5):
+    """Frame::ComputeImageBounds (src/Frame.cc:844-872) through the C ABI -> (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+    k = np.ascontiguousarray(K4, np.float32); d = np.ascontiguousarray(dist5, np.float32); b = np.zeros(4, np.float32)
+    check(lib().sd_image_bounds(int(cols), int(rows), _p(k), _p(d), _p(b)))
+    return b
+
+
+def distortion_of(cfg):
+    return np.array([cfg.get(k, 0.0) for k in ("k1", "k2", "p1", "p2", "k3")], np.float32)
+
+
 def make_camera(cfg):
-    """Frame statics for an undistorted camera: bounds = image rectangle (Frame.cc:864-870), mb = mbf/fx."""
+    """Frame statics: mb = mbf / fx; bounds = the image rectangle for an undistorted camera (Frame.cc:864-870), the undistorted
+    corner points otherwise (ComputeImageBounds)."""
     fx = np.float32(cfg["fx"]); bf = np.float32(cfg["bf"])
-    return dict(fx=fx, fy=np.float32(cfg["fy"]), cx=np.float32(cfg["cx"]), cy=np.float32(cfg["cy"]), mbf=bf,
-                mb=np.float32(bf / fx), mnMinX=np.float32(0), mnMaxX=np.float32(cfg["width"]), mnMinY=np.float32(0),
-                mnMaxY=np.float32(cfg["height"]))
+    cam = dict(fx=fx, fy=np.float32(cfg["fy"]), cx=np.float32(cfg["cx"]), cy=np.float32(cfg["cy"]), mbf=bf,
+               mb=np.float32(bf / fx), mnMinX=np.float32(0), mnMaxX=np.float32(cfg["width"]), mnMinY=np.float32(0),
+               mnMaxY=np.float32(cfg["height"]))
+    d = distortion_of(cfg)
+    if d[0] != 0:
+        b = image_bounds(cfg["width"], cfg["height"], [cam["fx"], cam["fy"], cam["cx"], cam["cy"]], d)
+        cam.update(mnMinX=b[0], mnMaxX=b[1], mnMinY=b[2], mnMaxY=b[3])
+    return cam
 
 
 def camera_array(cam):

@@ -218,7 +218,10 @@ private:
         sdfe::check(sd_batch_download(batch_, slot, F.mvKeys.data(), F.mDescriptors.data(), cap, &n, nullptr), "download");
         sdfe::check(sd_batch_download_rgbd(batch_, slot, F.mvuRight.data(), F.mvDepth.data(), cap), "download");
         F.N = n; F.mvKeys.resize(n); F.mDescriptors.resize((size_t)n * 32); F.mvuRight.resize(n); F.mvDepth.resize(n);
-        F.mvKeysUn = F.mvKeys;                         // Camera.k1 == 0 (UndistortKeyPoints, Frame.cc:814-818)
+        F.mvKeysUn.resize(cap);                        // UndistortKeyPoints (Frame.cc:812-842): a copy when Camera.k1 == 0
+        int nu = 0;
+        sdfe::check(sd_batch_download_keys_un(batch_, slot, F.mvKeysUn.data(), cap, &nu), "download");
+        F.mvKeysUn.resize(nu);
         F.mvbOutlier.assign(n, false);
         // boxes and the per-box dynamic sets
         int nb = 0, nAll = 0, nStatic = 0;
@@ -230,6 +233,8 @@ private:
         std::vector<sd_keypoint> dk(cap); std::vector<uint8_t> dd((size_t)cap * 32); std::vector<float> du(cap), dz(cap);
         int nd = 0;
         sdfe::check(sd_batch_download_dynamic(batch_, slot, dk.data(), dd.data(), du.data(), dz.data(), cap, &nd), "download_dynamic");
+        std::vector<sd_keypoint> dku(cap);
+        sdfe::check(sd_batch_download_dynamic_keys_un(batch_, slot, dku.data(), cap, &nd), "download_dynamic");
         F.objects.resize(nb); F.box_idx.assign(idx, idx + nb); F.box_status.assign(st, st + nb); F.omit.resize(nb); F.box_velocity.resize(nb);
         F.mvdynKeys.resize(nb); F.mvdynKeysUn.resize(nb); F.mdynDescriptors.resize(nb); F.mvudynRight.resize(nb); F.mvdynDepth.resize(nb);
         for (int j = 0; j < nb; j++) {
@@ -237,7 +242,7 @@ private:
             F.omit[j] = R.omit[j] != 0; F.box_velocity[j].x = R.box_velocity[j][0]; F.box_velocity[j].y = R.box_velocity[j][1];
             for (int k = start[j]; k < start[j + 1]; k++) {
                 const int i = items[k];
-                F.mvdynKeys[j].push_back(dk[i]); F.mvdynKeysUn[j].push_back(dk[i]);
+                F.mvdynKeys[j].push_back(dk[i]); F.mvdynKeysUn[j].push_back(dku[i]);
                 F.mdynDescriptors[j].insert(F.mdynDescriptors[j].end(), dd.begin() + (size_t)i * 32, dd.begin() + (size_t)i * 32 + 32);
                 F.mvudynRight[j].push_back(du[i]); F.mvdynDepth[j].push_back(dz[i]);
             }

@@ -29,6 +29,12 @@ TUM3 = dict(width=640, height=480, fx=535.4, fy=539.2, cx=320.1, cy=247.6, bf=40
             depth_map_factor=5000.0)
 
 
+# Examples/RGB-D/TUM1.yaml: the one family of shipped settings with lens distortion (Camera.k1 != 0)
+TUM1 = dict(width=640, height=480, fx=517.306408, fy=516.469215, cx=318.643040, cy=255.313989, k1=0.262383, k2=-0.953104, p1=-0.005358,
+            p2=0.002628, k3=1.163314, bf=40.0, th_depth=40.0, fps=30.0, n_features=1000, scale_factor=1.2, n_levels=8, ini_th_fast=20,
+            min_th_fast=7, depth_map_factor=5000.0)
+
+
 def _rng(seq, frame):
     return np.random.Generator(np.random.PCG64(BASE_SEED + 1000 * seq + frame))
 

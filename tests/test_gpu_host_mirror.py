@@ -78,19 +78,19 @@ def _read_frame_dump(buf, off, fe):
         return a
     N, N_ori, N_d, nb, flag, ret, ref, fid = [int(v) for v in take(np.int32, 8)]
     out = dict(N=N, N_ori=N_ori, N_d=N_d, nb=nb, flag=flag, ret=ret, ref=ref, id=fid)
-    out["kp"] = take(fe.KP_DTYPE, N); out["desc"] = take(np.uint8, 32 * N).reshape(N, 32)
+    out["kp"] = take(fe.KP_DTYPE, N); out["kpUn"] = take(fe.KP_DTYPE, N); out["desc"] = take(np.uint8, 32 * N).reshape(N, 32)
     out["ur"] = take(np.float32, N); out["dep"] = take(np.float32, N)
     out["boxes"] = []
     for _ in range(nb):
         r = take(np.float64, 4); idx, st, om = [int(v) for v in take(np.int32, 3)]; vel = take(np.float64, 2)
         k = int(take(np.int32, 1)[0])
-        out["boxes"].append(dict(rect=r, idx=idx, status=st, omit=om, vel=vel, kp=take(fe.KP_DTYPE, k), desc=take(np.uint8, 32 * k).reshape(k, 32),
+        out["boxes"].append(dict(rect=r, idx=idx, status=st, omit=om, vel=vel, kp=take(fe.KP_DTYPE, k), kpUn=take(fe.KP_DTYPE, k), desc=take(np.uint8, 32 * k).reshape(k, 32),
                                  ur=take(np.float32, k), dep=take(np.float32, k)))
     out["cell"] = take(np.int32, N)
     return out, off
 
 
-@pytest.mark.parametrize("kind", ["stereo", "rgbd"])
+@pytest.mark.parametrize("kind", ["stereo", "rgbd", "rgbd-tum1"])
 def test_cpp_system_track_matches_frame_oracle(gpu, fe, orc, synth, tmp_path, kind):
     """host/Frame.h: ORB_SLAM2::System::TrackStereo / TrackRGBD (C++, g++, no OpenCV) frame by frame against the frame-level oracle:
     every public Frame member this path produces, bit for bit (stereo: KITTI configs[2]; RGB-D: TUM3 configs[3] with mask + boxes)."""
@@ -102,7 +102,8 @@ def test_cpp_system_track_matches_frame_oracle(gpu, fe, orc, synth, tmp_path, ki
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "slam-dynamic_amd", "host"),
                            os.path.join(ROOT, "tests/cpp/frame_mirror_main.cpp"), "-L" + libdir, "-lsd_frontend", "-Wl,-rpath," + libdir, "-o", exe])
     stereo = kind == "stereo"
-    cfg = synth.KITTI_STEREO if stereo else synth.TUM3
+    cfg = synth.KITTI_STEREO if stereo else (synth.TUM1 if kind == "rgbd-tum1" else synth.TUM3)      # TUM1: Camera.k1 != 0, mvKeysUn != mvKeys
+    kind = "stereo" if stereo else "rgbd"
     T = 5 if stereo else 9
     ch = 1 if stereo else 3
     W, H = cfg["width"], cfg["height"]
@@ -123,7 +124,8 @@ def test_cpp_system_track_matches_frame_oracle(gpu, fe, orc, synth, tmp_path, ki
     inp.write_bytes(b"".join(blob))
     subprocess.check_call([exe, kind, str(W), str(H), str(ch), str(T), str(inp), str(out), repr(float(np.float32(cfg["fx"]))), repr(float(np.float32(cfg["fy"]))),
                            repr(float(np.float32(cfg["cx"]))), repr(float(np.float32(cfg["cy"]))), repr(float(np.float32(cfg["bf"]))), str(cfg["fps"]),
-                           str(cfg.get("depth_map_factor", 1.0)), str(cfg["n_features"]), str(cfg["ini_th_fast"])])
+                           str(cfg.get("depth_map_factor", 1.0)), str(cfg["n_features"]), str(cfg["ini_th_fast"])] +
+                          [repr(float(np.float32(cfg.get(k, 0.0)))) for k in ("k1", "k2", "p1", "p2", "k3")])
     buf = out.read_bytes()
     off = 0
     ran = 0
@@ -132,7 +134,7 @@ def test_cpp_system_track_matches_frame_oracle(gpu, fe, orc, synth, tmp_path, ki
         tag = "%s frame %d" % (kind, t)
         assert (g["N"], g["N_ori"], g["N_d"], g["nb"], g["id"]) == (F.N, F.N_s, F.N_d, len(F.objects), F.mnId), tag
         assert (g["flag"], g["ref"]) == (F.track_flag, F.ref_id) and g["ret"] == (F.separate_ret or 0), tag
-        assert g["kp"].tobytes() == F.kp.tobytes() and np.array_equal(g["desc"], F.desc), tag + ": mvKeysUn / mDescriptors"
+        assert g["kp"].tobytes() == F.kp.tobytes() and g["kpUn"].tobytes() == F.kpUn.tobytes() and np.array_equal(g["desc"], F.desc), tag + ": mvKeys / mvKeysUn / mDescriptors"
         assert np.array_equal(g["ur"].view(np.uint32), F.ur.view(np.uint32)) and np.array_equal(g["dep"].view(np.uint32), F.dep.view(np.uint32)), tag
         assert np.array_equal(g["cell"], F.cells), tag + ": mGrid"
         for j, bx in enumerate(g["boxes"]):
@@ -140,6 +142,7 @@ def test_cpp_system_track_matches_frame_oracle(gpu, fe, orc, synth, tmp_path, ki
             assert np.array_equal(bx["vel"], F.velocity[j]), tag
             it = F.boxItems[F.boxStart[j]:F.boxStart[j + 1]]
             assert bx["kp"].tobytes() == F.dyn_kp[it].tobytes() and np.array_equal(bx["desc"], F.dyn_desc[it]), tag + ": mvdynKeys / mdynDescriptors"
+            assert bx["kpUn"].tobytes() == F.dyn_kpUn[it].tobytes(), tag + ": mvdynKeysUn"
             assert np.array_equal(bx["ur"].view(np.uint32), F.dyn_ur[it].view(np.uint32)) and np.array_equal(bx["dep"].view(np.uint32), F.dyn_dep[it].view(np.uint32)), tag
         ran += F.track_flag != 0
     assert off == len(buf) and ran >= 1, "the dynamic block must have run at least once"

@@ -46,6 +46,7 @@ def _check_frame(fe, trk, lane, R, F, tag):
     # Frame members
     kp, desc, _ = b.download(slot)
     assert kp.tobytes() == F.kp.tobytes(), tag + ": mvKeys"
+    assert b.download_keys_un(slot).tobytes() == F.kpUn.tobytes(), tag + ": mvKeysUn"
     assert np.array_equal(desc, F.desc), tag + ": mDescriptors"
     ur, dep = b.download_rgbd(slot)
     assert np.array_equal(_u32(ur[:F.N]), _u32(F.ur)) and np.array_equal(_u32(dep[:F.N]), _u32(F.dep)), tag + ": mvuRight / mvDepth"
@@ -186,6 +187,27 @@ def test_rgbd_chain_tum3(gpu, fe, orc, synth):
     assert st["flag0"] >= 1 and (5, 1, 0) in st["refs"], "lane 1 must see TrackHomo fail on a featureless frame: %r" % st
     assert (6, 1, 3) in st["refs"], "frame 6 of lane 1 must reject frames 1 and 2 and settle on frame 3 (two extra rounds): %r" % st
     assert st["flag1"] + st["flag2"] >= 4, "%r" % st
+
+
+def test_rgbd_chain_tum1_lens_distortion(gpu, fe, orc, synth):
+    """Examples/RGB-D/TUM1.yaml (Camera.k1 = 0.26: the shipped settings WITH lens distortion): mvKeysUn is a second key-point array, and
+    the grid, both projection matchers, the RGB-D right coordinate, UnprojectStereo, TrackHomo's point pairs and classifyH / classifyF read it
+    where the reference does, while box membership and the depth lookup stay on mvKeys -- 9 frames, two lanes, bit for bit."""
+    cfg = synth.TUM1
+    T = 9
+    st = [t / 30.0 for t in range(T)]
+
+    def frames(seq):
+        def f(t):
+            rgb, depth, _ = synth.rgbd_frame_dyn(seq, t, cfg)
+            return rgb, depth
+        return f
+
+    rect = lambda seq, t: synth.rows_to_rects(synth.boxes_for_frame(seq, t, cfg))
+    lanes = [dict(frames=frames(81), boxes=lambda t: rect(81, t), stamps=st),
+             dict(frames=frames(82), boxes=lambda t: None if t == 2 else rect(82, t), stamps=st)]
+    stt = _run_chain(fe, orc, synth, cfg, fe.SENSOR_RGBD, lanes, T, channels=3)
+    assert stt["flag1"] + stt["flag2"] >= 3 and stt["appended"] > 0, "%r" % stt
 
 
 def test_mono_chain_tum3(gpu, fe, orc, synth):
