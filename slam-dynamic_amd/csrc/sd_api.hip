@@ -2232,12 +2232,15 @@ static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int hei
         HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<16, 1, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(16, 1, 2, 8)));
         HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<16, 1, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(16, 1, 1, 8)));
         HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<8, 1, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(8, 1, 1, 8)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<16, 1, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(16, 1, 2, 4)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<16, 1, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(16, 1, 1, 4)));
         y->attrF32 = true;
     }
     // tile variant of the >= 128-filter layers: 1 (default) = two independent 4-wave workgroups per CU, 128 x 128 tiles (equal to the 8-wave
     // 128 x 256 tile at batch 128, 9 % faster at batch 32: finer tile-count quantisation, one workgroup's prologue under the other's
     // main loop); 0 = 8-wave tiles; 2 = 4-wave for the 1x1 layers only.  SD_F32_VARIANT is a developer switch.
     static const int variant = getenv("SD_F32_VARIANT") ? atoi(getenv("SD_F32_VARIANT")) : 1;
+    static const int small4 = getenv("SD_F32_SMALL4") ? atoi(getenv("SD_F32_SMALL4")) : 1;       // 4-wave tiles for the <= 64-filter layers too (0.5 % at batch 128); developer switch
     const float* cur = y->d_blob8;
     int H = y->netH, W = y->netW, Cs = 8;
     int rowBase = 0;
@@ -2257,8 +2260,12 @@ static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int hei
             const int npix = n * r.H * r.W;
             if (i == 0)                         // 3 (-> 8) input channels, <= 32 filters
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<8, 1, 1, 8>), dim3((npix + 511) / 512, (l.filters + 31) / 32), dim3(512), SD_F32_LDS(8, 1, 1, 8), s, A);
+            else if (l.filters <= 32 && small4)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 1, 4>), dim3((npix + 255) / 256, 1), dim3(256), SD_F32_LDS(16, 1, 1, 4), s, A);
             else if (l.filters <= 32)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 1, 8>), dim3((npix + 511) / 512, 1), dim3(512), SD_F32_LDS(16, 1, 1, 8), s, A);
+            else if (l.filters <= 64 && small4)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 2, 4>), dim3((npix + 255) / 256, 1), dim3(256), SD_F32_LDS(16, 1, 2, 4), s, A);
             else if (l.filters <= 64)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 2, 8>), dim3((npix + 511) / 512, 1), dim3(512), SD_F32_LDS(16, 1, 2, 8), s, A);
             else if (variant == 1 || (variant == 2 && l.size == 1))
