@@ -106,21 +106,23 @@ __device__ inline void sd_f_denormalize(const double* Fn, const SdMotionNorm& n,
     sd_mat3_mul_d(Fn, T1, t);
     sd_mat3_mul_d(T2t, t, F);
 }
+// The 3-px predicates in cross-multiplied form (no f64 division in the loop that dominates k_motion_hyp: the same inequalities,
+// |x2 - H x1|^2 <= 9 multiplied through by w^2 and d^2 / (a^2 + b^2) <= 9 by the line's norm); the oracle evaluates the same
+// products and sums in the same order.
 __device__ __forceinline__ bool sd_h_inlier(const double* H, double x1, double y1, double x2, double y2)
 {
     const double w = H[6] * x1 + H[7] * y1 + H[8];
-    const double u = (H[0] * x1 + H[1] * y1 + H[2]) / w, v = (H[3] * x1 + H[4] * y1 + H[5]) / w;
-    const double dx = u - x2, dy = v - y2;
-    return dx * dx + dy * dy <= 9.0;
+    const double A = H[0] * x1 + H[1] * y1 + H[2], B = H[3] * x1 + H[4] * y1 + H[5];
+    const double dx = A - x2 * w, dy = B - y2 * w;
+    return dx * dx + dy * dy <= 9.0 * (w * w);
 }
 __device__ __forceinline__ bool sd_f_inlier(const double* F, double x1, double y1, double x2, double y2)
 {
     double a = F[0] * x1 + F[1] * y1 + F[2], b = F[3] * x1 + F[4] * y1 + F[5], c = F[6] * x1 + F[7] * y1 + F[8];
-    const double s2 = 1.0 / (a * a + b * b), d2 = x2 * a + y2 * b + c;
+    const double n2 = a * a + b * b, d2 = x2 * a + y2 * b + c;
     a = F[0] * x2 + F[3] * y2 + F[6]; b = F[1] * x2 + F[4] * y2 + F[7]; c = F[2] * x2 + F[5] * y2 + F[8];
-    const double s1 = 1.0 / (a * a + b * b), d1 = x1 * a + y1 * b + c;
-    const double e1 = d1 * d1 * s1, e2 = d2 * d2 * s2;
-    return (e1 > e2 ? e1 : e2) <= 9.0;
+    const double n1 = a * a + b * b, d1 = x1 * a + y1 * b + c;
+    return d1 * d1 <= 9.0 * n1 && d2 * d2 <= 9.0 * n2;
 }
 
 #define SD_N1X(P, i, n) (((double)(P)[4 * (i)] - (n).meanX1) * (n).sX1)
