@@ -15,6 +15,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "sd_frontend.h"
@@ -117,23 +118,34 @@ public:
     sd_extractor* handle() { return ex_; }
     sd_batch* batch() { return batch_; }
 
+    // The reference signature's body for ANY types with OpenCV's member names: MatT has .data .cols .rows .step .empty() .type(),
+    // KeyPointT is a 28-byte record laid out like cv::KeyPoint, OutArrT has create(rows, cols, type) / release() / getMat().data
+    // like cv::_OutputArray.  cv::Mat, cv::KeyPoint and cv::OutputArray satisfy this; tests/cpp/cv_like.h holds stand-in types with
+    // the same members so that THIS code is compiled and run on the GPU without OpenCV (tests/test_gpu_host_mirror.py).
+    template <class MatT, class KeyPointT, class OutArrT>
+    void extract(const MatT& image, std::vector<KeyPointT>& _keypoints, OutArrT& _descriptors)
+    {
+        static_assert(sizeof(KeyPointT) == sizeof(sd_keypoint), "the key-point type must have cv::KeyPoint's 28-byte layout");
+        if (image.empty()) return;                                     // ORBextractor.cc:1046-1047
+        if (image.type() != 0) throw std::invalid_argument("ORBextractor: image must be CV_8UC1");     // assert(image.type() == CV_8UC1), :1050
+        std::vector<sd_keypoint> kps; std::vector<uint8_t> desc;
+        sdfe::ImageView v; v.data = image.data; v.cols = image.cols; v.rows = image.rows; v.step = (size_t)image.step;
+        (*this)(v, sdfe::ImageView(), kps, desc);
+        _keypoints.resize(kps.size());
+        if (!kps.empty()) std::memcpy((void*)_keypoints.data(), kps.data(), kps.size() * sizeof(sd_keypoint));
+        if (kps.empty()) { _descriptors.release(); return; }           // :1064-1065
+        _descriptors.create((int)kps.size(), 32, 0 /* CV_8U */);
+        std::memcpy(_descriptors.getMat().data, desc.data(), desc.size());
+    }
+
 #ifdef SD_HAVE_OPENCV
-    // The reference signature itself (ORBextractor.h:59): with this overload the class drops into
-    // Frame::ExtractORB (Frame.cc:655-661) unchanged.
+    // The reference signature itself (ORBextractor.h:59): with this overload the class drops into Frame::ExtractORB (Frame.cc:655-661)
+    // unchanged; it only names the OpenCV types, the body is extract() above.
     void operator()(cv::InputArray _image, cv::InputArray, std::vector<cv::KeyPoint>& _keypoints, cv::OutputArray _descriptors)
     {
         if (_image.empty()) return;
         cv::Mat image = _image.getMat();
-        CV_Assert(image.type() == CV_8UC1);
-        static_assert(sizeof(cv::KeyPoint) == sizeof(sd_keypoint), "cv::KeyPoint layout");
-        std::vector<sd_keypoint> kps; std::vector<uint8_t> desc;
-        sdfe::ImageView v; v.data = image.data; v.cols = image.cols; v.rows = image.rows; v.step = image.step;
-        (*this)(v, sdfe::ImageView(), kps, desc);
-        _keypoints.resize(kps.size());
-        if (!kps.empty()) std::memcpy((void*)_keypoints.data(), kps.data(), kps.size() * sizeof(sd_keypoint));
-        if (kps.empty()) { _descriptors.release(); return; }
-        _descriptors.create((int)kps.size(), 32, CV_8U);
-        std::memcpy(_descriptors.getMat().data, desc.data(), desc.size());
+        extract(image, _keypoints, _descriptors);
     }
 #endif
 
@@ -158,9 +170,9 @@ public:
     static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;   // ORBmatcher.cc:37-39
     // Computes the Hamming distance between two ORB descriptors (ORBmatcher.h:44)
     static int DescriptorDistance(const uint8_t* a, const uint8_t* b) { return sd_descriptor_distance(a, b); }
-#ifdef SD_HAVE_OPENCV
-    static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b) { return sd_descriptor_distance(a.ptr<uint8_t>(), b.ptr<uint8_t>()); }
-#endif
+    // int DescriptorDistance(const cv::Mat &a, const cv::Mat &b) (ORBmatcher.h:44) for any row type with a .data pointer (cv::Mat is one)
+    template <class MatT, class = typename std::enable_if<std::is_class<MatT>::value>::type>
+    static int DescriptorDistance(const MatT& a, const MatT& b) { return sd_descriptor_distance((const uint8_t*)a.data, (const uint8_t*)b.data); }
 };
 
 }  // namespace ORB_SLAM2

@@ -8,6 +8,7 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
@@ -142,22 +143,27 @@ public:
         return mask;
     }
 
-#ifdef SD_HAVE_OPENCV
-    std::vector<cv::Rect2d> Segmentation_(cv::Mat& image)
+    // vector<cv::Rect2d> Segmentation_(cv::Mat&) / cv::Mat Segmentation(cv::Mat&) (include/yolo.h:34-35) for ANY types with OpenCV's member
+    // names (RectT(x, y, width, height); MatT with .data .cols .rows .step and a (rows, cols, type) constructor): cv::Rect2d / cv::Mat in a
+    // build that has OpenCV, tests/cpp/cv_like.h's stand-ins here, where this code is compiled and run by tests/test_gpu_host_mirror.py.
+    template <class RectT, class MatT> std::vector<RectT> SegmentationRects(MatT& image)
     {
-        sdfe::ImageView v; v.data = image.data; v.cols = image.cols; v.rows = image.rows; v.step = image.step;
-        std::vector<cv::Rect2d> out;
-        for (const Rect2d& r : Segmentation_(v)) out.push_back(cv::Rect2d(r.x, r.y, r.width, r.height));
+        sdfe::ImageView v; v.data = image.data; v.cols = image.cols; v.rows = image.rows; v.step = (size_t)image.step;
+        std::vector<RectT> out;
+        for (const Rect2d& r : Segmentation_(v)) out.push_back(RectT(r.x, r.y, r.width, r.height));
         return out;
     }
-    cv::Mat Segmentation(cv::Mat& image)
+    template <class MatT> MatT SegmentationMat(MatT& image)
     {
-        sdfe::ImageView v; v.data = image.data; v.cols = image.cols; v.rows = image.rows; v.step = image.step;
+        sdfe::ImageView v; v.data = image.data; v.cols = image.cols; v.rows = image.rows; v.step = (size_t)image.step;
         const std::vector<uint8_t> m = Segmentation(v);
-        cv::Mat out(image.rows, image.cols, CV_8U);
-        std::memcpy(out.data, m.data(), m.size());
+        MatT out(image.rows, image.cols, 0 /* CV_8U */);
+        for (int y = 0; y < image.rows; y++) std::memcpy(out.data + (size_t)y * (size_t)out.step, m.data() + (size_t)y * image.cols, (size_t)image.cols);
         return out;
     }
+#ifdef SD_HAVE_OPENCV
+    std::vector<cv::Rect2d> Segmentation_(cv::Mat& image) { return SegmentationRects<cv::Rect2d>(image); }
+    cv::Mat Segmentation(cv::Mat& image) { return SegmentationMat(image); }
 #endif
 };
 

@@ -3,8 +3,10 @@
 // writes: int32 n, n x sd_keypoint, n x 32 descriptor bytes, then the padded level-1 pyramid plane.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "ORBextractor.h"
+#include "cv_like.h"
 
 int main(int argc, char** argv)
 {
@@ -26,6 +28,25 @@ int main(int argc, char** argv)
         ex(v, empty, kps, desc);
         if (ex.GetLevels() != 8 || ex.GetScaleFactors().size() != 8) return 5;
         if (ORB_SLAM2::ORBmatcher::DescriptorDistance(desc.data(), desc.data()) != 0) return 6;
+        {   // the cv-typed path: the same template body an OpenCV build runs, here with stand-in types of the same member names
+            cvlike::Mat cimg(h, w, 0, img.data(), (size_t)w);
+            std::vector<cvlike::KeyPoint> ck;
+            cvlike::OutputArray cd;
+            ex.extract(cimg, ck, cd);
+            if (ck.size() != kps.size() || cd.getMat().rows != (int)kps.size() || cd.getMat().cols != 32) return 8;
+            if (memcmp(ck.data(), kps.data(), kps.size() * sizeof(sd_keypoint)) != 0 || memcmp(cd.getMat().data, desc.data(), desc.size()) != 0) return 9;
+            if (ck[0].pt.x != kps[0].x || ck[0].octave != kps[0].octave) return 10;
+            cvlike::Mat a(1, 32, 0, cd.getMat().data, 32), b(1, 32, 0, cd.getMat().data + 32, 32);
+            if (ORB_SLAM2::ORBmatcher::DescriptorDistance(a, b) != ORB_SLAM2::ORBmatcher::DescriptorDistance(desc.data(), desc.data() + 32)) return 11;
+            cvlike::Mat none;
+            ex.extract(none, ck, cd);                    // empty image: silent return, outputs untouched
+            if (ck.size() != kps.size()) return 12;
+            cvlike::Mat flat(h, w, 0);                   // no key points: descriptors released (ORBextractor.cc:1064-1065)
+            memset(flat.data, 77, (size_t)w * h);
+            ex.extract(flat, ck, cd);
+            if (!ck.empty() || !cd.getMat().empty()) return 13;
+            ex(v, empty, kps, desc);                     // restore the state the dump below expects
+        }
         ex.SyncPyramid();
         const ORB_SLAM2::ORBextractor::PyramidLevel& P1 = ex.mvImagePyramid[1];
         FILE* o = fopen(argv[4], "wb");

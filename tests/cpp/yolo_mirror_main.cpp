@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <vector>
 #include "yolo.h"
+#include "cv_like.h"
+#include <cstring>
 
 int main(int argc, char** argv)
 {
@@ -22,6 +24,15 @@ int main(int argc, char** argv)
         sdfe::ImageView v; v.data = img.data(); v.cols = w; v.rows = h; v.step = (size_t)w * 3;
         const std::vector<yolov3::Rect2d> boxes = yolo.Segmentation_(v);
         const std::vector<uint8_t> mask = yolo.Segmentation(v);
+        {   // the cv-typed entry points' bodies (what an OpenCV build runs), with stand-in types of the same member names
+            cvlike::Mat cimg(h, w, 16 /* CV_8UC3 */, img.data(), (size_t)w * 3);
+            const std::vector<cvlike::Rect2d> cb = yolo.SegmentationRects<cvlike::Rect2d>(cimg);
+            if (cb.size() != boxes.size()) return 5;
+            for (size_t i = 0; i < cb.size(); i++)
+                if (cb[i].x != boxes[i].x || cb[i].y != boxes[i].y || cb[i].width != boxes[i].width || cb[i].height != boxes[i].height) return 6;
+            const cvlike::Mat cm = yolo.SegmentationMat(cimg);
+            if (cm.rows != h || cm.cols != w || memcmp(cm.data, mask.data(), mask.size()) != 0) return 7;
+        }
         FILE* o = fopen(argv[6], "wb");
         const int32_t n = (int32_t)boxes.size();
         fwrite(&n, 4, 1, o);
