@@ -177,28 +177,34 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 const uint8_t* p = tile + (sy + 3) * SD_FS_TW + sx + 4;
                 const int S = SD_FS_TW;
                 const int v = p[0];
-                int d[16];
-                d[0] = v - p[3 * S];       d[1] = v - p[3 * S + 1];   d[2] = v - p[2 * S + 2];   d[3] = v - p[S + 3];
-                d[4] = v - p[3];           d[5] = v - p[-S + 3];      d[6] = v - p[-2 * S + 2];  d[7] = v - p[-3 * S + 1];
-                d[8] = v - p[-3 * S];      d[9] = v - p[-3 * S - 1];  d[10] = v - p[-2 * S - 2]; d[11] = v - p[-S - 3];
-                d[12] = v - p[-3];         d[13] = v - p[S - 3];      d[14] = v - p[2 * S - 2];  d[15] = v - p[3 * S - 1];
-                int mn3[16], mx3[16];
+                // Polarity first: a 9-arc holds at least two of the four compass points, so the pixel can only be a "darker ring"
+                // corner at T if two compass points are < v - T and a "brighter ring" corner if two are > v + T.  The 16 ring
+                // differences are formed with the sign of the possible polarity folded in (one v_mad_i32_i24 each, the price of the
+                // plain subtraction), and only that polarity's 9-arc minima are evaluated: half the min3/max3 work.  Both at once
+                // (0.2 - 0.7 % of the survivors) is handled by a second evaluation in the waves that hold such a pixel; a polarity
+                // that cannot reach T contributes nothing to max(dark, bright) of a corner, so the stored score is unchanged.
+                const int r0 = p[3 * S], r4 = p[3], r8 = p[-3 * S], r12 = p[-3];
+                const int lo = v - T, hi = v + T;
+                const bool dark = (r0 < lo) + (r4 < lo) + (r8 < lo) + (r12 < lo) >= 2;
+                const bool both = dark && (r0 > hi) + (r4 > hi) + (r8 > hi) + (r12 > hi) >= 2;
+                auto side = [&](const int sg) -> int {
+                    const int sv = sg * v, ng = -sg;
+                    int d[16];
+                    d[0] = __mul24(r0, ng) + sv;             d[1] = __mul24(p[3 * S + 1], ng) + sv;   d[2] = __mul24(p[2 * S + 2], ng) + sv;   d[3] = __mul24(p[S + 3], ng) + sv;
+                    d[4] = __mul24(r4, ng) + sv;             d[5] = __mul24(p[-S + 3], ng) + sv;      d[6] = __mul24(p[-2 * S + 2], ng) + sv;  d[7] = __mul24(p[-3 * S + 1], ng) + sv;
+                    d[8] = __mul24(r8, ng) + sv;             d[9] = __mul24(p[-3 * S - 1], ng) + sv;  d[10] = __mul24(p[-2 * S - 2], ng) + sv; d[11] = __mul24(p[-S - 3], ng) + sv;
+                    d[12] = __mul24(r12, ng) + sv;           d[13] = __mul24(p[S - 3], ng) + sv;      d[14] = __mul24(p[2 * S - 2], ng) + sv;  d[15] = __mul24(p[3 * S - 1], ng) + sv;
+                    int mn3[16], a9[16];
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    mn3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-                    mx3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-                }
-                int a9[16], b9[16];
+                    for (int k = 0; k < 16; k++) mn3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    a9[k] = min(min(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]);
-                    b9[k] = max(max(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]);
-                }
-#pragma unroll
-                for (int w = 8; w >= 1; w >>= 1)
-#pragma unroll
-                    for (int k = 0; k < w; k++) { a9[k] = max(a9[k], a9[k + w]); b9[k] = min(b9[k], b9[k + w]); }
-                const int sc = max(a9[0], -b9[0]) - 1;
+                    for (int k = 0; k < 16; k++) a9[k] = min(min(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]);
+                    a9[0] = max(max(a9[0], a9[1]), a9[2]);    a9[3] = max(max(a9[3], a9[4]), a9[5]);    a9[6] = max(max(a9[6], a9[7]), a9[8]);
+                    a9[9] = max(max(a9[9], a9[10]), a9[11]);  a9[12] = max(max(a9[12], a9[13]), a9[14]);
+                    return max(max(max(a9[0], a9[3]), a9[6]), max(max(a9[9], a9[12]), a9[15]));
+                };
+                int sc = side(dark ? 1 : -1) - 1;
+                if (__any(both)) { if (both) sc = max(sc, side(-1) - 1); }
                 corner = sc >= T;
                 if (corner) score[(sy + 1) * SD_FS_SW + sx + 1] = (uint8_t)sc;
             }

@@ -95,7 +95,7 @@ struct sd_batch {
     unsigned* d_bowWordF = nullptr; double* d_bowWF = nullptr; unsigned* d_bowNidF = nullptr; unsigned* d_fvNode = nullptr; unsigned* d_fvFeat = nullptr;
     int* d_fvRunStart = nullptr; unsigned* d_fvRunNode = nullptr; unsigned* d_bowWord = nullptr; double* d_bowVal = nullptr; int* d_bowMeta = nullptr;
     int* d_bowImg = nullptr; std::vector<uint8_t> bowValid;
-    float* d_moPts = nullptr; SdMotionNorm* d_moNorm = nullptr; int* d_moCounts = nullptr; uint8_t* d_moMaskH = nullptr; uint8_t* d_moMaskF = nullptr;
+    float* d_moPts = nullptr; SdMotionNorm* d_moNorm = nullptr; int* d_moCounts = nullptr; double* d_moModels = nullptr; uint8_t* d_moMaskH = nullptr; uint8_t* d_moMaskF = nullptr;
     SdMotionResult* d_moRes = nullptr; int nMotion = 0;      // TrackHomo model fit
     unsigned* d_lmCand = nullptr; uint8_t* d_lmN = nullptr; uint8_t* d_lmOvf = nullptr; int* d_lmIdx = nullptr; int lmCap = 0;   // local-map search scratch
     int* d_match = nullptr;
@@ -238,7 +238,7 @@ static void batch_free(sd_batch* b)
                     b->d_sepPairs, b->d_kpD, b->d_descD, b->d_urD, b->d_depD, b->d_rowIdx, b->d_rowStart,
                     b->d_lmCand, b->d_lmN, b->d_lmOvf, b->d_lmIdx, b->d_bowWordF, b->d_bowWF, b->d_bowNidF, b->d_fvNode, b->d_fvFeat,
                     b->d_fvRunStart, b->d_fvRunNode, b->d_bowWord, b->d_bowVal, b->d_bowMeta, b->d_bowImg,
-                    b->d_moPts, b->d_moNorm, b->d_moCounts, b->d_moMaskH, b->d_moMaskF, b->d_moRes, b->d_pyrExt, b->d_copyPairs, b->d_kpUn, b->d_kpDUn, b->d_unSlots, b->d_cloudBits, b->d_cloudRows, b->d_cloudT, b->d_cloudSlots};
+                    b->d_moPts, b->d_moNorm, b->d_moCounts, b->d_moModels, b->d_moMaskH, b->d_moMaskF, b->d_moRes, b->d_pyrExt, b->d_copyPairs, b->d_kpUn, b->d_kpDUn, b->d_unSlots, b->d_cloudBits, b->d_cloudRows, b->d_cloudT, b->d_cloudSlots};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& r : b->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : b->pool) (void)hipEventDestroy(e);
@@ -1407,7 +1407,7 @@ static int estimate_motion_impl(sd_batch* b, int n_pairs, void* stream_, const i
     const size_t nI = b->maxImages, cap = b->plan.kpCap;
     if (!b->d_moPts) {
         HIPCHK(hipMalloc((void**)&b->d_moPts, nI * cap * 16)); HIPCHK(hipMalloc((void**)&b->d_moNorm, nI * sizeof(SdMotionNorm)));
-        HIPCHK(hipMalloc((void**)&b->d_moCounts, nI * SD_MOTION_K * 4)); HIPCHK(hipMalloc((void**)&b->d_moMaskH, nI * cap));
+        HIPCHK(hipMalloc((void**)&b->d_moCounts, nI * SD_MOTION_K * 4)); HIPCHK(hipMalloc((void**)&b->d_moModels, nI * SD_MOTION_K * 72)); HIPCHK(hipMalloc((void**)&b->d_moMaskH, nI * cap));
         HIPCHK(hipMalloc((void**)&b->d_moMaskF, nI * cap)); HIPCHK(hipMalloc((void**)&b->d_moRes, nI * sizeof(SdMotionResult)));
     }
     {
@@ -1418,8 +1418,13 @@ static int estimate_motion_impl(sd_batch* b, int n_pairs, void* stream_, const i
     }
     {
         ProfScope ps(b, s, K_MOTION_H);
-        hipLaunchKernelGGL(k_motion_hyp, dim3(SD_MOTION_K / 256, n_pairs), dim3(256), cap * 16, s, b->d_moPts, b->d_moNorm, (int)cap, b->d_moCounts, d_active);
-        LAUNCH_CHECK("k_motion_hyp");
+        for (int stage = 0; stage < 2; stage++) {
+            const int nh = stage ? SD_MOTION_N1 : SD_MOTION_N0;
+            hipLaunchKernelGGL(k_motion_models, dim3(nh / 64, n_pairs), dim3(64), 0, s, b->d_moPts, b->d_moNorm, (int)cap, b->d_moCounts, b->d_moModels, d_active, stage);
+            LAUNCH_CHECK("k_motion_models");
+            hipLaunchKernelGGL(k_motion_count, dim3(nh / SD_MOTION_HB, n_pairs), dim3(256), 0, s, b->d_moPts, b->d_moNorm, (int)cap, b->d_moCounts, b->d_moModels, d_active, stage);
+            LAUNCH_CHECK("k_motion_count");
+        }
     }
     {
         ProfScope ps(b, s, K_MOTION_S);
@@ -2234,6 +2239,7 @@ static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int hei
         HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<8, 1, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(8, 1, 1, 8)));
         HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<16, 1, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(16, 1, 2, 4)));
         HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<16, 1, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(16, 1, 1, 4)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<16, 2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(16, 2, 2, 4)));
         y->attrF32 = true;
     }
     // tile variant of the >= 128-filter layers: 1 (default) = two independent 4-wave workgroups per CU, 128 x 128 tiles (equal to the 8-wave
@@ -2268,6 +2274,8 @@ static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int hei
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 2, 4>), dim3((npix + 255) / 256, 1), dim3(256), SD_F32_LDS(16, 1, 2, 4), s, A);
             else if (l.filters <= 64)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 2, 8>), dim3((npix + 511) / 512, 1), dim3(512), SD_F32_LDS(16, 1, 2, 8), s, A);
+            else if (variant == 3)                   // three 4-wave workgroups per CU on half-depth K steps
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 2, 2, 4>), dim3((npix + 127) / 128, r.coutPad / 128), dim3(256), SD_F32_LDS(16, 2, 2, 4), s, A);
             else if (variant == 1 || (variant == 2 && l.size == 1))
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<32, 2, 2, 4>), dim3((npix + 127) / 128, r.coutPad / 128), dim3(256), SD_F32_LDS(32, 2, 2, 4), s, A);
             else
