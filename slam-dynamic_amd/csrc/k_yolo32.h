@@ -29,7 +29,7 @@ struct SdConvArgsF {
 // step earlier) are written to the other buffer and the global loads of stage s + 2 are issued -- one barrier per step, and
 // neither the address arithmetic of the gather nor the LDS writes sit between two barriers with the MFMA pipe idle.
 template <int BK, int WM, int MT, int NW>
-__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (BK == 16 && WM == 2 ? 3 : 2)) k_conv_f32(SdConvArgsF A)
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (WM == 2 && BK == 16 ? 3 : 2)) k_conv_f32(SdConvArgsF A)
 {
     constexpr int NT = 64 * NW;                         // NW = 8: one workgroup per CU; NW = 4: two independent workgroups per CU
     constexpr int WN = NW / WM, BM = 32 * MT * WM, BN = 64 * WN;

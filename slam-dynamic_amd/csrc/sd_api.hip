@@ -2242,10 +2242,12 @@ static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int hei
         HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<16, 2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(16, 2, 2, 4)));
         y->attrF32 = true;
     }
-    // tile variant of the >= 128-filter layers: 1 (default) = two independent 4-wave workgroups per CU, 128 x 128 tiles (equal to the 8-wave
-    // 128 x 256 tile at batch 128, 9 % faster at batch 32: finer tile-count quantisation, one workgroup's prologue under the other's
-    // main loop); 0 = 8-wave tiles; 2 = 4-wave for the 1x1 layers only.  SD_F32_VARIANT is a developer switch.
-    static const int variant = getenv("SD_F32_VARIANT") ? atoi(getenv("SD_F32_VARIANT")) : 1;
+    // tile variant of the >= 128-filter layers: 3 (default) = 128 x 128 tiles on 4-wave workgroups with 16-channel K steps, 40 KB of LDS and 144
+    // VGPRs: THREE independent workgroups per CU (3 waves per SIMD keep the MFMA pipe fed through each other's barriers and staging;
+    // +3.3 % over variant 1 on every such layer at batch 128; four per CU -- 8-channel steps, or 128 VGPRs without fragment prefetch --
+    // were 5 % slower); 1 = the same tile with 32-channel steps, two workgroups per CU; 0 = 8-wave 128 x 256 tiles; 2 = variant 1 for the
+    // 1x1 layers only.  SD_F32_VARIANT is a developer switch.
+    static const int variant = getenv("SD_F32_VARIANT") ? atoi(getenv("SD_F32_VARIANT")) : 3;
     static const int small4 = getenv("SD_F32_SMALL4") ? atoi(getenv("SD_F32_SMALL4")) : 1;       // 4-wave tiles for the <= 64-filter layers too (0.5 % at batch 128); developer switch
     const float* cur = y->d_blob8;
     int H = y->netH, W = y->netW, Cs = 8;
@@ -2274,7 +2276,7 @@ static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int hei
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 2, 4>), dim3((npix + 255) / 256, 1), dim3(256), SD_F32_LDS(16, 1, 2, 4), s, A);
             else if (l.filters <= 64)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 2, 8>), dim3((npix + 511) / 512, 1), dim3(512), SD_F32_LDS(16, 1, 2, 8), s, A);
-            else if (variant == 3)                   // three 4-wave workgroups per CU on half-depth K steps
+            else if (variant == 3)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 2, 2, 4>), dim3((npix + 127) / 128, r.coutPad / 128), dim3(256), SD_F32_LDS(16, 2, 2, 4), s, A);
             else if (variant == 1 || (variant == 2 && l.size == 1))
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<32, 2, 2, 4>), dim3((npix + 127) / 128, r.coutPad / 128), dim3(256), SD_F32_LDS(32, 2, 2, 4), s, A);
