@@ -2244,8 +2244,8 @@ static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int hei
     }
     // tile variant of the >= 128-filter layers: 3 (default) = 128 x 128 tiles on 4-wave workgroups with 16-channel K steps, 40 KB of LDS and 144
     // VGPRs: THREE independent workgroups per CU (3 waves per SIMD keep the MFMA pipe fed through each other's barriers and staging;
-    // +3.3 % over variant 1 on every such layer at batch 128; four per CU -- 8-channel steps, or 128 VGPRs without fragment prefetch --
-    // were 5 % slower); 1 = the same tile with 32-channel steps, two workgroups per CU; 0 = 8-wave 128 x 256 tiles; 2 = variant 1 for the
+    // +3.3 % over variant 1 on every such layer at batch 128; four per CU -- 8-channel steps, 128 VGPRs without fragment prefetch, or 64 x 128 tiles --
+    // were 5-7 % slower); 1 = the same tile with 32-channel steps, two workgroups per CU; 0 = 8-wave 128 x 256 tiles; 2 = variant 1 for the
     // 1x1 layers only.  SD_F32_VARIANT is a developer switch.
     static const int variant = getenv("SD_F32_VARIANT") ? atoi(getenv("SD_F32_VARIANT")) : 3;
     static const int small4 = getenv("SD_F32_SMALL4") ? atoi(getenv("SD_F32_SMALL4")) : 1;       // 4-wave tiles for the <= 64-filter layers too (0.5 % at batch 128); developer switch
