@@ -255,7 +255,8 @@ def cpu_baseline(workload, cfg, kind, sensor, with_boxes, with_detector, pkg, bu
         yo = graft.load_yolo_oracle()
         layers, anchors = pkg.yolo.v3_layers()
         _, per = pkg.yolo.synth_weights(layers, seed=3)
-        det_threads = torch.get_num_threads()
+        det_threads = max(1, min(torch.get_num_threads(), usable_cpus()))      # more threads than usable cores only slows torch's convolutions down
+        torch.set_num_threads(det_threads)
         blob = yo.blob_from_image(pool[0]["images"][0][:, :, ::-1], 640, 480, orc.resize_linear)
         yo.torch_forward(layers, per, blob)                     # warm-up
         t0 = time.perf_counter()
@@ -269,10 +270,30 @@ def cpu_baseline(workload, cfg, kind, sensor, with_boxes, with_detector, pkg, bu
                      "(oracle/pipeline.py over libsd_oracle, g++ -O3 %s), %d extraction thread(s) as the reference; front end median %.2f ms / mean %.2f ms"
                      % (warm, len(times), flags, 2 if sensor == P.SENSOR_STEREO else 1, fe_median * 1e3, fe_mean * 1e3) +
                      ("; detector = YOLOv3 torch-fp32 forward on %d host threads, %.0f ms / image over %d images, added per frame" % (det_threads, det_s * 1e3, det_n)
-                      if with_detector else "") + "; host has %d logical cores" % (os.cpu_count() or 0),
+                      if with_detector else "") + "; host has %d logical cores, %d usable by this process" % (os.cpu_count() or 0, usable_cpus()),
            "front_end_ms": {"median": round(fe_median * 1e3, 3), "mean": round(fe_mean * 1e3, 3), "frames": len(times)},
            "detector_ms": round(det_s * 1e3, 2) if with_detector else None}
     return out
+
+
+def usable_cpus():
+    """Host cores this process may actually run on: the affinity mask, cut by a cgroup CPU quota when there is one (the GPU box gives a
+    one-GPU job a share of the host, and threads beyond it only fight each other)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.999)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, int(q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()) + 0.999)))
+            break
+        except Exception:
+            continue
+    return max(1, n)
 
 
 def cpu_all_cores(cfg, kind, sensor, with_boxes, pkg, threads, frames_per_thread=6):
@@ -684,7 +705,7 @@ def main():
         if world == 1 and args.cpu_budget > 0:
             P_SENSOR = {"stereo": 1, "rgbd": 2}[wl.kind]
             cpu = cpu_baseline(args.workload, wl.cfg, wl.kind, P_SENSOR, wl.with_boxes or wl.detector, wl.detector, pkg, budget_s=args.cpu_budget)
-            nthr = max(1, min(os.cpu_count() or 1, 64))
+            nthr = max(1, min(usable_cpus(), 64))
             cpu["all_cores"] = cpu_all_cores(wl.cfg, wl.kind, P_SENSOR, wl.with_boxes or wl.detector, pkg, nthr)
         text = WORKLOAD_TEXT[args.workload] % args.kitti_frames if args.workload == "kitti-batch" else WORKLOAD_TEXT[args.workload]
         cull = wl.with_boxes
