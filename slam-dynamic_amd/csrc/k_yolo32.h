@@ -20,6 +20,7 @@ struct SdConvArgsF {
     int N, H, W, cin, cinStride;
     int Ho, Wo, cout, outStride, resStride;
     int ksize, stride, pad, leaky;
+    int tilesX, tilesY, groupY;      // pixel tiles, filter tiles (groupY divides tilesY): the launch is 1-D, SD_F32_GRID(tilesX, tilesY) workgroups
 };
 
 // Tile shapes: WM waves along the filters x (8 / WM) waves along the pixels, a wave owns MT x 2 MFMA tiles (32 MT filters x 64
@@ -42,7 +43,19 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (WM == 2 && BK == 16 ? 
     extern __shared__ __align__(16) float smemf[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r32 = lane & 31, h = lane >> 5;
     const int wm = wv % WM, wn = wv / WM;               // wave tile: filters [32 MT wm, +32 MT), pixels [64 wn, +64)
-    const int pix0 = blockIdx.x * BN, co0 = blockIdx.y * BM;
+    // XCD-aware order (workgroup L runs on XCD L % 8, each XCD has its own 4 MB L2): XCD x owns a CONTIGUOUS range of pixel tiles (the
+    // rows that neighbouring pixel tiles share for the 3 x 3 taps meet in one L2) and walks it once per GROUP of groupY filter tiles,
+    // the filter tiles of a group back to back on each pixel tile.  groupY is chosen on the host so that a group's weights stay
+    // L2-resident (<= 2.5 MB): the activations are then fetched from HBM tilesY / groupY times instead of tilesY times, without
+    // trading them for weight misses (all 8 filter tiles of a 512 -> 1024 3 x 3 layer are 19 MB of weights).  Measured per 128-image batch
+    // (FETCH_SIZE, doubled): 246 GB read in plain (pixel tile, filter tile) grid order, 139 GB with this order at the same 124.1 ms;
+    // all filter tiles back to back regardless of their weights: 103 GB but 126.4 ms.
+    const int perXcd = (A.tilesX + 7) >> 3;
+    const int slot = blockIdx.x >> 3, perGroup = perXcd * A.groupY;
+    const int grp = slot / perGroup, r = slot - grp * perGroup;
+    const int tx = (blockIdx.x & 7) * perXcd + r / A.groupY, ty = grp * A.groupY + r % A.groupY;
+    if (tx >= A.tilesX) return;
+    const int pix0 = tx * BN, co0 = ty * BM;
     const int npix = A.N * A.Ho * A.Wo;
     int pyi[XC], pxi[XC];
     size_t pbase[XC];
@@ -192,6 +205,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (WM == 2 && BK == 16 ? 
             }
     }
 }
+#define SD_F32_GRID(tx, ty) (unsigned)((((tx) + 7) / 8) * 8 * (ty))
 #define SD_F32_LDS(BK, WM, MT, NW) (2 * (32 * (MT) * (WM) + 64 * ((NW) / (WM))) * ((BK) + 4) * 4)
 
 // blobFromImage as k_blob_from_image, NHWC f32 with 8 channels (R, G, B after swapRB, then zeros)

@@ -2222,6 +2222,15 @@ int sd_yolo_flops(const sd_yolo* y, double* flops_per_image)
 }
 
 // The forward pass in f32 (k_yolo32.h): same graph walk, one generic convolution kernel, f32 activations.
+// filter tiles walked back to back on a pixel tile (k_conv_f32's workgroup order): the largest power of two that divides tilesY and
+// keeps the group's weights (bm filters x kdim floats per tile) within 2.5 MB of an XCD's 4 MB L2
+static int f32_group_y(int tilesY, int bm, int kdim)
+{
+    int g = 1;
+    while (2 * g <= tilesY && tilesY % (2 * g) == 0 && (size_t)(2 * g) * bm * kdim * 4 <= (size_t)2560 * 1024) g *= 2;
+    return g;
+}
+
 static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int height, size_t stride, size_t image_pitch, int n,
                             float conf_threshold, hipStream_t s)
 {
@@ -2267,21 +2276,21 @@ static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int hei
             }
             const int npix = n * r.H * r.W;
             if (i == 0)                         // 3 (-> 8) input channels, <= 32 filters
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<8, 1, 1, 8>), dim3((npix + 511) / 512, (l.filters + 31) / 32), dim3(512), SD_F32_LDS(8, 1, 1, 8), s, A);
+                { A.tilesX = (npix + 511) / 512; A.tilesY = (l.filters + 31) / 32; A.groupY = f32_group_y(A.tilesY, 32, A.cin * l.size * l.size); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<8, 1, 1, 8>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(512), SD_F32_LDS(8, 1, 1, 8), s, A); }
             else if (l.filters <= 32 && small4)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 1, 4>), dim3((npix + 255) / 256, 1), dim3(256), SD_F32_LDS(16, 1, 1, 4), s, A);
+                { A.tilesX = (npix + 255) / 256; A.tilesY = 1; A.groupY = f32_group_y(A.tilesY, 32, A.cin * l.size * l.size); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 1, 4>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(256), SD_F32_LDS(16, 1, 1, 4), s, A); }
             else if (l.filters <= 32)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 1, 8>), dim3((npix + 511) / 512, 1), dim3(512), SD_F32_LDS(16, 1, 1, 8), s, A);
+                { A.tilesX = (npix + 511) / 512; A.tilesY = 1; A.groupY = f32_group_y(A.tilesY, 32, A.cin * l.size * l.size); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 1, 8>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(512), SD_F32_LDS(16, 1, 1, 8), s, A); }
             else if (l.filters <= 64 && small4)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 2, 4>), dim3((npix + 255) / 256, 1), dim3(256), SD_F32_LDS(16, 1, 2, 4), s, A);
+                { A.tilesX = (npix + 255) / 256; A.tilesY = 1; A.groupY = f32_group_y(A.tilesY, 64, A.cin * l.size * l.size); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 2, 4>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(256), SD_F32_LDS(16, 1, 2, 4), s, A); }
             else if (l.filters <= 64)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 2, 8>), dim3((npix + 511) / 512, 1), dim3(512), SD_F32_LDS(16, 1, 2, 8), s, A);
+                { A.tilesX = (npix + 511) / 512; A.tilesY = 1; A.groupY = f32_group_y(A.tilesY, 64, A.cin * l.size * l.size); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 2, 8>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(512), SD_F32_LDS(16, 1, 2, 8), s, A); }
             else if (variant == 3)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 2, 2, 4>), dim3((npix + 127) / 128, r.coutPad / 128), dim3(256), SD_F32_LDS(16, 2, 2, 4), s, A);
+                { A.tilesX = (npix + 127) / 128; A.tilesY = r.coutPad / 128; A.groupY = f32_group_y(A.tilesY, 128, A.cin * l.size * l.size); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 2, 2, 4>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(256), SD_F32_LDS(16, 2, 2, 4), s, A); }
             else if (variant == 1 || (variant == 2 && l.size == 1))
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<32, 2, 2, 4>), dim3((npix + 127) / 128, r.coutPad / 128), dim3(256), SD_F32_LDS(32, 2, 2, 4), s, A);
+                { A.tilesX = (npix + 127) / 128; A.tilesY = r.coutPad / 128; A.groupY = f32_group_y(A.tilesY, 128, A.cin * l.size * l.size); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<32, 2, 2, 4>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(256), SD_F32_LDS(32, 2, 2, 4), s, A); }
             else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<32, 2, 2, 8>), dim3((npix + 255) / 256, r.coutPad / 128), dim3(512), SD_F32_LDS(32, 2, 2, 8), s, A);
+                { A.tilesX = (npix + 255) / 256; A.tilesY = r.coutPad / 128; A.groupY = f32_group_y(A.tilesY, 128, A.cin * l.size * l.size); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<32, 2, 2, 8>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(512), SD_F32_LDS(32, 2, 2, 8), s, A); }
             LAUNCH_CHECK("k_conv_f32");
         } else if (l.type == SD_YOLO_SHORTCUT) {
             if (!r.alias) return set_err(SD_ERR_UNSUPPORTED, "unfused [shortcut] is not implemented");
