@@ -383,17 +383,30 @@ class Workload:
         self.main = torch.cuda.current_stream()
         self.det = None
         if self.detector:
+            # --det-split n: the frame's images go through the detector as n independent sub-batches on their own streams (one
+            # sub-batch's convolutions could fill the chip while the other's drain or run their small kernels).  Same work, same
+            # results, only the launch schedule differs -- and on MI355X no gain was measured, so the default stays 1.
             layers, anchors = pkg.yolo.v3_layers()
-            self.det = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=self.S, precision=self.det_prec)
-            self.det.load_weights(pkg.yolo.synth_weights(layers, seed=3)[0])
-            self.det_stream = torch.cuda.Stream(device=dev)
+            self.n_det = max(1, min(int(args.det_split), self.S))
+            while self.S % self.n_det:
+                self.n_det -= 1
+            self.S_det = self.S // self.n_det
+            payload = pkg.yolo.synth_weights(layers, seed=3)[0]
+            self.dets = []
+            for _ in range(self.n_det):
+                d_ = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=self.S_det, precision=self.det_prec)
+                d_.load_weights(payload)
+                self.dets.append(d_)
+            self.det = self.dets[0]
+            self.det_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_det)]
+            self.det_stream = self.det_streams[0]
             self.det_in_flight = -1
             self.lookahead = True             # the next frame's forward pass is launched before this frame's front end
             S_ = self.S                       # two result slots: forward + NMS + download of frame t + 1 are queued before frame t's boxes are consumed
             self.det_dev = [dict(b=torch.zeros((S_, 32, 4), dtype=torch.float64, device=dev), c=torch.zeros((S_, 32), dtype=torch.int32, device=dev),
                                  f=torch.zeros((S_, 32), dtype=torch.float32, device=dev), n=torch.zeros((S_,), dtype=torch.int32, device=dev)) for _ in range(2)]
             self.det_host = [dict(b=torch.zeros((S_, 32, 4), dtype=torch.float64).pin_memory(), n=torch.zeros((S_,), dtype=torch.int32).pin_memory()) for _ in range(2)]
-            self.det_ev = [torch.cuda.Event(), torch.cuda.Event()]
+            self.det_ev = [[torch.cuda.Event() for _ in range(self.n_det)] for _ in range(2)]
         self.cloud = name == "tum-mask"          # PointCloudMapping::generatePointCloud on every frame: the consumer of the semantic mask
         if self.cloud:
             self.cap_pts = ((self.W + 2) // 3) * ((self.H + 2) // 3)
@@ -437,7 +450,8 @@ class Workload:
             if self.det_in_flight != self.t:      # first step: nothing was launched ahead
                 self.enqueue_detector(self.t)
             k = self.t & 1
-            self.det_ev[k].synchronize()          # yolo->Segmentation_(imLeft) of THIS frame is on the host (stereo_kitti.cc:107)
+            for e in self.det_ev[k]:
+                e.synchronize()                   # yolo->Segmentation_(imLeft) of THIS frame is on the host (stereo_kitti.cc:107)
             nb_all = self.det_host[k]["n"].numpy()
             if (nb_all < 0).any():
                 raise RuntimeError("detector post-processing on the device exceeded its capacity")
@@ -459,22 +473,27 @@ class Workload:
         """forward + postprocess_ (device NMS) + download of frame t's boxes on the detector stream, nothing waits."""
         torch = self.torch
         W, H, S = self.W, self.H, self.S
-        ds = self.det_stream.cuda_stream
         k = t & 1
         fr = self.frames[t]
-        self.det.forward_device(fr["images"].data_ptr(), W, H, W * 3, self.ipl * W * H * 3, S, 0.5, ds)
         d = self.det_dev[k]
-        self.det.boxes_device(S, W, H, d["b"].data_ptr(), d["c"].data_ptr(), d["f"].data_ptr(), d["n"].data_ptr(), stream=ds)
-        with torch.cuda.stream(self.det_stream):
-            self.det_host[k]["b"].copy_(d["b"], non_blocking=True)
-            self.det_host[k]["n"].copy_(d["n"], non_blocking=True)
-            self.det_ev[k].record(self.det_stream)
+        Sn = self.S_det
+        for p in range(self.n_det):
+            st = self.det_streams[p]
+            ds = st.cuda_stream
+            lo, hi = p * Sn, (p + 1) * Sn
+            self.dets[p].forward_device(fr["images"].data_ptr() + lo * self.ipl * W * H * 3, W, H, W * 3, self.ipl * W * H * 3, Sn, 0.5, ds)
+            self.dets[p].boxes_device(Sn, W, H, d["b"][lo:hi].data_ptr(), d["c"][lo:hi].data_ptr(), d["f"][lo:hi].data_ptr(), d["n"][lo:hi].data_ptr(), stream=ds)
+            with torch.cuda.stream(st):
+                self.det_host[k]["b"][lo:hi].copy_(d["b"][lo:hi], non_blocking=True)
+                self.det_host[k]["n"][lo:hi].copy_(d["n"][lo:hi], non_blocking=True)
+                self.det_ev[k][p].record(st)
         self.det_in_flight = t
 
     def close(self):
         self.trk.close()
         if self.det is not None:
-            self.det.close()
+            for d_ in self.dets:
+                d_.close()
 
 
 def run_workload(name, args, rank, world, dev, pkg, dist, headline):
@@ -554,17 +573,27 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline):
         det_ms = None
         if wl.det is not None:                 # the detector alone, nothing else on the GPU: the MFMA block
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            with torch.cuda.stream(wl.det_stream):
-                fr = wl.frames[wl.t]
-                wl.det.forward_device(fr["images"].data_ptr(), wl.W, wl.H, wl.W * 3, wl.ipl * wl.W * wl.H * 3, wl.S, 0.5, wl.det_stream.cuda_stream)
-                wl.det_stream.synchronize()
-                e0.record(wl.det_stream)
-                for _ in range(3):
-                    wl.det.forward_device(fr["images"].data_ptr(), wl.W, wl.H, wl.W * 3, wl.ipl * wl.W * wl.H * 3, wl.S, 0.5, wl.det_stream.cuda_stream)
-                e1.record(wl.det_stream)
-                wl.det_stream.synchronize()
-            det_ms = e0.elapsed_time(e1) / 3
+            fr = wl.frames[wl.t]
+            Sn = wl.S_det
+
+            def det_pass(p):
+                wl.dets[p].forward_device(fr["images"].data_ptr() + p * Sn * wl.ipl * wl.W * wl.H * 3, wl.W, wl.H, wl.W * 3, wl.ipl * wl.W * wl.H * 3, Sn, 0.5,
+                                          wl.det_streams[p].cuda_stream)
+            for p in range(wl.n_det):
+                det_pass(p)
+            torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = [torch.cuda.Event(enable_timing=True) for _ in range(wl.n_det)]
+            e0.record(wl.det_streams[0])
+            for p in range(1, wl.n_det):
+                wl.det_streams[p].wait_event(e0)                       # every sub-batch starts behind the same mark
+            for _ in range(3):
+                for p in range(wl.n_det):
+                    det_pass(p)
+            for p in range(wl.n_det):
+                e1[p].record(wl.det_streams[p])
+            torch.cuda.synchronize()
+            det_ms = max(e0.elapsed_time(e) for e in e1) / 3
             wl.det_in_flight = -1               # the profiled steps below run exactly like the timed ones (next frame's detector pass beside the front end)
         for _ in range(prof_steps):
             wl.step()
@@ -617,16 +646,16 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline):
                 try:
                     e = json.load(open(pmc)).get("k_conv_f32" if prec == "f32" else "")
                     if e and e.get("batch_images") == n_img:
-                        det_traffic = int(e["hbm_bytes_per_launch"]) * n_conv
+                        det_traffic = int(e["hbm_bytes_per_launch"]) * n_conv * wl.n_det       # the profile's launches are sub-batch launches
                 except Exception:
                     det_traffic = None
-                top = {"bound": "mfma", "kernel": "k_conv_f32 x %d launches = the convolutions of one %d-image detector batch" % (n_conv, wl.S) if prec == "f32"
+                top = {"bound": "mfma", "kernel": "k_conv_f32 x %d launches = the convolutions of one %d-image detector batch" % (n_conv * wl.n_det, wl.S) if prec == "f32"
                                                   else "the f16 convolution kernels of one %d-image detector batch" % wl.S,
                        "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS[prec], "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS[prec], 4),
                        "traffic": det_traffic, "algorithmic_flops_per_launch": int(fl * wl.S), "avg_launch_ms": round(det_ms, 3),
                        "algorithmic_bytes_per_launch": detector_algorithmic_bytes(wl.det.layers, wl.det.net_w, wl.det.net_h, wl.S, 4 if prec == "f32" else 2),
                        "operands": prec, "images_per_s": round(wl.S / (det_ms * 1e-3), 1), "gflop_per_image": round(fl / 1e9, 2), "batch": wl.S,
-                       "measured": "3 detector passes alone on the detector's stream between two events on that stream (untimed pass)",
+                       "measured": "3 detector passes alone (%d sub-batch(es) of %d images on their own streams, as in the timed steps) between events on those streams (untimed pass)" % (wl.n_det, wl.S_det),
                        "weights": "synthetic (yolov3.weights is a download that never was in the reference)",
                        "front_end": roof}
                 roof = top
@@ -661,6 +690,8 @@ def main():
     ap.add_argument("--extra", default="auto", help="comma-separated workloads also run (short) and reported under 'extra'; 'auto' = stereo,rgbd,rgbd-cull at N=1, none otherwise; 'none'")
     ap.add_argument("--extra-steps", type=int, default=12)
     ap.add_argument("--kitti-frames", type=int, default=256)
+    ap.add_argument("--det-split", type=int, default=1, help="sub-batches the detector processes a step's images in, each on its own stream "
+                    "(measured on MI355X: 1 -> 995.5, 2 -> 995.1, 4 -> 989.7 frames/s: the convolutions' drain phases are not worth filling)")
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of host time for the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the separate per-kernel pass (no roofline block)")
     args = ap.parse_args()
@@ -729,17 +760,21 @@ def main():
     extras = {}
     names = []
     if args.extra == "auto":
-        names = [w for w in ("stereo-yolo-f16", "stereo", "rgbd", "rgbd-cull", "tum-mask") if w != args.workload] if world == 1 else []
+        names = [w for w in ("stereo-yolo-f16", "stereo", "rgbd", "rgbd-cull", "tum-mask", "kitti-batch") if w != args.workload] if world == 1 else []
     elif args.extra != "none":
         names = [w for w in args.extra.split(",") if w]
     for w in names:
         if w not in WORKLOADS:
             raise SystemExit("unknown workload " + w)
+        kf = args.kitti_frames
+        if w == "kitti-batch" and args.extra == "auto":
+            args.kitti_frames = min(kf, 64)          # a bounded sample of configs[4] (the host generates every frame of every sequence): the text says how many
         o, _ = run_workload(w, args, rank, world, dev, pkg, dist, headline=False)
         if rank == 0:
             extras[w] = {"value": o["value"], "unit": "frames/s", "ms_per_step": o["ms_per_step"], "steps": o["steps"], "lanes_per_gpu": o["lanes_per_gpu"],
                          "scaling": "strong" if w == "kitti-batch" else "weak",
                          "workload": WORKLOAD_TEXT[w] % args.kitti_frames if w == "kitti-batch" else WORKLOAD_TEXT[w], "lane0_last_frame": o["lane0_last_frame"]}
+        args.kitti_frames = kf
 
     if rank == 0:
         cpu = None
