@@ -84,7 +84,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (WM == 2 && BK == 16 ? 
     // arithmetic and the bounds test of the im2col gather run once per TAP (every cin / BK steps), and a padded tap reads a zero
     // page through the same unconditional load.  (The per-step form of this arithmetic, ~150 VALU instructions with 64-bit
     // multiplies and branches, cost the MFMA pipe a quarter of its time: tools/micro/conv_loop_cost.hip.)
-    sd_f4 xr[XC], wr[WC];
+    // DEEP: two register sets, a stage's tiles are requested TWO steps before they go to LDS.  The 64-filter tile <.., 1, 2, ..> stages
+    // four activation chunks per thread; a second set would cost it its third wave per SIMD (186 VGPRs) and more than it gains.
+    constexpr bool DEEP = !(WM == 1 && MT == 2);
+    constexpr int NSET = DEEP ? 2 : 1;
+    sd_f4 xr[NSET][XC], wr[NSET][WC];
     const float* wptr[WC];
     const float* xptr[XC];
     int winc[WC], xinc[XC];
@@ -108,21 +112,21 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (WM == 2 && BK == 16 ? 
         }
     };
     retap();
-    auto fetch = [&]() {
+    auto fetch = [&](const int set) {
 #pragma unroll
-        for (int i = 0; i < WC; i++) { wr[i] = *(const sd_f4*)wptr[i]; wptr[i] += winc[i]; }
+        for (int i = 0; i < WC; i++) { wr[set][i] = *(const sd_f4*)wptr[i]; wptr[i] += winc[i]; }
 #pragma unroll
-        for (int i = 0; i < XC; i++) { xr[i] = *(const sd_f4*)xptr[i]; xptr[i] += xinc[i]; }
+        for (int i = 0; i < XC; i++) { xr[set][i] = *(const sd_f4*)xptr[i]; xptr[i] += xinc[i]; }
         c0 += BK;
         if (c0 == A.cin) { c0 = 0; kw++; if (kw == A.ksize) { kw = 0; kh++; } retap(); }
     };
-    auto store = [&](int buf) {
+    auto store = [&](int buf, const int set) {
         float* sW = smemf + buf * STAGE;
         float* sX = sW + BM * LD;
 #pragma unroll
-        for (int i = 0; i < WC; i++) { const int chunk = tid + NT * i; if ((WC * NT == BM * CPR) || chunk < BM * CPR) *(sd_f4*)(sW + (chunk / CPR) * LD + 4 * (chunk % CPR)) = wr[i]; }
+        for (int i = 0; i < WC; i++) { const int chunk = tid + NT * i; if ((WC * NT == BM * CPR) || chunk < BM * CPR) *(sd_f4*)(sW + (chunk / CPR) * LD + 4 * (chunk % CPR)) = wr[set][i]; }
 #pragma unroll
-        for (int i = 0; i < XC; i++) { const int chunk = tid + NT * i; if ((XC * NT == BN * CPR) || chunk < BN * CPR) *(sd_f4*)(sX + (chunk / CPR) * LD + 4 * (chunk % CPR)) = xr[i]; }
+        for (int i = 0; i < XC; i++) { const int chunk = tid + NT * i; if ((XC * NT == BN * CPR) || chunk < BN * CPR) *(sd_f4*)(sX + (chunk / CPR) * LD + 4 * (chunk % CPR)) = xr[set][i]; }
     };
     const int aoff = (32 * MT * wm + r32) * LD + 4 * h, boff = BM * LD + (64 * wn + r32) * LD + 4 * h;
     sd_f4 fa[2][MT], fb[2][2];                          // fragments of two consecutive K chunks: the reads of chunk c + 1 are issued before the MFMAs of chunk c
@@ -145,28 +149,45 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (WM == 2 && BK == 16 ? 
     // The two waves that share a SIMD (w and w + 4) do their staging at DIFFERENT K chunks of a step: the ~150 address / LDS-write
     // instructions of one wave then run under the other wave's MFMAs instead of both leaving the MFMA pipe idle together.
     const int myslot = NW == 8 ? (NCH >= 4 ? 2 * (wv >> 2) : (NCH == 2 ? (wv >> 2) : 0)) : 0;
-    fetch();
-    store(0);
-    if (ksteps > 1) fetch();
+    // DEEP: stage s lives in register set s & 1 from its request (two steps ahead: ~12 000 cycles with three waves per SIMD, against an
+    // L2 / HBM latency of several thousand under load -- with ONE step of distance the ds_writes waited on their loads for 11 % of
+    // the kernel time) until it is written to LDS buffer s & 1 during step s - 1.
+    fetch(0);
+    store(0, 0);
+    if (ksteps > 1) fetch(NSET - 1);
+    if (DEEP && ksteps > 2) fetch(0);
     __syncthreads();
-    for (int ks = 0; ks < ksteps; ks++) {
-        const int cur = ks & 1;
+    auto step = [&](const int ks, const int par) {     // par = ks & 1, a literal at both call sites
+        const int cur = par;
+#ifndef SD_F32_EXPERIMENT_NOFRAGS
         frags(cur, 0, 0);
+#else
+        if (ks == 0) { frags(cur, 0, 0); frags(cur, 1, 1); }
+#endif
 #pragma unroll
         for (int kc = 0; kc < NCH; kc++) {
+#ifndef SD_F32_EXPERIMENT_NOFRAGS
             if (kc + 1 < NCH) frags(cur, kc + 1, (kc + 1) & 1);
+#endif
             mfmas(kc & 1);
-            if (kc == myslot) {                         // next stage into the other buffer, stage s + 2 requested
-                if (ks + 1 < ksteps) store(cur ^ 1);
-                if (ks + 2 < ksteps) fetch();
+#ifndef SD_F32_EXPERIMENT_NOSTAGE
+            if (kc == myslot) {                         // stage ks + 1 into the other buffer, stage ks + 3 requested into the set that frees
+                if (ks + 1 < ksteps) store(cur ^ 1, DEEP ? par ^ 1 : 0);
+                if (ks + 1 + NSET < ksteps) fetch(DEEP ? par ^ 1 : 0);
             }
+#endif
         }
         // The barrier stays BEHIND the step's last MFMA: hoisted above them (legal, they touch no memory) the two waves of a SIMD
         // would reach it a staging block apart and the earlier one would sit there with its remaining MFMAs unissued.
         __builtin_amdgcn_sched_barrier(0);
+#ifndef SD_F32_EXPERIMENT_NOBARRIER
         __syncthreads();
+#endif
         __builtin_amdgcn_sched_barrier(0);
-    }
+    };
+    int ks = 0;
+    for (; ks + 1 < ksteps; ks += 2) { step(ks, 0); step(ks + 1, 1); }
+    if (ks < ksteps) step(ks, 0);
     // ---- epilogue: D column = pixel (lane & 31), rows = filters (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  All shortcut reads are
     // requested before the first one is used (one memory round trip, not one per 16-byte piece).
     sd_f4 rr[2][MT][4];

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsd_frontend.so")
+LIB_PATH = os.environ.get("SD_FRONTEND_LIB") or os.path.join(_HERE, "lib", "libsd_frontend.so")     # the override is for kernel experiments only
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])
