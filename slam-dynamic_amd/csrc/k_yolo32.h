@@ -158,7 +158,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (WM == 2 && BK == 16 ? 
     if (DEEP && ksteps > 2) fetch(0);
     __syncthreads();
     // Measured around this loop at batch 128 (ms per detector batch; the ablation switches below give wrong results and exist for timing):
-    // as is 121.0; without the barrier 119.9; without any staging (no loads, no LDS writes, no address updates) 109.3; staging without the
+    // as is 121.0-122.5; without the barrier -1 % (122.9 against 124.1, measured before the two-step prefetch); without any staging (no
+    // loads, no LDS writes, no address updates) 109.3; staging without the
     // global loads 120.1 -- i.e. what the staging costs is not the memory latency.  Requests issued unconditionally (so that the
     // compiler can wait with vmcnt(7..4) instead of vmcnt(3..0)) 122.2; a staging map whose ds_write_b128 passes hit 16 distinct bank
     // quads (SQ_LDS_BANK_CONFLICT 0 instead of 33 % of the LDS-active cycles, but the LDS is busy only 10-16 % of the time) 123.7.
