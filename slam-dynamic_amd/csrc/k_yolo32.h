@@ -197,42 +197,95 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (WM == 2 && BK == 16 ? 
     int ks = 0;
     for (; ks + 1 < ksteps; ks += 2) { step(ks, 0); step(ks + 1, 1); }
     if (ks < ksteps) step(ks, 0);
-    // ---- epilogue: D column = pixel (lane & 31), rows = filters (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  All shortcut reads are
-    // requested before the first one is used (one memory round trip, not one per 16-byte piece).
-    sd_f4 rr[2][MT][4];
+    if constexpr (WM == 1) {
+        // ---- epilogue.  D column = pixel (lane & 31), rows = filters (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): written straight from the
+        // accumulators a store instruction would cover 32 pixels x 32 bytes.  The wave's 32-pixel half tiles go through its own piece of
+        // the (now free) LDS instead -- [pixel][32 MT filters] -- and come back with consecutive lanes on consecutive 16-byte pieces of a
+        // pixel's filter row: stores and shortcut reads of 128 / 256 contiguous bytes per pixel.  (The first layers write 5 GB per
+        // 128-image batch against a few dozen K steps: their time was the scattered stores.)  Only the <= 64-filter tiles (WM == 1) do
+        // this: on the 128-filter tiles, whose epilogue is 3 % of a long K loop and overlaps the other workgroups' MFMAs, the LDS round
+        // trip made every 3 x 3 body layer 1-6 % slower (measured), so they keep the direct stores below.
+        constexpr int TWD = 32 * MT, TLD = TWD + 4;           // floats per pixel row of the transpose tile (+4: rows 16 bytes apart mod 256)
+        constexpr int PPI = 64 / (TWD / 4);                   // pixels per store instruction: a pixel row is TWD / 4 pieces
+        static_assert(NW * 32 * TLD <= 2 * STAGE, "the transpose tiles of the epilogue must fit the staging buffers");
+        float* T = smemf + wv * 32 * TLD;                     // wave-private: no workgroup barrier inside the epilogue
+        const int piece = lane % (TWD / 4), prow = lane / (TWD / 4);
+        const int cob = co0 + TWD * wm + 4 * piece;           // first of this lane's four output channels
+        sd_f4 bias4 = sd_f4{0.f, 0.f, 0.f, 0.f};
+        if (cob < A.cout) bias4 = *(const sd_f4*)(A.bias + cob);                       // bias rows are padded to the filter tile
+        __syncthreads();                                      // every wave's last fragment reads are done: the staging buffers are free
 #pragma unroll
-    for (int n = 0; n < 2; n++) {
-        const int p = pix0 + 64 * wn + 32 * n + r32;
+        for (int n = 0; n < 2; n++) {
 #pragma unroll
-        for (int m = 0; m < MT; m++)
+            for (int m = 0; m < MT; m++)
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int co = co0 + 32 * MT * wm + 32 * m + 8 * g + 4 * h;
-                rr[n][m][g] = sd_f4{0.f, 0.f, 0.f, 0.f};
-                if (A.res && p < npix && co < A.cout) rr[n][m][g] = *(const sd_f4*)(A.res + (size_t)p * A.resStride + co);
+                for (int g = 0; g < 4; g++)
+                    *(sd_f4*)(T + r32 * TLD + 32 * m + 8 * g + 4 * h) = sd_f4{acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int pb = pix0 + 64 * wn + 32 * n;
+            sd_f4 rr[32 / PPI];
+#pragma unroll
+            for (int it = 0; it < 32 / PPI; it++) {            // all shortcut reads requested before the first one is used
+                const int p = pb + PPI * it + prow;
+                rr[it] = sd_f4{0.f, 0.f, 0.f, 0.f};
+                if (A.res && p < npix && cob < A.cout) rr[it] = *(const sd_f4*)(A.res + (size_t)p * A.resStride + cob);
             }
-    }
 #pragma unroll
-    for (int n = 0; n < 2; n++) {
-        const int p = pix0 + 64 * wn + 32 * n + r32;
-        if (p >= npix) continue;
-#pragma unroll
-        for (int m = 0; m < MT; m++)
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int co = co0 + 32 * MT * wm + 32 * m + 8 * g + 4 * h;
-                if (co >= A.cout) continue;
+            for (int it = 0; it < 32 / PPI; it++) {
+                const int pl = PPI * it + prow, p = pb + pl;
+                if (p >= npix || cob >= A.cout) continue;
+                const sd_f4 a = *(const sd_f4*)(T + pl * TLD + 4 * piece);
                 sd_f4 v;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    float x = acc[m][n][4 * g + e] + A.bias[co + e];            // bias rows are padded to the filter tile
+                    float x = a[e] + bias4[e];
                     if (A.leaky) x = x > 0.f ? x : 0.1f * x;
-                    v[e] = x + rr[n][m][g][e];
+                    v[e] = x + rr[it][e];
                 }
-                float* dst = A.out + (size_t)p * A.outStride + co;
-                if (co + 3 < A.cout) *(sd_f4*)dst = v;
-                else for (int e = 0; e < 4 && co + e < A.cout; e++) dst[e] = v[e];
+                float* dst = A.out + (size_t)p * A.outStride + cob;
+                if (cob + 3 < A.cout) *(sd_f4*)dst = v;
+                else for (int e = 0; e < 4 && cob + e < A.cout; e++) dst[e] = v[e];
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    } else {
+        // ---- epilogue: D column = pixel (lane & 31), rows = filters (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  All shortcut reads are
+        // requested before the first one is used (one memory round trip, not one per 16-byte piece).
+        sd_f4 rr[2][MT][4];
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            const int p = pix0 + 64 * wn + 32 * n + r32;
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int co = co0 + 32 * MT * wm + 32 * m + 8 * g + 4 * h;
+                    rr[n][m][g] = sd_f4{0.f, 0.f, 0.f, 0.f};
+                    if (A.res && p < npix && co < A.cout) rr[n][m][g] = *(const sd_f4*)(A.res + (size_t)p * A.resStride + co);
+                }
+        }
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            const int p = pix0 + 64 * wn + 32 * n + r32;
+            if (p >= npix) continue;
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int co = co0 + 32 * MT * wm + 32 * m + 8 * g + 4 * h;
+                    if (co >= A.cout) continue;
+                    sd_f4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        float x = acc[m][n][4 * g + e] + A.bias[co + e];            // bias rows are padded to the filter tile
+                        if (A.leaky) x = x > 0.f ? x : 0.1f * x;
+                        v[e] = x + rr[n][m][g][e];
+                    }
+                    float* dst = A.out + (size_t)p * A.outStride + co;
+                    if (co + 3 < A.cout) *(sd_f4*)dst = v;
+                    else for (int e = 0; e < 4 && co + e < A.cout; e++) dst[e] = v[e];
+                }
+        }
     }
 }
 #define SD_F32_GRID(tx, ty) (unsigned)((((tx) + 7) / 8) * 8 * (ty))
