@@ -3,7 +3,8 @@
 // exists so that the box sets can be compared with an f32 forward pass instead of being explained away by a tolerance, and
 // so that the f16 mode's disagreements can be counted against it (tests/test_gpu_yolo.py).  Activations NHWC f32, weights
 // [coutPad][taps][cin] f32 with batch-norm folded in f32.
-//   k_blob_from_image_f32   blobFromImage -> NHWC f32 x 8 channels (3 + 5 zeros: one K-chunk of the MFMA loop)
+//   k_blob_from_image_f32   blobFromImage -> NHWC f32 x 4 channels (R, G, B, 0: one 16-byte piece per pixel; the first layer pairs two
+//                           filter taps into one 8-wide K chunk, see `pair` below)
 //   k_conv_f32<BK>          implicit-GEMM convolution, 1x1 / 3x3, stride 1 / 2, + bias + leaky ReLU + shortcut
 // One f32 MFMA is 64 cycles for 4096 FLOPs and needs ONE float per operand per lane, so the kernel is MFMA-bound with a
 // plain structure: 8 waves, K walked in steps of BK channels of one filter tap, tiles staged through registers into LDS.  A lane reads
@@ -20,6 +21,8 @@ struct SdConvArgsF {
     int N, H, W, cin, cinStride;
     int Ho, Wo, cout, outStride, resStride;
     int ksize, stride, pad, leaky;
+    int pair;                // first layer (BK == 8 only): the input has 4 channels per pixel and K step s holds taps 2 s and 2 s + 1 (tap 9 = zeros):
+                             // 5 steps of 8 instead of 9 steps of 8 with five zero channels each; weights [coutPad][5][2][4]
     int tilesX, tilesY, groupY;      // pixel tiles, filter tiles (groupY divides tilesY): the launch is 1-D, SD_F32_GRID(tilesX, tilesY) workgroups
 };
 
@@ -72,7 +75,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (WM == 2 && BK == 16 ? 
         pbase[i] = (size_t)n * A.H * A.W;
     }
     const int taps = A.ksize * A.ksize;
-    const int ksteps = taps * (A.cin / BK);
+    const bool pair = BK == 8 && A.pair;
+    const int ksteps = pair ? (taps + 1) / 2 : taps * (A.cin / BK);
+    const int wrow = pair ? 8 * ksteps : taps * A.cin;   // floats per filter
     sd_f16v acc[MT][2];
 #pragma unroll
     for (int m = 0; m < MT; m++)
@@ -96,19 +101,26 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (WM == 2 && BK == 16 ? 
     for (int i = 0; i < WC; i++) {
         const int chunk = tid + NT * i;
         const bool on = chunk < BM * CPR;
-        wptr[i] = on ? A.wgt + (size_t)(co0 + chunk / CPR) * taps * A.cin + 4 * (chunk % CPR) : A.zero;
+        wptr[i] = on ? A.wgt + (size_t)(co0 + chunk / CPR) * wrow + 4 * (chunk % CPR) : A.zero;
         winc[i] = on ? BK : 0;                          // (tap, channel) is one contiguous axis of a filter's weights
     }
-    int c0 = 0, kh = 0, kw = 0;
+    int c0 = 0, kh = 0, kw = 0, ps = 0;
     auto retap = [&]() {                                // branch-free: the address of a padded tap is computed and discarded
 #pragma unroll
         for (int i = 0; i < XC; i++) {
             const int chunk = tid + NT * i;
-            const int yi = pyi[i] + kh, xi = pxi[i] + kw;
-            const bool ok = pok[i] && yi >= 0 && yi < A.H && xi >= 0 && xi < A.W;
-            const float* p = A.in + ((ptrdiff_t)pbase[i] + (ptrdiff_t)yi * A.W + xi) * A.cinStride + 4 * (chunk % CPR);
+            int dy = kh, dx = kw, coff = 4 * (chunk % CPR);
+            bool tapok = true;
+            if (BK == 8 && pair) {                      // piece q of the row = tap 2 ps + q, all four channels of its pixel
+                const int tap = 2 * ps + (chunk % CPR);
+                dy = tap / A.ksize; dx = tap - dy * A.ksize; coff = 0;
+                tapok = tap < taps;
+            }
+            const int yi = pyi[i] + dy, xi = pxi[i] + dx;
+            const bool ok = pok[i] && tapok && yi >= 0 && yi < A.H && xi >= 0 && xi < A.W;
+            const float* p = A.in + ((ptrdiff_t)pbase[i] + (ptrdiff_t)yi * A.W + xi) * A.cinStride + coff;
             xptr[i] = ok ? p : A.zero;
-            xinc[i] = ok ? BK : 0;
+            xinc[i] = ok && !pair ? BK : 0;
         }
     };
     retap();
@@ -117,6 +129,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (WM == 2 && BK == 16 ? 
         for (int i = 0; i < WC; i++) { wr[set][i] = *(const sd_f4*)wptr[i]; wptr[i] += winc[i]; }
 #pragma unroll
         for (int i = 0; i < XC; i++) { xr[set][i] = *(const sd_f4*)xptr[i]; xptr[i] += xinc[i]; }
+        if (BK == 8 && pair) { ps++; retap(); return; }
         c0 += BK;
         if (c0 == A.cin) { c0 = 0; kw++; if (kw == A.ksize) { kw = 0; kh++; } retap(); }
     };
@@ -291,7 +304,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (WM == 2 && BK == 16 ? 
 #define SD_F32_GRID(tx, ty) (unsigned)((((tx) + 7) / 8) * 8 * (ty))
 #define SD_F32_LDS(BK, WM, MT, NW) (2 * (32 * (MT) * (WM) + 64 * ((NW) / (WM))) * ((BK) + 4) * 4)
 
-// blobFromImage as k_blob_from_image, NHWC f32 with 8 channels (R, G, B after swapRB, then zeros)
+// blobFromImage as k_blob_from_image, NHWC f32 with 4 channels (R, G, B after swapRB, then a zero)
 __global__ void __launch_bounds__(256) k_blob_from_image_f32(const uint8_t* __restrict__ src, int sw, int sh, size_t sstride, size_t spitch,
                                                              const short4* __restrict__ ct, const short4* __restrict__ rt,
                                                              float* __restrict__ dst, int dw, int dh, int swapRB)
@@ -312,7 +325,6 @@ __global__ void __launch_bounds__(256) k_blob_from_image_f32(const uint8_t* __re
         const int v = ((((int)re.y * (h0 >> 4)) >> 16) + (((int)re.z * (h1 >> 4)) >> 16) + 2) >> 2;
         ch[c] = (float)(v & 255) * (float)(1 / 255.0);
     }
-    float* o = dst + ((size_t)img * dh * dw + (size_t)y * dw + x) * 8;
+    float* o = dst + ((size_t)img * dh * dw + (size_t)y * dw + x) * 4;
     *(sd_f4*)o = sd_f4{swapRB ? ch[2] : ch[0], ch[1], swapRB ? ch[0] : ch[2], 0.f};
-    *(sd_f4*)(o + 4) = sd_f4{0.f, 0.f, 0.f, 0.f};
 }

@@ -2164,8 +2164,12 @@ int sd_yolo_load_darknet_weights(sd_yolo* y, const float* p, size_t n_floats)
                 if (l.batch_normalize) { sc = scales[f] / sqrtf(var[f] + 0.000001f); bias = biases[f] - mean[f] * sc; }
                 b32[r.bOff + f] = bias;
                 for (int c = 0; c < cin; c++)
-                    for (int t = 0; t < taps; t++)
-                        w32[r.wOff + ((size_t)f * taps + t) * cinP + c] = wt[((size_t)f * cin + c) * taps + t] * sc;
+                    for (int t = 0; t < taps; t++) {
+                        // first layer: K step s = taps 2 s and 2 s + 1, four channels each (k_conv_f32's `pair` mode); else [tap][cinPad]
+                        const size_t k = i == 0 ? (size_t)f * 8 * ((taps + 1) / 2) + (size_t)(t / 2) * 8 + (size_t)(t % 2) * 4 + c
+                                                : ((size_t)f * taps + t) * cinP + c;
+                        w32[r.wOff + k] = wt[((size_t)f * cin + c) * taps + t] * sc;
+                    }
             }
         }
         HIPCHK(hipMemcpy(y->d_wgt32, w32.data(), y->wTotal * 4, hipMemcpyHostToDevice));
@@ -2259,7 +2263,7 @@ static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int hei
     static const int variant = getenv("SD_F32_VARIANT") ? atoi(getenv("SD_F32_VARIANT")) : 3;
     static const int small4 = getenv("SD_F32_SMALL4") ? atoi(getenv("SD_F32_SMALL4")) : 1;       // 4-wave tiles for the <= 64-filter layers too (0.5 % at batch 128); developer switch
     const float* cur = y->d_blob8;
-    int H = y->netH, W = y->netW, Cs = 8;
+    int H = y->netH, W = y->netW, Cs = 4;
     int rowBase = 0;
     for (size_t i = 0; i < y->L.size(); i++) {
         const sd_yolo_layer& l = y->L[i];
@@ -2267,7 +2271,7 @@ static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int hei
         if (l.type == SD_YOLO_CONV) {
             SdConvArgsF A;
             A.in = cur; A.wgt = y->d_wgt32 + r.wOff; A.bias = y->d_bias + r.bOff; A.res = nullptr; A.out = (float*)r.out; A.zero = (const float*)y->d_zero;
-            A.N = n; A.H = H; A.W = W; A.cin = i == 0 ? 8 : r.cinPad; A.cinStride = Cs;
+            A.N = n; A.H = H; A.W = W; A.cin = i == 0 ? 8 : r.cinPad; A.cinStride = Cs; A.pair = i == 0 ? 1 : 0;
             A.Ho = r.H; A.Wo = r.W; A.cout = l.filters; A.outStride = r.outC; A.resStride = 0;
             A.ksize = l.size; A.stride = l.stride; A.pad = l.size / 2; A.leaky = l.leaky;
             if (i + 1 < y->L.size() && y->L[i + 1].type == SD_YOLO_SHORTCUT && y->R[i + 1].alias) {
