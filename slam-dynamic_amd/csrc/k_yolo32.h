@@ -177,8 +177,10 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (WM == 2 && BK == 16 ? 
     // compiler can wait with vmcnt(7..4) instead of vmcnt(3..0)) 122.2; a staging map whose ds_write_b128 passes hit 16 distinct bank
     // quads (SQ_LDS_BANK_CONFLICT 0 instead of 33 % of the LDS-active cycles, but the LDS is busy only 10-16 % of the time) 123.7; the
     // barrier moved in front of the step's last chunk with the next step's first fragments requested right behind it (the post-barrier
-    // LDS round trip under 16 MFMAs) 121.4.  PMC: clock 2.37-2.39 GHz in these kernels (no DVFS give-back), MFMA pipe busy 83 % in the
-    // 3 x 3 body layers.
+    // LDS round trip under 16 MFMAs) 121.4.  The same tile staged entirely by LDS-DMA (global_load_lds_dwordx4 into unpadded, XOR-
+    // swizzled rows, a ring of three 16 KB stages at three workgroups per CU, counted vmcnt(4) + one barrier per step; results
+    // identical) 132.6 against 120.3: slower, not kept.  PMC: clock 2.37-2.39 GHz in these kernels (no DVFS give-back), MFMA pipe busy
+    // 83 % in the 3 x 3 body layers.
     auto step = [&](const int ks, const int par) {     // par = ks & 1, a literal at both call sites
         const int cur = par;
 #ifndef SD_F32_EXPERIMENT_NOFRAGS
