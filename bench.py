@@ -684,7 +684,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--lanes", "--batch", type=int, default=128, dest="lanes", help="independent camera streams per GPU = frames per step per GPU")
+    ap.add_argument("--lanes", "--batch", type=int, default=256, dest="lanes", help="independent camera streams per GPU = frames per step per GPU")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic sequences generated on the host (replicated over the lanes on the device)")
     ap.add_argument("--workload", choices=WORKLOADS, default="stereo-yolo")
     ap.add_argument("--extra", default="auto", help="comma-separated workloads also run (short) and reported under 'extra'; 'auto' = stereo,rgbd,rgbd-cull at N=1, none otherwise; 'none'")

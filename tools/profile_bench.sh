@@ -1,8 +1,8 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): kernel trace + the two PMC passes of the default bench.py workload.
 #   bash tools/profile_bench.sh <tag>      -> gpurun_out/<tag>_kt, <tag>_pmc_fetch, <tag>_pmc_write
-# Then, back in the container:  python tools/summarize_prof.py <tag> gpurun_out/<tag>_kt gpurun_out/<tag>_pmc_fetch gpurun_out/<tag>_pmc_write 256
-# (256 = images per front-end launch at the default 128 stereo lanes).  Counters are collected in their own runs, never with a trace.
+# Then, back in the container:  python tools/summarize_prof.py <tag> gpurun_out/<tag>_kt gpurun_out/<tag>_pmc_fetch gpurun_out/<tag>_pmc_write 512
+# (512 = images per front-end launch at the default 256 stereo lanes).  Counters are collected in their own runs, never with a trace.
 set -e
 TAG=${1:-prof}
 REPO=$(pwd)
