@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include "k_sort.h"
 
 typedef _Float16 sd_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 sd_h4 __attribute__((ext_vector_type(4)));

@@ -1,0 +1,670 @@
+// The detector part of the C ABI (include/sd_frontend.h, sd_yolo_*): its own translation unit, so that a change to a front-end kernel
+// does not recompile the convolution stack and vice versa.  Kernels: k_yolo.h (f16 mode), k_yolo32.h (f32 mode).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cstddef>
+#include <cmath>
+#include <string>
+#include <vector>
+#include "sd_common.h"
+#include "sd_yolo.h"
+
+extern "C" {
+
+// ---------------------------------------------------------------- detector (YOLOv3 on MFMA)
+int sd_yolo_v3_layers(sd_yolo_layer* layers, int cap, int* n, float anchors[18])
+{
+    if (!n) return SD_ERR_INVALID;
+    std::vector<sd_yolo_layer> L;
+    yolo_v3_layers(L);
+    *n = (int)L.size();
+    if (anchors) memcpy(anchors, kYoloV3Anchors, sizeof(kYoloV3Anchors));
+    if (layers) {
+        if (cap < (int)L.size()) return set_err(SD_ERR_CAPACITY, "layer buffer too small");
+        memcpy(layers, L.data(), L.size() * sizeof(sd_yolo_layer));
+    }
+    return SD_OK;
+}
+
+static void yolo_free(sd_yolo* y)
+{
+    if (!y) return;
+    for (void* p : y->owned) if (p) (void)hipFree(p);
+    if (y->d_hostImg) (void)hipFree(y->d_hostImg);
+    if (y->d_hostMask) (void)hipFree(y->d_hostMask);
+    if (y->stream) (void)hipStreamDestroy(y->stream);
+    delete y;
+}
+
+int sd_yolo_create(sd_yolo** out, const sd_yolo_layer* layers, int n_layers, const float anchors[18], int classes, int net_w,
+                   int net_h, int max_batch)
+{
+    return sd_yolo_create_prec(out, layers, n_layers, anchors, classes, net_w, net_h, max_batch, SD_YOLO_F16);
+}
+
+int sd_yolo_create_prec(sd_yolo** out, const sd_yolo_layer* layers, int n_layers, const float anchors[18], int classes, int net_w,
+                        int net_h, int max_batch, int precision)
+{
+    if (!out) return SD_ERR_INVALID;
+    *out = nullptr;
+    if (precision != SD_YOLO_F16 && precision != SD_YOLO_F32) return set_err(SD_ERR_INVALID, "precision must be SD_YOLO_F16 or SD_YOLO_F32");
+    if (!layers || n_layers < 1 || !anchors || classes != 80 || net_w < 32 || net_h < 32 || (net_w % 32) || (net_h % 32) || max_batch < 1)
+        return set_err(SD_ERR_INVALID, "bad detector arguments (classes must be 80, net size a multiple of 32)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(SD_ERR_NO_DEVICE, "no HIP device: the detector has no CPU fallback");
+    sd_yolo* y = new sd_yolo();
+    y->L.assign(layers, layers + n_layers);
+    y->R.resize(n_layers);
+    y->netW = net_w; y->netH = net_h; y->classes = classes; y->maxBatch = max_batch;
+    y->f32 = precision == SD_YOLO_F32;
+    const size_t eb = y->f32 ? 4 : 2;                     // bytes per activation element
+    memcpy(y->anchors, anchors, sizeof(y->anchors));
+    // ---- shapes
+    int H = net_h, W = net_w, C = 32;      // blob: 3 channels padded to 32
+    size_t wOff = 0, bOff = 0;
+    for (int i = 0; i < n_layers; i++) {
+        const sd_yolo_layer& l = y->L[i];
+        sd_yolo::Rt& r = y->R[i];
+        if (l.type == SD_YOLO_CONV) {
+            if ((l.size != 1 && l.size != 3) || (l.stride != 1 && l.stride != 2) || l.filters < 1) { delete y; return set_err(SD_ERR_UNSUPPORTED, "convolution size/stride not supported"); }
+            if (i == 0 && (l.size != 3 || l.stride != 1 || l.filters > 32)) { delete y; return set_err(SD_ERR_UNSUPPORTED, "first convolution must be 3x3, stride 1, <= 32 filters"); }
+            const int cinReal = i == 0 ? 3 : C;
+            r.cinPad = i == 0 ? 32 : C;
+            if (r.cinPad % 32) { delete y; return set_err(SD_ERR_UNSUPPORTED, "input channels must be a multiple of 32"); }
+            const int pad = l.size / 2;
+            r.H = (H + 2 * pad - l.size) / l.stride + 1; r.W = (W + 2 * pad - l.size) / l.stride + 1; r.C = l.filters;
+            r.outC = (l.filters + 31) / 32 * 32;            // stored channel count (255 -> 256)
+            r.coutPad = (l.filters + SD_G3_BM - 1) / SD_G3_BM * SD_G3_BM;        // weight/bias rows are padded to the widest filter tile
+            r.wOff = wOff; r.bOff = bOff;
+            wOff += (size_t)r.coutPad * l.size * l.size * r.cinPad;
+            bOff += r.coutPad;
+            y->convFlops += 2.0 * r.H * r.W * (double)l.filters * l.size * l.size * cinReal;
+            y->nconv++;
+        } else if (l.type == SD_YOLO_SHORTCUT) {
+            const int f = yolo_resolve(i, l.from[0]);
+            if (f < 0 || f >= i || y->R[f].H != H || y->R[f].W != W || y->R[f].C != C) { delete y; return set_err(SD_ERR_INVALID, "bad shortcut"); }
+            r.H = H; r.W = W; r.C = C; r.outC = C;
+        } else if (l.type == SD_YOLO_ROUTE) {
+            const int f0 = yolo_resolve(i, l.from[0]);
+            if (f0 < 0 || f0 >= i) { delete y; return set_err(SD_ERR_INVALID, "bad route"); }
+            r.H = y->R[f0].H; r.W = y->R[f0].W; r.C = y->R[f0].C;
+            if (l.nfrom == 2) {
+                const int f1 = yolo_resolve(i, l.from[1]);
+                if (f1 < 0 || f1 >= i || y->R[f1].H != r.H || y->R[f1].W != r.W) { delete y; return set_err(SD_ERR_INVALID, "bad route"); }
+                r.C += y->R[f1].C;
+            }
+            r.outC = r.C;
+        } else if (l.type == SD_YOLO_UPSAMPLE) {
+            r.H = 2 * H; r.W = 2 * W; r.C = C; r.outC = C;
+        } else if (l.type == SD_YOLO_YOLO) {
+            if (C != 3 * (5 + classes)) { delete y; return set_err(SD_ERR_INVALID, "[yolo] input must have 3*(5+classes) channels"); }
+            r.H = H; r.W = W; r.C = C; r.outC = C;
+            y->totalRows += H * W * 3;
+        } else { delete y; return set_err(SD_ERR_INVALID, "unknown layer type"); }
+        H = r.H; W = r.W; C = r.C;
+        if ((l.type == SD_YOLO_CONV) && (r.C % 4) && r.C != 3 * (5 + classes)) { delete y; return set_err(SD_ERR_UNSUPPORTED, "filters must be a multiple of 4"); }
+    }
+    y->wTotal = wOff; y->bTotal = bOff;
+    y->detCap = 8192;
+    // ---- device memory
+    auto alloc = [&](void** p, size_t bytes) -> bool {
+        if (hipMalloc(p, bytes) != hipSuccess) return false;
+        y->owned.push_back(*p);
+        return true;
+    };
+    bool ok = true;
+    const size_t nB = (size_t)max_batch;
+    if (y->f32) ok = ok && alloc((void**)&y->d_blob8, nB * net_h * net_w * 8 * 4);
+    else ok = ok && alloc((void**)&y->d_blob4, nB * net_h * net_w * 4 * 2);
+    ok = ok && alloc((void**)&y->d_zero, 256);
+    if (ok) ok = hipMemset(y->d_zero, 0, 256) == hipSuccess;
+
+    if (y->f32) ok = ok && alloc((void**)&y->d_wgt32, wOff * 4 + 64);
+    else ok = ok && alloc((void**)&y->d_wgt, wOff * 2 + 64);
+    ok = ok && alloc((void**)&y->d_bias, bOff * 4 + 64);
+    ok = ok && alloc((void**)&y->d_dets, nB * y->detCap * sizeof(SdDet));
+    ok = ok && alloc((void**)&y->d_ndet, nB * 4);
+    ok = ok && alloc((void**)&y->d_raw, (size_t)y->totalRows * (5 + classes) * 4 + 64);
+    ok = ok && alloc((void**)&y->d_ct, 8 * 8192);
+    ok = ok && alloc((void**)&y->d_rt, 8 * 8192);
+    for (int i = 0; ok && i < n_layers; i++) {
+        const sd_yolo_layer& l = y->L[i];
+        sd_yolo::Rt& r = y->R[i];
+        if (l.type == SD_YOLO_CONV) {
+            ok = alloc((void**)&r.out, nB * r.H * r.W * r.outC * eb + 64);
+            if (ok && r.outC != r.C) ok = hipMemset(r.out, 0, nB * r.H * r.W * r.outC * eb) == hipSuccess;
+        } else if (l.type == SD_YOLO_SHORTCUT) {
+            // fused into the preceding convolution's epilogue when that output has no other consumer
+            bool fuse = i > 0 && y->L[i - 1].type == SD_YOLO_CONV && yolo_resolve(i, l.from[0]) != i - 1;
+            for (int j = 0; fuse && j < n_layers; j++) {
+                if (j == i) continue;
+                const sd_yolo_layer& o = y->L[j];
+                if (o.type == SD_YOLO_SHORTCUT || o.type == SD_YOLO_ROUTE)
+                    for (int k = 0; k < o.nfrom; k++) if (yolo_resolve(j, o.from[k]) == i - 1) fuse = false;
+            }
+            if (fuse) { r.out = y->R[i - 1].out; r.alias = true; }
+            else ok = alloc((void**)&r.out, nB * r.H * r.W * r.outC * eb + 64);
+        } else if (l.type == SD_YOLO_ROUTE && l.nfrom == 1) {
+            r.out = y->R[yolo_resolve(i, l.from[0])].out; r.alias = true; r.outC = y->R[yolo_resolve(i, l.from[0])].outC;
+        } else if (l.type == SD_YOLO_ROUTE) {
+            ok = alloc((void**)&r.out, nB * r.H * r.W * r.outC * eb + 64);
+        } else if (l.type == SD_YOLO_UPSAMPLE) {
+            // materialised only inside the following 2-input route (k_upsample_concat); stand-alone upsample unsupported
+            if (!(i + 1 < n_layers && y->L[i + 1].type == SD_YOLO_ROUTE && y->L[i + 1].nfrom == 2 && yolo_resolve(i + 1, y->L[i + 1].from[0]) == i)) {
+                yolo_free(y); return set_err(SD_ERR_UNSUPPORTED, "[upsample] must feed a 2-input [route] as its first input");
+            }
+        } else if (l.type == SD_YOLO_YOLO) {
+            r.out = y->R[i - 1].out; r.alias = true; r.outC = y->R[i - 1].outC;
+        }
+    }
+    if (ok) ok = hipStreamCreateWithFlags(&y->stream, hipStreamNonBlocking) == hipSuccess;
+    if (!ok) { yolo_free(y); return set_err(SD_ERR_HIP, "detector allocation failed"); }
+    *out = y;
+    return SD_OK;
+}
+
+int sd_yolo_destroy(sd_yolo* y) { if (y) { (void)hipDeviceSynchronize(); yolo_free(y); } return SD_OK; }
+
+int sd_yolo_weight_count(const sd_yolo* y, size_t* n_floats)
+{
+    if (!y || !n_floats) return SD_ERR_INVALID;
+    size_t n = 0;
+    int C = 3;
+    for (size_t i = 0; i < y->L.size(); i++) {
+        const sd_yolo_layer& l = y->L[i];
+        if (l.type == SD_YOLO_CONV) {
+            const int cin = i == 0 ? 3 : (int)y->R[i].cinPad;
+            n += (size_t)l.filters * (l.batch_normalize ? 4 : 1) + (size_t)l.filters * cin * l.size * l.size;
+        }
+        (void)C;
+    }
+    *n_floats = n;
+    return SD_OK;
+}
+
+int sd_yolo_load_darknet_weights(sd_yolo* y, const float* p, size_t n_floats)
+{
+    if (!y || !p) return SD_ERR_INVALID;
+    size_t need = 0;
+    sd_yolo_weight_count(y, &need);
+    if (n_floats != need) return set_err(SD_ERR_INVALID, "weight payload has " + std::to_string(n_floats) + " floats, the network needs " + std::to_string(need));
+    if (y->f32) {
+        // f32 mode: [coutPad][taps][cinPad] f32 (the first layer's 3 input channels sit in a K chunk of 8), batch-norm folded in f32
+        std::vector<float> w32(y->wTotal, 0.f);
+        std::vector<float> b32(y->bTotal, 0.f);
+        const float* q = p;
+        for (size_t i = 0; i < y->L.size(); i++) {
+            const sd_yolo_layer& l = y->L[i];
+            if (l.type != SD_YOLO_CONV) continue;
+            const sd_yolo::Rt& r = y->R[i];
+            const int cin = i == 0 ? 3 : r.cinPad, cinP = i == 0 ? 8 : r.cinPad, F = l.filters, taps = l.size * l.size;
+            const float* biases = q; q += F;
+            const float *scales = nullptr, *mean = nullptr, *var = nullptr;
+            if (l.batch_normalize) { scales = q; q += F; mean = q; q += F; var = q; q += F; }
+            const float* wt = q; q += (size_t)F * cin * taps;
+            for (int f = 0; f < F; f++) {
+                float sc = 1.f, bias = biases[f];
+                if (l.batch_normalize) { sc = scales[f] / sqrtf(var[f] + 0.000001f); bias = biases[f] - mean[f] * sc; }
+                b32[r.bOff + f] = bias;
+                for (int c = 0; c < cin; c++)
+                    for (int t = 0; t < taps; t++) {
+                        // first layer: K step s = taps 2 s and 2 s + 1, four channels each (k_conv_f32's `pair` mode); else [tap][cinPad]
+                        const size_t k = i == 0 ? (size_t)f * 8 * ((taps + 1) / 2) + (size_t)(t / 2) * 8 + (size_t)(t % 2) * 4 + c
+                                                : ((size_t)f * taps + t) * cinP + c;
+                        w32[r.wOff + k] = wt[((size_t)f * cin + c) * taps + t] * sc;
+                    }
+            }
+        }
+        HIPCHK(hipMemcpy(y->d_wgt32, w32.data(), y->wTotal * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(y->d_bias, b32.data(), y->bTotal * 4, hipMemcpyHostToDevice));
+        y->weightsLoaded = true;
+        return SD_OK;
+    }
+    std::vector<_Float16> w(y->wTotal, (_Float16)0.f);
+    std::vector<float> b(y->bTotal, 0.f);
+    for (size_t i = 0; i < y->L.size(); i++) {
+        const sd_yolo_layer& l = y->L[i];
+        if (l.type != SD_YOLO_CONV) continue;
+        const sd_yolo::Rt& r = y->R[i];
+        const int cin = i == 0 ? 3 : r.cinPad, F = l.filters, taps = l.size * l.size;
+        const float* biases = p; p += F;
+        const float *scales = nullptr, *mean = nullptr, *var = nullptr;
+        if (l.batch_normalize) { scales = p; p += F; mean = p; p += F; var = p; p += F; }
+        const float* wt = p; p += (size_t)F * cin * taps;
+        for (int f = 0; f < F; f++) {
+            // batch-norm folding as cv::dnn's Darknet importer applies it: y = (x - mean) * scale / sqrt(var + 1e-6) + beta
+            float s = 1.f, bias = biases[f];
+            if (l.batch_normalize) { s = scales[f] / sqrtf(var[f] + 0.000001f); bias = biases[f] - mean[f] * s; }
+            b[r.bOff + f] = bias;
+            for (int c = 0; c < cin; c++)
+                for (int t = 0; t < taps; t++)
+                {
+                    if (i == 0)                        // k_conv_first: one 48-wide K row per filter, k = tap*4 + c
+                        w[r.wOff + (size_t)f * 48 + (size_t)t * 4 + c] = (_Float16)(wt[((size_t)f * cin + c) * taps + t] * s);
+                    else
+                        w[r.wOff + ((size_t)f * taps + t) * r.cinPad + c] = (_Float16)(wt[((size_t)f * cin + c) * taps + t] * s);
+                }
+        }
+    }
+    HIPCHK(hipMemcpy(y->d_wgt, w.data(), y->wTotal * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(y->d_bias, b.data(), y->bTotal * 4, hipMemcpyHostToDevice));
+    y->weightsLoaded = true;
+    return SD_OK;
+}
+
+int sd_yolo_layer_shape(const sd_yolo* y, int layer, int* h, int* w, int* c)
+{
+    if (!y || layer < 0 || layer >= (int)y->L.size()) return SD_ERR_INVALID;
+    if (h) *h = y->R[layer].H;
+    if (w) *w = y->R[layer].W;
+    if (c) *c = y->R[layer].C;
+    return SD_OK;
+}
+
+int sd_yolo_flops(const sd_yolo* y, double* flops_per_image)
+{
+    if (!y || !flops_per_image) return SD_ERR_INVALID;
+    *flops_per_image = y->convFlops;
+    return SD_OK;
+}
+
+// The forward pass in f32 (k_yolo32.h): same graph walk, one generic convolution kernel, f32 activations.
+// filter tiles walked back to back on a pixel tile (k_conv_f32's workgroup order): the largest power of two that divides tilesY and
+// keeps the group's weights (bm filters x kdim floats per tile) within 2.5 MB of an XCD's 4 MB L2
+static int f32_group_y(int tilesY, int bm, int kdim)
+{
+    int g = 1;
+    while (2 * g <= tilesY && tilesY % (2 * g) == 0 && (size_t)(2 * g) * bm * kdim * 4 <= (size_t)2560 * 1024) g *= 2;
+    return g;
+}
+
+static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int height, size_t stride, size_t image_pitch, int n,
+                            float conf_threshold, hipStream_t s)
+{
+    {
+        dim3 blk(64, 4), grd((y->netW + 63) / 64, (y->netH + 3) / 4, n);
+        hipLaunchKernelGGL(k_blob_from_image_f32, grd, blk, 0, s, d_bgr, width, height, stride, image_pitch, y->d_ct, y->d_rt, y->d_blob8, y->netW, y->netH, 1);
+    }
+    LAUNCH_CHECK("k_blob_from_image_f32");
+    HIPCHK(hipMemsetAsync(y->d_ndet, 0, (size_t)n * 4, s));
+    if (!y->attrF32) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<32, 2, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(32, 2, 2, 8)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<32, 2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(32, 2, 2, 4)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<16, 1, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(16, 1, 2, 8)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<16, 1, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(16, 1, 1, 8)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<8, 1, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(8, 1, 1, 8)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<16, 1, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(16, 1, 2, 4)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<16, 1, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(16, 1, 1, 4)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<16, 2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(16, 2, 2, 4)));
+        y->attrF32 = true;
+    }
+    // tile variant of the >= 128-filter layers: 3 (default) = 128 x 128 tiles on 4-wave workgroups with 16-channel K steps, 40 KB of LDS and 144
+    // VGPRs: THREE independent workgroups per CU (3 waves per SIMD keep the MFMA pipe fed through each other's barriers and staging;
+    // +3.3 % over variant 1 on every such layer at batch 128; four per CU -- 8-channel steps, 128 VGPRs without fragment prefetch, or 64 x 128 tiles --
+    // were 5-7 % slower); 1 = the same tile with 32-channel steps, two workgroups per CU; 0 = 8-wave 128 x 256 tiles; 2 = variant 1 for the
+    // 1x1 layers only.  SD_F32_VARIANT is a developer switch.
+    static const int variant = getenv("SD_F32_VARIANT") ? atoi(getenv("SD_F32_VARIANT")) : 3;
+    static const int small4 = getenv("SD_F32_SMALL4") ? atoi(getenv("SD_F32_SMALL4")) : 1;       // 4-wave tiles for the <= 64-filter layers too (0.5 % at batch 128); developer switch
+    const float* cur = y->d_blob8;
+    int H = y->netH, W = y->netW, Cs = 4;
+    int rowBase = 0;
+    for (size_t i = 0; i < y->L.size(); i++) {
+        const sd_yolo_layer& l = y->L[i];
+        const sd_yolo::Rt& r = y->R[i];
+        if (l.type == SD_YOLO_CONV) {
+            SdConvArgsF A;
+            A.in = cur; A.wgt = y->d_wgt32 + r.wOff; A.bias = y->d_bias + r.bOff; A.res = nullptr; A.out = (float*)r.out; A.zero = (const float*)y->d_zero;
+            A.N = n; A.H = H; A.W = W; A.cin = i == 0 ? 8 : r.cinPad; A.cinStride = Cs; A.pair = i == 0 ? 1 : 0;
+            A.Ho = r.H; A.Wo = r.W; A.cout = l.filters; A.outStride = r.outC; A.resStride = 0;
+            A.ksize = l.size; A.stride = l.stride; A.pad = l.size / 2; A.leaky = l.leaky;
+            if (i + 1 < y->L.size() && y->L[i + 1].type == SD_YOLO_SHORTCUT && y->R[i + 1].alias) {
+                const int f = yolo_resolve((int)i + 1, y->L[i + 1].from[0]);
+                A.res = (const float*)y->R[f].out; A.resStride = y->R[f].outC;
+            }
+            const int npix = n * r.H * r.W;
+            if (i == 0)                         // 3 (-> 8) input channels, <= 32 filters
+                { A.tilesX = (npix + 511) / 512; A.tilesY = (l.filters + 31) / 32; A.groupY = f32_group_y(A.tilesY, 32, A.cin * l.size * l.size); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<8, 1, 1, 8>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(512), SD_F32_LDS(8, 1, 1, 8), s, A); }
+            else if (l.filters <= 32 && small4)
+                { A.tilesX = (npix + 255) / 256; A.tilesY = 1; A.groupY = f32_group_y(A.tilesY, 32, A.cin * l.size * l.size); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 1, 4>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(256), SD_F32_LDS(16, 1, 1, 4), s, A); }
+            else if (l.filters <= 32)
+                { A.tilesX = (npix + 511) / 512; A.tilesY = 1; A.groupY = f32_group_y(A.tilesY, 32, A.cin * l.size * l.size); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 1, 8>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(512), SD_F32_LDS(16, 1, 1, 8), s, A); }
+            else if (l.filters <= 64 && small4)
+                { A.tilesX = (npix + 255) / 256; A.tilesY = 1; A.groupY = f32_group_y(A.tilesY, 64, A.cin * l.size * l.size); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 2, 4>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(256), SD_F32_LDS(16, 1, 2, 4), s, A); }
+            else if (l.filters <= 64)
+                { A.tilesX = (npix + 511) / 512; A.tilesY = 1; A.groupY = f32_group_y(A.tilesY, 64, A.cin * l.size * l.size); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 2, 8>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(512), SD_F32_LDS(16, 1, 2, 8), s, A); }
+            else if (variant == 3)
+                { A.tilesX = (npix + 127) / 128; A.tilesY = r.coutPad / 128; A.groupY = f32_group_y(A.tilesY, 128, A.cin * l.size * l.size); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 2, 2, 4>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(256), SD_F32_LDS(16, 2, 2, 4), s, A); }
+            else if (variant == 1 || (variant == 2 && l.size == 1))
+                { A.tilesX = (npix + 127) / 128; A.tilesY = r.coutPad / 128; A.groupY = f32_group_y(A.tilesY, 128, A.cin * l.size * l.size); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<32, 2, 2, 4>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(256), SD_F32_LDS(32, 2, 2, 4), s, A); }
+            else
+                { A.tilesX = (npix + 255) / 256; A.tilesY = r.coutPad / 128; A.groupY = f32_group_y(A.tilesY, 128, A.cin * l.size * l.size); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<32, 2, 2, 8>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(512), SD_F32_LDS(32, 2, 2, 8), s, A); }
+            LAUNCH_CHECK("k_conv_f32");
+        } else if (l.type == SD_YOLO_SHORTCUT) {
+            if (!r.alias) return set_err(SD_ERR_UNSUPPORTED, "unfused [shortcut] is not implemented");
+        } else if (l.type == SD_YOLO_ROUTE && l.nfrom == 2) {
+            const int fa = yolo_resolve((int)i, l.from[0]), fb = yolo_resolve((int)i, l.from[1]);
+            const int src = yolo_resolve(fa, -1);
+            const sd_yolo::Rt& ra = y->R[src]; const sd_yolo::Rt& rb = y->R[fb];
+            if (ra.outC != ra.C || rb.outC != rb.C || (ra.C % 4) || (rb.C % 4)) return set_err(SD_ERR_UNSUPPORTED, "route inputs must be dense, channels % 4 == 0");
+            // the copy kernel moves 16-byte pieces: an f32 channel counts as two halfs
+            hipLaunchKernelGGL(k_upsample_concat, dim3(2048), dim3(256), 0, s, ra.out, 2 * ra.C, ra.H, ra.W, rb.out, 2 * rb.C, r.out, n);
+            LAUNCH_CHECK("k_upsample_concat");
+        } else if (l.type == SD_YOLO_YOLO) {
+            const float* an = y->anchors;
+            const int rows = n * r.H * r.W * 3;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_region_decode<float>), dim3((rows + 255) / 256), dim3(256), 0, s, (const float*)r.out, r.outC, r.H, r.W, n, an[2 * l.mask[0]],
+                               an[2 * l.mask[0] + 1], an[2 * l.mask[1]], an[2 * l.mask[1] + 1], an[2 * l.mask[2]], an[2 * l.mask[2] + 1],
+                               y->netW, y->netH, conf_threshold, rowBase, y->d_dets, y->d_ndet, y->detCap, n == 1 ? y->d_raw : nullptr);
+            LAUNCH_CHECK("k_region_decode");
+            rowBase += r.H * r.W * 3;
+        }
+        if (l.type != SD_YOLO_YOLO && l.type != SD_YOLO_UPSAMPLE) { cur = (const float*)r.out; H = r.H; W = r.W; Cs = r.outC; }
+        if (l.type == SD_YOLO_YOLO) { cur = (const float*)r.out; }
+    }
+    return SD_OK;
+}
+
+int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int height, size_t stride, size_t image_pitch, int n,
+                           float conf_threshold, void* stream_)
+{
+    if (!y || !d_bgr || width < 2 || height < 2 || n < 1 || n > y->maxBatch || width > 8192 || height > 8192) return set_err(SD_ERR_INVALID, "bad forward arguments");
+    if (!y->weightsLoaded) return set_err(SD_ERR_STATE, "detector weights not loaded");
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : y->stream;
+    if (y->tabW != width || y->tabH != height) {
+        std::vector<int16_t> ct, rt;
+        yolo_resize_tables(width, height, y->netW, y->netH, ct, rt);
+        HIPCHK(hipMemcpy(y->d_ct, ct.data(), ct.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(y->d_rt, rt.data(), rt.size() * 2, hipMemcpyHostToDevice));
+        y->tabW = width; y->tabH = height;
+    }
+    if (y->f32) {
+        int rc = yolo_forward_f32(y, d_bgr, width, height, stride, image_pitch, n, conf_threshold, s);
+        if (rc != SD_OK) return rc;
+        y->lastN = n;
+        if (!stream_) HIPCHK(hipStreamSynchronize(s));
+        return SD_OK;
+    }
+    {
+        dim3 blk(64, 4), grd((y->netW + 63) / 64, (y->netH + 3) / 4, n);
+        hipLaunchKernelGGL(k_blob_from_image, grd, blk, 0, s, d_bgr, width, height, stride, image_pitch, y->d_ct, y->d_rt, y->d_blob4,
+                           y->netW, y->netH, 1);
+    }
+    LAUNCH_CHECK("k_blob_from_image");
+    HIPCHK(hipMemsetAsync(y->d_ndet, 0, (size_t)n * 4, s));
+    const _Float16* cur = y->d_blob4;
+    int H = y->netH, W = y->netW, Cs = 32;
+    int rowBase = 0;
+    for (size_t i = 0; i < y->L.size(); i++) {
+        const sd_yolo_layer& l = y->L[i];
+        const sd_yolo::Rt& r = y->R[i];
+        if (l.type == SD_YOLO_CONV && i == 0) {
+            const size_t npix0 = (size_t)n * r.H * r.W;
+            hipLaunchKernelGGL(k_conv_first, dim3((unsigned)((npix0 + 255) / 256)), dim3(256), 0, s, y->d_blob4, y->d_wgt + r.wOff,
+                               y->d_bias + r.bOff, r.out, n, r.H, r.W, l.filters, r.outC, l.leaky);
+            LAUNCH_CHECK("k_conv_first");
+        } else if (l.type == SD_YOLO_CONV) {
+            SdConvArgs A;
+            A.zero = y->d_zero; A.in = cur; A.wgt = y->d_wgt + r.wOff; A.bias = y->d_bias + r.bOff; A.res = nullptr; A.out = r.out;
+            A.N = n; A.H = H; A.W = W; A.cin = r.cinPad; A.cinStride = Cs;
+            A.Ho = r.H; A.Wo = r.W; A.cout = l.filters; A.coutPad = r.coutPad; A.outStride = r.outC; A.outOff = 0; A.resStride = 0;
+            A.ksize = l.size; A.stride = l.stride; A.pad = l.size / 2; A.leaky = l.leaky;
+            if (i + 1 < y->L.size() && y->L[i + 1].type == SD_YOLO_SHORTCUT && y->R[i + 1].alias) {
+                const int f = yolo_resolve((int)i + 1, y->L[i + 1].from[0]);
+                A.res = y->R[f].out; A.resStride = y->R[f].outC;
+            }
+            const int npix = n * r.H * r.W;
+            dim3 grd((npix + SD_CV_BN - 1) / SD_CV_BN, (l.filters + SD_CV_BM - 1) / SD_CV_BM);
+            const bool flat3 = l.size == 3 && l.stride == 1 && W <= 160 && l.filters % SD_G3_BM == 0 && r.cinPad % 32 == 0 && npix >= SD_G3_BN;
+            if (!flat3 && r.cinPad % 32 == 0 && npix >= 512 && (l.size == 1 || l.filters >= SD_G3_BM / 2)) {
+                bool& attr = y->attrGlds;          // per detector (= per device): function attributes are per device
+                const int lds8 = 3 * (512 * 64 + SD_G3_WBYTES), lds4 = 3 * (256 * 64 + SD_G3_WBYTES);
+                if (!attr) {
+                    HIPCHK(hipFuncSetAttribute((const void*)k_conv_glds<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds8));
+                    HIPCHK(hipFuncSetAttribute((const void*)k_conv_glds<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4));
+                    HIPCHK(hipFuncSetAttribute((const void*)k_conv_glds<8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds8));
+                    HIPCHK(hipFuncSetAttribute((const void*)k_conv_glds<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4));
+                    attr = true;
+                }
+                const int ct = r.coutPad / SD_G3_BM;
+                const bool big = ((npix + 511) / 512) * ct >= 256;
+                const dim3 g8((npix + 511) / 512, ct), g4((npix + 255) / 256, ct);
+                if (l.size == 1 && big) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_glds<8, 1>), g8, dim3(512), lds8, s, A);
+                else if (l.size == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_glds<4, 1>), g4, dim3(256), lds4, s, A);
+                else if (big) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_glds<8, 3>), g8, dim3(512), lds8, s, A);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_glds<4, 3>), g4, dim3(256), lds4, s, A);
+            } else if (flat3) {
+                bool& attr = y->attrFlat3;
+                if (!attr) {
+                    HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_glds<80>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_G3_LDS(80)));
+                    HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_glds<160>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_G3_LDS(160)));
+                    attr = true;
+                }
+                const dim3 g3((npix + SD_G3_BN - 1) / SD_G3_BN, l.filters / SD_G3_BM);
+                if (W <= 80) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv3x3_glds<80>), g3, dim3(512), SD_G3_LDS(80), s, A);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv3x3_glds<160>), g3, dim3(512), SD_G3_LDS(160), s, A);
+            } else if (l.size == 3 && l.stride == 1 && W <= SD_C3_MAXW && l.filters % SD_C3_BM == 0 && r.cinPad % SD_C3_BK == 0)
+                hipLaunchKernelGGL(k_conv3x3_flat, dim3((npix + SD_C3_BN - 1) / SD_C3_BN, l.filters / SD_C3_BM), dim3(256), 0, s, A);
+            else if (r.cinPad % 64 == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_mfma<64>), grd, dim3(256), 0, s, A);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_mfma<32>), grd, dim3(256), 0, s, A);
+            LAUNCH_CHECK("k_conv_mfma");
+        } else if (l.type == SD_YOLO_SHORTCUT) {
+            if (!r.alias) return set_err(SD_ERR_UNSUPPORTED, "unfused [shortcut] is not implemented");
+        } else if (l.type == SD_YOLO_ROUTE && l.nfrom == 2) {
+            const int fa = yolo_resolve((int)i, l.from[0]), fb = yolo_resolve((int)i, l.from[1]);
+            const int src = yolo_resolve(fa, -1);          // the layer the [upsample] reads
+            const sd_yolo::Rt& ra = y->R[src]; const sd_yolo::Rt& rb = y->R[fb];
+            if (ra.outC != ra.C || rb.outC != rb.C || (ra.C % 8) || (rb.C % 8)) return set_err(SD_ERR_UNSUPPORTED, "route inputs must be dense, channels % 8 == 0");
+            hipLaunchKernelGGL(k_upsample_concat, dim3(2048), dim3(256), 0, s, ra.out, ra.C, ra.H, ra.W, rb.out, rb.C, r.out, n);
+            LAUNCH_CHECK("k_upsample_concat");
+        } else if (l.type == SD_YOLO_YOLO) {
+            const float* an = y->anchors;
+            const int rows = n * r.H * r.W * 3;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_region_decode<_Float16>), dim3((rows + 255) / 256), dim3(256), 0, s, (const _Float16*)r.out, r.outC, r.H, r.W, n, an[2 * l.mask[0]],
+                               an[2 * l.mask[0] + 1], an[2 * l.mask[1]], an[2 * l.mask[1] + 1], an[2 * l.mask[2]], an[2 * l.mask[2] + 1],
+                               y->netW, y->netH, conf_threshold, rowBase, y->d_dets, y->d_ndet, y->detCap, n == 1 ? y->d_raw : nullptr);
+            LAUNCH_CHECK("k_region_decode");
+            rowBase += r.H * r.W * 3;
+        }
+        // the input of the next layer
+        if (l.type != SD_YOLO_YOLO && l.type != SD_YOLO_UPSAMPLE) { cur = r.out; H = r.H; W = r.W; Cs = r.outC; }
+        if (l.type == SD_YOLO_YOLO) { cur = r.out; }
+    }
+    y->lastN = n;
+    if (!stream_) HIPCHK(hipStreamSynchronize(s));
+    return SD_OK;
+}
+
+int sd_yolo_download_layer(sd_yolo* y, int layer, int image, uint16_t* out)
+{
+    if (!y || !out || layer < 0 || layer >= (int)y->L.size() || image < 0 || image >= y->lastN) return SD_ERR_INVALID;
+    const sd_yolo::Rt& r = y->R[layer];
+    if (!r.out) return set_err(SD_ERR_INVALID, "layer has no materialised output");
+    HIPCHK(hipDeviceSynchronize());
+    const size_t pix = (size_t)r.H * r.W, eb = y->f32 ? 4 : 2;       // f32 mode: `out` receives floats
+    const unsigned char* src = (const unsigned char*)r.out + (size_t)image * pix * r.outC * eb;
+    if (r.outC == r.C) {
+        HIPCHK(hipMemcpy(out, src, pix * r.C * eb, hipMemcpyDeviceToHost));
+    } else {
+        HIPCHK(hipMemcpy2D(out, (size_t)r.C * eb, src, (size_t)r.outC * eb, (size_t)r.C * eb, pix, hipMemcpyDeviceToHost));
+    }
+    return SD_OK;
+}
+
+int sd_yolo_precision(const sd_yolo* y, int* precision)
+{
+    if (!y || !precision) return SD_ERR_INVALID;
+    *precision = y->f32 ? SD_YOLO_F32 : SD_YOLO_F16;
+    return SD_OK;
+}
+
+int sd_yolo_download_region(sd_yolo* y, float* rows, int* total_rows)
+{
+    if (!y || !rows || y->lastN != 1) return set_err(SD_ERR_STATE, "region rows are kept only after a forward with n == 1");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(rows, y->d_raw, (size_t)y->totalRows * (5 + y->classes) * 4, hipMemcpyDeviceToHost));
+    if (total_rows) *total_rows = y->totalRows;
+    return SD_OK;
+}
+
+// shared by Segmentation_ / Segmentation: rows above the threshold -> int boxes -> NMSBoxes -> kept (class-filtered) indices
+static int yolo_nms(sd_yolo* y, int image, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold,
+                    std::vector<SdDet>& d, std::vector<YRect>& rects, std::vector<int>& kept)
+{
+    HIPCHK(hipDeviceSynchronize());
+    int nd = 0;
+    HIPCHK(hipMemcpy(&nd, y->d_ndet + image, 4, hipMemcpyDeviceToHost));
+    if (nd > y->detCap) return set_err(SD_ERR_CAPACITY, "more than 8192 rows above the confidence threshold");
+    d.resize(nd);
+    if (nd) HIPCHK(hipMemcpy(d.data(), y->d_dets + (size_t)image * y->detCap, (size_t)nd * sizeof(SdDet), hipMemcpyDeviceToHost));
+    std::sort(d.begin(), d.end(), [](const SdDet& a, const SdDet& b) { return a.row < b.row; });   // cv::dnn row order
+    rects.assign(nd, YRect{0, 0, 0, 0});
+    for (int i = 0; i < nd; i++) {
+        if (!(d[i].conf > conf_threshold)) continue;
+        const int centerX = (int)(d[i].cx * frame_cols), centerY = (int)(d[i].cy * frame_rows);
+        const int width = (int)(d[i].w * frame_cols), height = (int)(d[i].h * frame_rows);
+        rects[i] = YRect{centerX - width / 2, centerY - height / 2, width, height};
+    }
+    std::vector<int> order;
+    for (int i = 0; i < nd; i++) if (d[i].conf > conf_threshold) order.push_back(i);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return d[a].conf > d[b].conf; });
+    std::vector<int> keep;
+    for (int idx : order) {
+        bool k = true;
+        for (size_t j = 0; j < keep.size() && k; j++) k = yolo_overlap(rects[idx], rects[keep[j]]) <= nms_threshold;
+        if (k) keep.push_back(idx);
+    }
+    kept.clear();
+    for (int idx : keep) {
+        const int c = d[idx].cls;     // coco.names: 0 person, 1 bicycle, 2 car, 3 motorbike ("motorcycle" never matches), 5 bus, 7 truck
+        if (c == 0 || c == 1 || c == 2 || c == 5 || c == 7) kept.push_back(idx);
+    }
+    return SD_OK;
+}
+
+// yolov3Segment::Segmentation (yolo.cc:34-58): mask = 1 outside the dilated central halves of the kept boxes; all ones
+// (and *no_target = 1) when nothing is kept.  d_mask: frame_rows x frame_cols u8 in HBM.
+int sd_yolo_mask_device(sd_yolo* y, int image, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold,
+                        uint8_t* d_mask, size_t stride, int* no_target, void* stream_)
+{
+    if (!y || !d_mask || image < 0 || image >= y->lastN || frame_cols < 1 || frame_rows < 1 || stride < (size_t)frame_cols) return SD_ERR_INVALID;
+    std::vector<SdDet> d; std::vector<YRect> rects; std::vector<int> kept;
+    int rc = yolo_nms(y, image, frame_cols, frame_rows, conf_threshold, nms_threshold, d, rects, kept);
+    if (rc != SD_OK) return rc;
+    if (kept.size() > 32) return set_err(SD_ERR_CAPACITY, "more than 32 kept boxes");
+    if (no_target) *no_target = kept.empty();
+    SdMaskRects R;
+    R.n = (int)kept.size();
+    for (int k = 0; k < R.n; k++) {
+        const YRect& b = rects[kept[k]];
+        R.x0[k] = std::max(0, b.x + b.w / 4); R.x1[k] = std::min(b.x + 3 * b.w / 4, frame_cols);
+        R.y0[k] = std::max(0, b.y); R.y1[k] = std::min(b.y + b.h, frame_rows);
+    }
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : y->stream;
+    hipLaunchKernelGGL(k_mask_dilate, dim3((frame_cols + 15) / 16, (frame_rows + 15) / 16), dim3(256), 0, s, R, frame_cols, frame_rows, d_mask, stride);
+    LAUNCH_CHECK("k_mask_dilate");
+    if (!stream_) HIPCHK(hipStreamSynchronize(s));
+    return SD_OK;
+}
+
+int sd_yolo_boxes(sd_yolo* y, int image, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold, double* boxes,
+                  int32_t* class_ids, float* confidences, int cap, int* n_out)
+{
+    if (!y || !n_out || image < 0 || image >= y->lastN || frame_cols < 1 || frame_rows < 1) return SD_ERR_INVALID;
+    {
+        std::vector<SdDet> d; std::vector<YRect> rects; std::vector<int> kept;
+        int rc = yolo_nms(y, image, frame_cols, frame_rows, conf_threshold, nms_threshold, d, rects, kept);
+        if (rc != SD_OK) return rc;
+        int n = 0;
+        for (int idx : kept) {
+            if (n >= cap) return set_err(SD_ERR_CAPACITY, "box buffer too small");
+            const YRect& r = rects[idx];
+            // rectCenterScale(box, Size2d(-0.2 w, 0.6 h)): rect += size; rect -= size / 2
+            const double sw = -0.2 * (double)r.w, sh = 0.6 * (double)r.h;
+            if (boxes) { boxes[4 * n] = (double)r.x - sw / 2.0; boxes[4 * n + 1] = (double)r.y - sh / 2.0; boxes[4 * n + 2] = (double)r.w + sw; boxes[4 * n + 3] = (double)r.h + sh; }
+            if (class_ids) class_ids[n] = d[idx].cls;
+            if (confidences) confidences[n] = d[idx].conf;
+            n++;
+        }
+        *n_out = n;
+        return SD_OK;
+    }
+}
+
+// Host-image forms for a per-frame caller (yolo->Segmentation_(imLeft) in the example drivers): upload + forward for one image,
+// and the Segmentation mask downloaded to host memory.
+int sd_yolo_forward_host(sd_yolo* y, const uint8_t* bgr, int width, int height, size_t stride, float conf_threshold)
+{
+    if (!y || !bgr || width < 1 || height < 1 || stride < (size_t)width * 3) return set_err(SD_ERR_INVALID, "bad yolo_forward_host arguments");
+    const size_t bytes = stride * (size_t)height;
+    if (bytes > y->hostImgCap) {
+        if (y->d_hostImg) (void)hipFree(y->d_hostImg);
+        y->d_hostImg = nullptr; y->hostImgCap = 0;
+        HIPCHK(hipMalloc((void**)&y->d_hostImg, bytes));
+        y->hostImgCap = bytes;
+    }
+    HIPCHK(hipMemcpyAsync(y->d_hostImg, bgr, bytes, hipMemcpyHostToDevice, y->stream));
+    return sd_yolo_forward_device(y, y->d_hostImg, width, height, stride, bytes, 1, conf_threshold, y->stream);
+}
+
+int sd_yolo_mask_host(sd_yolo* y, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold, uint8_t* mask, size_t stride,
+                      int* no_target)
+{
+    if (!y || !mask || frame_cols < 1 || frame_rows < 1 || stride < (size_t)frame_cols) return set_err(SD_ERR_INVALID, "bad yolo_mask_host arguments");
+    const size_t bytes = (size_t)frame_cols * frame_rows;
+    if (bytes > y->hostMaskCap) {
+        if (y->d_hostMask) (void)hipFree(y->d_hostMask);
+        y->d_hostMask = nullptr; y->hostMaskCap = 0;
+        HIPCHK(hipMalloc((void**)&y->d_hostMask, bytes));
+        y->hostMaskCap = bytes;
+    }
+    int rc = sd_yolo_mask_device(y, 0, frame_cols, frame_rows, conf_threshold, nms_threshold, y->d_hostMask, (size_t)frame_cols, no_target, nullptr);
+    if (rc != SD_OK) return rc;
+    HIPCHK(hipMemcpy2D(mask, stride, y->d_hostMask, (size_t)frame_cols, (size_t)frame_cols, (size_t)frame_rows, hipMemcpyDeviceToHost));
+    return SD_OK;
+}
+
+// postprocess_ for the first n_images of the last forward pass, entirely on the device (k_yolo_nms): one launch, and
+// with the host form one download of n_images x (32 boxes + count) instead of a synchronisation per image.
+int sd_yolo_boxes_device(sd_yolo* y, int n_images, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold,
+                         double* d_boxes, int32_t* d_class_ids, float* d_confidences, int32_t* d_n_boxes, void* stream_)
+{
+    if (!y || n_images < 0 || n_images > y->lastN || frame_cols < 1 || frame_rows < 1 || !d_boxes || !d_class_ids || !d_confidences || !d_n_boxes)
+        return set_err(SD_ERR_INVALID, "bad yolo_boxes_device arguments");
+    if (n_images == 0) return SD_OK;
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : y->stream;
+    if (!y->attrNms) { HIPCHK(hipFuncSetAttribute((const void*)k_yolo_nms, hipFuncAttributeMaxDynamicSharedMemorySize, SD_NMS_LDS)); y->attrNms = true; }
+    hipLaunchKernelGGL(k_yolo_nms, dim3(n_images), dim3(256), SD_NMS_LDS, s, y->d_dets, y->d_ndet, y->detCap, frame_cols, frame_rows, conf_threshold,
+                       nms_threshold, d_boxes, d_class_ids, d_confidences, d_n_boxes);
+    LAUNCH_CHECK("k_yolo_nms");
+    return SD_OK;
+}
+
+int sd_yolo_boxes_batch(sd_yolo* y, int n_images, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold,
+                        double* boxes, int32_t* class_ids, float* confidences, int32_t* n_boxes, void* stream_)
+{
+    if (!y || !boxes || !n_boxes || n_images < 0 || n_images > y->maxBatch) return set_err(SD_ERR_INVALID, "bad yolo_boxes_batch arguments");
+    if (!y->d_nmsBoxes) {
+        const size_t nB = (size_t)y->maxBatch;
+        HIPCHK(hipMalloc((void**)&y->d_nmsBoxes, nB * 32 * 4 * 8)); y->owned.push_back(y->d_nmsBoxes);
+        HIPCHK(hipMalloc((void**)&y->d_nmsCls, nB * 32 * 4)); y->owned.push_back(y->d_nmsCls);
+        HIPCHK(hipMalloc((void**)&y->d_nmsConf, nB * 32 * 4)); y->owned.push_back(y->d_nmsConf);
+        HIPCHK(hipMalloc((void**)&y->d_nmsN, nB * 4)); y->owned.push_back(y->d_nmsN);
+    }
+    int rc = sd_yolo_boxes_device(y, n_images, frame_cols, frame_rows, conf_threshold, nms_threshold, y->d_nmsBoxes, y->d_nmsCls, y->d_nmsConf,
+                                  y->d_nmsN, stream_);
+    if (rc != SD_OK || n_images == 0) return rc;
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : y->stream;
+    HIPCHK(hipMemcpyAsync(boxes, y->d_nmsBoxes, (size_t)n_images * 32 * 4 * 8, hipMemcpyDeviceToHost, s));
+    if (class_ids) HIPCHK(hipMemcpyAsync(class_ids, y->d_nmsCls, (size_t)n_images * 32 * 4, hipMemcpyDeviceToHost, s));
+    if (confidences) HIPCHK(hipMemcpyAsync(confidences, y->d_nmsConf, (size_t)n_images * 32 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(n_boxes, y->d_nmsN, (size_t)n_images * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int i = 0; i < n_images; i++)
+        if (n_boxes[i] < 0) return set_err(SD_ERR_CAPACITY, "postprocess on device: more than 4096 rows above the threshold or more than 32 kept boxes");
+    return SD_OK;
+}
+
+
+}  // extern "C"
