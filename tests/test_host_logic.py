@@ -161,3 +161,23 @@ def test_oracle_local_map_best_second_ratio():
     track, mpm, kpm, nm = orc.search_local_map(kp, desc, ur, mp, md, T, cam10, sf, 1.0, 0.8)
     # its best is kp1 (8 bits, level 0), second kp2 (16 bits, level 1): levels differ -> no ratio test
     assert mpm.tolist() == [0, 1] and kpm.tolist() == [0, 1, -1] and nm == 2
+
+
+def test_bench_helpers_cpu_share_and_detector_bytes():
+    """bench.usable_cpus() never exceeds the affinity mask and is at least 1; detector_algorithmic_bytes() of the built-in YOLOv3 list at
+    640 x 480: every convolution's input + output (+ the fused shortcut operand) once per image, the weights once per launch."""
+    import os
+    import bench
+    import __graft_entry__ as graft
+    n = bench.usable_cpus()
+    assert 1 <= n <= (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    pkg = graft.load_package()
+    layers, _ = pkg.yolo.v3_layers()
+    one = bench.detector_algorithmic_bytes(layers, 640, 480, 1)
+    two = bench.detector_algorithmic_bytes(layers, 640, 480, 2)
+    weights = 2 * one - two                                  # the batch-independent part
+    cins = pkg.yolo.conv_inputs(layers)
+    expect = sum(int(l["filters"]) * cins[i] * int(l["size"]) ** 2 for i, l in enumerate(layers) if l["type"] == pkg.yolo.CONV)
+    assert weights == 4 * expect == 4 * 61_895_776           # yolov3.cfg's convolution weights (its 62,001,757 parameters minus biases / batch-norm terms), f32
+    assert (one - weights) % 4 == 0 and 600e6 < one - weights < 700e6        # ~669 MB of activation traffic per image
+    assert bench.detector_algorithmic_bytes(layers, 640, 480, 1, elt=2) * 2 == one
