@@ -416,6 +416,8 @@ class Workload:
             self.cam = fe.make_camera(cfg)
             self.depth_factor = float(np.float32(1.0) / np.float32(cfg["depth_map_factor"]))
         self.frames = []          # per timestep: dict(images, depth, boxes, n_boxes, stamps)
+        self.n_total = 0          # time steps this workload will run (prepare() adds to it)
+        self.max_resident = self.T if self.strong else 48     # time steps generated and parked in HBM; longer runs walk them back and forth
         self.t = 0
         self.n_boxes_seen = []
 
@@ -424,8 +426,9 @@ class Workload:
         torch, synth, cfg = self.torch, self.synth, self.cfg
         S, D = self.S, self.distinct
         reps = (S + D - 1) // D
+        self.n_total += n_steps
         base = len(self.frames)
-        for t in range(base, base + n_steps):
+        for t in range(base, min(base + n_steps, self.max_resident)):
             per = [synth_timestep(synth, self.kind, cfg, (10 + self.my_sequences[d]) if self.strong else (10 + 37 * self.rank + d), t) for d in range(D)]
             img = torch.from_numpy(np.stack([p["images"] for p in per])).to(self.dev)                  # [D, ipl, H, W, 3]
             img = img.repeat((reps, 1, 1, 1, 1))[:S].contiguous()
@@ -441,9 +444,21 @@ class Workload:
                 msk = torch.from_numpy(np.stack([p["mask"] for p in per])).to(self.dev).repeat((reps, 1, 1))[:S].contiguous()
             self.frames.append(dict(images=img, depth=dep, mask=msk, boxes=bx, n_boxes=nb, stamps=np.full(S, per[0]["stamp"], np.float64)))
 
+    def frame_at(self, t):
+        """Time step t of the run.  Beyond the resident steps the sequences are walked back and forth (P-1, P-2, ..., 1, 0, 1, ...): the
+        camera motion reverses, consecutive frames stay consecutive views of the same scene, and the time stamps keep increasing -- the
+        work per step is that of a longer sequence, for an arbitrary --steps, within a fixed amount of HBM and of host generation time."""
+        P = len(self.frames)
+        if t < P:
+            return self.frames[t]
+        m = t % (2 * P - 2) if P > 1 else 0
+        fr = dict(self.frames[m if m < P else 2 * P - 2 - m])
+        fr["stamps"] = np.full(self.S, t / float(self.cfg["fps"]), np.float64)
+        return fr
+
     def step(self):
         fe, torch = self.fe, self.torch
-        fr = self.frames[self.t]
+        fr = self.frame_at(self.t)
         W, H, S = self.W, self.H, self.S
         boxes, n_boxes = (fr["boxes"], fr["n_boxes"]) if self.with_boxes else (None, None)
         if self.det is not None:
@@ -457,7 +472,7 @@ class Workload:
                 raise RuntimeError("detector post-processing on the device exceeded its capacity")
             n_boxes = np.minimum(nb_all, 16).astype(np.int32)          # boxTrack may re-inject as many again: keep within SD_MAX_BOXES
             boxes = self.det_host[k]["b"].numpy().copy()
-            if self.lookahead and self.t + 1 < len(self.frames):     # the next frame's detector pass is queued behind this one's download
+            if self.lookahead and self.t + 1 < self.n_total:     # the next frame's detector pass is queued behind this one's download
                 self.enqueue_detector(self.t + 1)
         res = self.trk.track(fr["images"].data_ptr(), W * 3, W * H * 3, fr["stamps"], boxes=boxes, n_boxes=n_boxes,
                              d_depth=fr["depth"].data_ptr() if fr["depth"] is not None else 0, depth_stride=W, depth_pitch=W * H,
@@ -474,7 +489,7 @@ class Workload:
         torch = self.torch
         W, H, S = self.W, self.H, self.S
         k = t & 1
-        fr = self.frames[t]
+        fr = self.frame_at(t)
         d = self.det_dev[k]
         Sn = self.S_det
         for p in range(self.n_det):
@@ -573,7 +588,7 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline):
         det_ms = None
         if wl.det is not None:                 # the detector alone, nothing else on the GPU: the MFMA block
             torch.cuda.synchronize()
-            fr = wl.frames[wl.t]
+            fr = wl.frame_at(wl.t)
             Sn = wl.S_det
 
             def det_pass(p):
