@@ -179,7 +179,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (WM == 2 && BK == 16 ? 
     // barrier moved in front of the step's last chunk with the next step's first fragments requested right behind it (the post-barrier
     // LDS round trip under 16 MFMAs) 121.4.  The same tile staged entirely by LDS-DMA (global_load_lds_dwordx4 into unpadded, XOR-
     // swizzled rows, a ring of three 16 KB stages at three workgroups per CU, counted vmcnt(4) + one barrier per step; results
-    // identical) 132.6 against 120.3: slower, not kept.  PMC: clock 2.37-2.39 GHz in these kernels (no DVFS give-back), MFMA pipe busy
+    // identical) 132.6 against 120.3: slower, not kept.  The weight operand kept out of LDS altogether (each lane fetches its own A
+    // fragments from L2 one step ahead, only the activations are staged: half the LDS writes and reads; results identical) 136.0
+    // against 119.7: slower, not kept -- so the ~9 % that vanish with the staging are not the LDS writes as such.  PMC: clock 2.37-2.39 GHz in these kernels (no DVFS give-back), MFMA pipe busy
     // 83 % in the 3 x 3 body layers.
     auto step = [&](const int ks, const int par) {     // par = ks & 1, a literal at both call sites
         const int cur = par;
