@@ -276,6 +276,15 @@ def cpu_baseline(workload, cfg, kind, sensor, with_boxes, with_detector, pkg, bu
     return out
 
 
+def pingpong_index(t, P):
+    """Index of the resident time step shown at step t when P steps are resident: 0 .. P-1, P-2 .. 1, 0, 1, ... (consecutive steps always
+    show neighbouring resident steps)."""
+    if P <= 1:
+        return 0
+    m = t % (2 * P - 2)
+    return m if m < P else 2 * P - 2 - m
+
+
 def detector_algorithmic_bytes(layers, net_w, net_h, batch, elt=4):
     """HBM bytes a detector batch needs at least: every convolution reads its input once, writes its output once (plus the shortcut
     operand it adds in its epilogue) and reads its weights once per launch."""
@@ -451,8 +460,7 @@ class Workload:
         P = len(self.frames)
         if t < P:
             return self.frames[t]
-        m = t % (2 * P - 2) if P > 1 else 0
-        fr = dict(self.frames[m if m < P else 2 * P - 2 - m])
+        fr = dict(self.frames[pingpong_index(t, P)])
         fr["stamps"] = np.full(self.S, t / float(self.cfg["fps"]), np.float64)
         return fr
 

@@ -181,3 +181,15 @@ def test_bench_helpers_cpu_share_and_detector_bytes():
     assert weights == 4 * expect == 4 * 61_895_776           # yolov3.cfg's convolution weights (its 62,001,757 parameters minus biases / batch-norm terms), f32
     assert (one - weights) % 4 == 0 and 600e6 < one - weights < 700e6        # ~669 MB of activation traffic per image
     assert bench.detector_algorithmic_bytes(layers, 640, 480, 1, elt=2) * 2 == one
+
+
+def test_bench_pingpong_index_keeps_neighbours():
+    """Long runs walk the resident time steps back and forth: the first P steps are the resident ones in order, and any two consecutive
+    steps show resident steps that are neighbours (|difference| == 1), so the tracker always sees consecutive views of one scene."""
+    import bench
+    for P in (2, 3, 5, 48):
+        seq = [bench.pingpong_index(t, P) for t in range(5 * P)]
+        assert seq[:P] == list(range(P))
+        assert all(0 <= i < P for i in seq)
+        assert all(abs(a - b) == 1 for a, b in zip(seq, seq[1:]))
+    assert [bench.pingpong_index(t, 1) for t in range(4)] == [0, 0, 0, 0]
