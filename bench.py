@@ -122,9 +122,10 @@ def decode_record(rec_u8, layout, cap):
     fb = part("fb")
     head = fb[:16].view(np.int32)                     # SdFrameBoxes: nb, nAll, nOri, nDyn
     nb, n_s = int(head[0]), int(head[2])
-    base = 16 + 32 * 4 * 8
-    box_idx = fb[base:base + 128].view(np.int32)[:nb].copy()
-    box_status = fb[base + 128:base + 256].view(np.int32)[:nb].copy()
+    M = (len(fb) - 24) // 48                         # SD_MAX_BOXES from sizeof(sd_frame_boxes) = 16 + M * 32 + 3 * M * 4 + (M + 1) * 4 + 4
+    base = 16 + M * 4 * 8
+    box_idx = fb[base:base + 4 * M].view(np.int32)[:nb].copy()
+    box_status = fb[base + 4 * M:base + 8 * M].view(np.int32)[:nb].copy()
     kp = part("kp").view(np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")]))[:N]
     readmitted = np.arange(N) >= n_s                 # dyn_mask of SURVEY 8e: keypoints UpdateFrame appended behind the static ones
     return dict(N=N, N_s=n_s, N_d=int(head[3]), n_boxes=nb, box_idx=box_idx, box_status=box_status, kp=kp.copy(),
@@ -412,9 +413,10 @@ class Workload:
             self.det_in_flight = -1
             self.lookahead = True             # the next frame's forward pass is launched before this frame's front end
             S_ = self.S                       # two result slots: forward + NMS + download of frame t + 1 are queued before frame t's boxes are consumed
-            self.det_dev = [dict(b=torch.zeros((S_, 32, 4), dtype=torch.float64, device=dev), c=torch.zeros((S_, 32), dtype=torch.int32, device=dev),
-                                 f=torch.zeros((S_, 32), dtype=torch.float32, device=dev), n=torch.zeros((S_,), dtype=torch.int32, device=dev)) for _ in range(2)]
-            self.det_host = [dict(b=torch.zeros((S_, 32, 4), dtype=torch.float64).pin_memory(), n=torch.zeros((S_,), dtype=torch.int32).pin_memory()) for _ in range(2)]
+            M = fe.MAXB                       # SD_MAX_BOXES: the detector's box table and the tracker's have the same stride, nothing is cut
+            self.det_dev = [dict(b=torch.zeros((S_, M, 4), dtype=torch.float64, device=dev), c=torch.zeros((S_, M), dtype=torch.int32, device=dev),
+                                 f=torch.zeros((S_, M), dtype=torch.float32, device=dev), n=torch.zeros((S_,), dtype=torch.int32, device=dev)) for _ in range(2)]
+            self.det_host = [dict(b=torch.zeros((S_, M, 4), dtype=torch.float64).pin_memory(), n=torch.zeros((S_,), dtype=torch.int32).pin_memory()) for _ in range(2)]
             self.det_ev = [[torch.cuda.Event() for _ in range(self.n_det)] for _ in range(2)]
         self.cloud = name == "tum-mask"          # PointCloudMapping::generatePointCloud on every frame: the consumer of the semantic mask
         if self.cloud:
@@ -429,6 +431,7 @@ class Workload:
         self.max_resident = self.T if self.strong else 48     # time steps generated and parked in HBM; longer runs walk them back and forth
         self.t = 0
         self.n_boxes_seen = []
+        self.max_det_boxes = 0
 
     def prepare(self, n_steps):
         """Generate `n_steps` more time steps and park them in HBM (distinct sequences on the host, replicated to the lanes on the device)."""
@@ -444,7 +447,7 @@ class Workload:
             dep = None
             if self.kind == "rgbd":
                 dep = torch.from_numpy(np.stack([p["depth"] for p in per]).view(np.int16)).to(self.dev).repeat((reps, 1, 1))[:S].contiguous()
-            bx = np.zeros((S, 32, 4), np.float64); nb = np.full(S, -1, np.int32)
+            bx = np.zeros((S, self.fe.MAXB, 4), np.float64); nb = np.full(S, -1, np.int32)
             if self.with_boxes and not self.detector:
                 for l in range(S):
                     b = per[l % D]["boxes"]; nb[l] = len(b); bx[l, :len(b)] = b
@@ -478,7 +481,8 @@ class Workload:
             nb_all = self.det_host[k]["n"].numpy()
             if (nb_all < 0).any():
                 raise RuntimeError("detector post-processing on the device exceeded its capacity")
-            n_boxes = np.minimum(nb_all, 16).astype(np.int32)          # boxTrack may re-inject as many again: keep within SD_MAX_BOXES
+            n_boxes = nb_all.astype(np.int32)      # every box the detector kept goes on, as `SLAM.TrackStereo(imLeft, imRight, boxes, t)` does (stereo_kitti.cc:107-122);
+            self.max_det_boxes = max(self.max_det_boxes, int(nb_all.max()))      # an overflow of the box tables is SD_ERR_CAPACITY, never a cut
             boxes = self.det_host[k]["b"].numpy().copy()
             if self.lookahead and self.t + 1 < self.n_total:     # the next frame's detector pass is queued behind this one's download
                 self.enqueue_detector(self.t + 1)
@@ -583,6 +587,7 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline):
         R = res[0]
         out = {"workload": name, "value": round(value, 2), "ms_per_step": round(elapsed / steps * 1e3, 4), "steps": steps, "frames": frames,
                "timed_s": round(elapsed, 3), "lanes_per_gpu": wl.S, "images_per_frame": wl.ipl,
+               "frames_truncated": 0, "max_detector_boxes_in_a_frame": wl.max_det_boxes if wl.det is not None else None,
                "lane0_last_frame": {"N": R.N, "N_s": R.N_s, "N_d": R.N_d, "n_boxes": R.n_boxes, "track_flag": R.track_flag, "separate_ret": R.separate_ret,
                                     "n_track_matches": R.n_track_matches, "n_last_matches": R.n_last_matches}}
         if gatherer is not None:               # rank 0 decodes a record it received from the LAST rank: the gather carries usable data

@@ -84,6 +84,11 @@ int sd_batch_extract_device(sd_batch* b, const uint8_t* d_gray, size_t stride, s
  * sd_cvt_gray_device followed by sd_batch_extract_device.  `stride` in bytes (>= 3 * width). */
 int sd_batch_extract_color_device(sd_batch* b, const uint8_t* d_src, size_t stride, size_t image_pitch, int rgb_order, int n_images,
                                   void* stream);
+/* The same for any input Tracking::GrabImage* accepts (src/Tracking.cc:175-200, 187-200: `if(mImGray.channels()==3) ... else
+ * if(mImGray.channels()==4)` with CV_RGB2GRAY / CV_BGR2GRAY / CV_RGBA2GRAY / CV_BGRA2GRAY): channels = 1 (gray, copied), 3, or 4 (the
+ * alpha byte is ignored, same weights).  `stride` in bytes (>= channels * width). */
+int sd_batch_extract_pixels_device(sd_batch* b, const uint8_t* d_src, size_t stride, size_t image_pitch, int channels, int rgb_order,
+                                   int n_images, void* stream);
 /* Same, from host memory (upload + extract + stream sync).  Empty image (NULL / 0 size) => 0 keypoints,
  * as ORBextractor.cc:1046-1047. */
 int sd_batch_extract_host(sd_batch* b, const uint8_t* gray, size_t stride, size_t image_pitch, int n_images);
@@ -119,6 +124,10 @@ int sd_batch_rgbd_from_u16(sd_batch* b, const uint16_t* d_depth, size_t stride_e
                            int n_images, float depth_factor, float mbf, void* stream);
 int sd_batch_rgbd_from_f32(sd_batch* b, const float* d_depth, size_t stride_elems, size_t image_pitch_elems,
                            int n_images, float mbf, void* stream);
+/* CV_32F depth that still has to be scaled: `if((fabs(mDepthMapFactor-1.0f)>1e-5) || imDepth.type()!=CV_32F) imDepth.convertTo(imDepth,
+ * CV_32F, mDepthMapFactor)` (Tracking.cc:271-272) for a CV_32F input and a factor other than 1: d = depth * depth_factor in f32. */
+int sd_batch_rgbd_from_f32_scaled(sd_batch* b, const float* d_depth, size_t stride_elems, size_t image_pitch_elems, int n_images,
+                                  float depth_factor, float mbf, void* stream);
 int sd_batch_download_rgbd(sd_batch* b, int image, float* uright, float* depth, int cap);
 
 
@@ -261,7 +270,10 @@ int sd_batch_matches_device(sd_batch* b, int32_t** d_match, int32_t** d_pairs, i
 int sd_batch_download_matches(sd_batch* b, int pair, int32_t* match, int32_t* pairs, int cap, int* npairs, int* nmatches);
 
 /* ---- dynamic-object handling (src/Frame.cc:481-641, src/Tracking.cc:1093-1367) ---- */
-#define SD_MAX_BOXES 32
+/* Capacity of every per-frame box table of this ABI (the reference's vector<cv::Rect2d> is unbounded, include/Frame.h:55-68): a frame
+ * may bring up to SD_MAX_BOXES detector boxes, and objects (the boxes after Frame::boxTrack's re-injection of unmatched last-frame boxes)
+ * must fit the same table -- SD_ERR_CAPACITY says so explicitly when it does not; nothing is ever truncated. */
+#define SD_MAX_BOXES 64
 /* Frame::boxTrack(boxes, last_frame) (src/Frame.cc:481-552), host code (f64, a handful of boxes).  boxes: [cap][4]
  * (x, y, width, height) in/out — unmatched last-frame boxes are re-injected once, so *n_out may exceed n_box.
  * Outputs box_idx / omit / velocity ([cap], [cap], [cap][2]) are the frame's members of the same names. */
@@ -298,13 +310,13 @@ int sd_batch_download_dynamic(sd_batch* b, int slot, sd_keypoint* kp, uint8_t* d
 /* Tracking::Separate(HorF, flag, dynStatus) (src/Tracking.cc:1093-1239) for n_pairs (current, reference) slots:
  * per box with the same id in both frames cv::BFMatcher(NORM_HAMMING, crossCheck).match, the <3 / <20 % skip,
  * classifyH (flag 1, :1241-1309) or classifyF (flag 2, :1311-1367) with H/F row-major 3x3 f32, the static /
- * dynamic box decision and box_status update against mLastFrame's (last_box_idx / last_box_status, [n_pairs][32]).
+ * dynamic box decision and box_status update against mLastFrame's (last_box_idx / last_box_status, [n_pairs][SD_MAX_BOXES]).
  * HorF == flag == NULL: pair p takes both from pair p of the preceding sd_batch_estimate_motion without leaving the
  * device; a pair whose TrackHomo flag is 0 is skipped as Tracking::Track_new does (ret 0, nothing classified). */
 int sd_batch_separate(sd_batch* b, int n_pairs, const int32_t* cur_index, const int32_t* ref_index, const float* HorF,
                       const int32_t* flag, const int32_t* last_box_idx, const int32_t* last_box_status,
                       const int32_t* n_last, void* stream);
-/* ret = Separate's return value; dyn_start[33] / dyn_status = dynStatus as CSR over the current frame's boxes
+/* ret = Separate's return value; dyn_start[SD_MAX_BOXES + 1] / dyn_status = dynStatus as CSR over the current frame's boxes
  * (entries: index into the box list or -1); matches = (queryIdx, trainIdx) per entry. */
 int sd_batch_download_separate(sd_batch* b, int pair, int32_t* ret, int32_t* dyn_start, int32_t* dyn_status, int32_t* matches,
                                int cap);
@@ -351,17 +363,24 @@ typedef struct sd_tracker sd_tracker;
 typedef struct sd_tracker_params {
     int32_t sensor;         /* SD_SENSOR_* */
     int32_t width, height;
-    int32_t channels;       /* input images: 1 = 8-bit gray, 3 = 8-bit BGR / RGB (cvtColor fused into the level-0 copy) */
+    int32_t channels;       /* input images: 1 = 8-bit gray, 3 = 8-bit BGR / RGB, 4 = BGRA / RGBA (cvtColor fused into the level-0 copy;
+                             * Tracking.cc:175-200) */
     int32_t rgb_order;      /* Camera.RGB (Tracking.cc:107-112) */
     int32_t n_lanes;        /* independent camera streams */
     int32_t track_last;     /* != 0: also match against mLastFrame */
-    int32_t reserved;
+    int32_t depth_type;     /* RGB-D: element type of the depth image, SD_DEPTH_U16 (CV_16U) or SD_DEPTH_F32 (CV_32F: passed through when
+                             * DepthMapFactor is 1, scaled in f32 otherwise -- Tracking.cc:271-272) */
     sd_camera cam;          /* Camera.fx .. Camera.bf and the image bounds */
     float dist[5];          /* Camera.k1, k2, p1, p2, k3 (k1 == 0: mvKeysUn == mvKeys, as Frame.cc:814-818) */
     float fps;              /* Camera.fps = mMaxFrames (Tracking.cc:93-98) */
     float depth_map_factor; /* DepthMapFactor (Tracking.cc:141-146); RGB-D only */
     float th_depth;         /* ThDepth (kept for the caller; not used on this path) */
+    int32_t ini_features;   /* monocular: nFeatures of mpIniORBextractor (Tracking.cc:127-128: 2 * nFeatures), used while a lane is not
+                             * initialised (Tracking.cc:335-338); 0 = one extractor for every frame */
+    int32_t reserved2;
 } sd_tracker_params;
+#define SD_DEPTH_U16 0
+#define SD_DEPTH_F32 1
 typedef struct sd_lane_result {
     int32_t frame_id;       /* mnId within the lane (0, 1, ...) */
     int32_t cur_slot;       /* sd_batch slot of mCurrentFrame */
@@ -384,19 +403,34 @@ int sd_tracker_reset(sd_tracker* t);              /* Tracking::Reset (src/Tracki
 int sd_tracker_batch(sd_tracker* t, sd_batch** b); /* the workspace that holds the frames (owned by the tracker) */
 /* One frame of every lane.  d_images: image k (0 = left / the only one, 1 = right) of lane s starts at
  * d_images + (s * images_per_lane + k) * image_pitch, rows `stride` bytes apart, `channels` bytes per pixel.
- * d_depth (RGB-D): CV_16U depth image of lane s at d_depth + s * depth_pitch_elems.  boxes [n_lanes][SD_MAX_BOXES][4]
+ * d_depth (RGB-D): depth image (CV_16U, or CV_32F when params.depth_type says so) of lane s at d_depth + s * depth_pitch_elems elements.  boxes [n_lanes][SD_MAX_BOXES][4]
  * (x, y, w, h) / n_boxes [n_lanes]: the detector's boxes of this frame; n_boxes[s] < 0 (or boxes == NULL) selects the
  * constructor without boxes for that lane.  timestamps [n_lanes].  Tcw / Twc (nullable, [n_lanes][16] row-major): pose
  * of the frame and its inverse.  results [n_lanes] (nullable).  The call returns after the results are on the host. */
-int sd_tracker_track(sd_tracker* t, const uint8_t* d_images, size_t stride, size_t image_pitch, const uint16_t* d_depth,
+int sd_tracker_track(sd_tracker* t, const uint8_t* d_images, size_t stride, size_t image_pitch, const void* d_depth,
                      size_t depth_stride_elems, size_t depth_pitch_elems, const double* boxes, const int32_t* n_boxes,
                      const double* timestamps, const float* Tcw, const float* Twc, sd_lane_result* results, void* stream);
 /* The same from host images (a per-frame caller such as System::TrackStereo): images[s * images_per_lane + k] points to image k
  * of lane s in host memory (rows `stride` bytes apart), depth[s] to lane s's CV_16U depth image (RGB-D).  Uploads, then
  * sd_tracker_track. */
-int sd_tracker_track_host(sd_tracker* t, const uint8_t* const* images, size_t stride, const uint16_t* const* depth,
+int sd_tracker_track_host(sd_tracker* t, const uint8_t* const* images, size_t stride, const void* const* depth,
                           size_t depth_stride_elems, const double* boxes, const int32_t* n_boxes, const double* timestamps,
                           const float* Tcw, const float* Twc, sd_lane_result* results);
+/* The SLAM state a caller with a live back end owns, handed over the boundary (all optional; without them the tracker runs in its
+ * sharded batch mode):
+ *  - the pose prior is the Tcw / Twc argument of sd_tracker_track: `mCurrentFrame.SetPose(mVelocity*mLastFrame.mTcw)` (Tracking.cc:982)
+ *    and the mRwc / mOw of Frame::UpdatePoseMatrices (Frame.cc:663-675);
+ *  - sd_tracker_set_mappoints: the MapPoints of the frame just tracked, as the back end left them (mCurrentFrame.mvpMapPoints after
+ *    TrackWithMotionModel / TrackLocalMap): xw [n_lanes][cap][3] = mvpMapPoints[i]->GetWorldPos(), flags [n_lanes][cap] (bit0: the point
+ *    exists and is not an outlier, bit1: Observations() > 0), n [n_lanes] = entries given for the lane (its N), < 0 = leave the lane's
+ *    own stereo points.  Call it after sd_tracker_track: it replaces the map-point table of the lane's mLastFrame, which is also the
+ *    newest q_frame entry (they are copies of the same frame, Tracking.cc:952-959), i.e. what TrackHomo's and TrackWithMotionModel's
+ *    SearchByProjection project in later frames (Tracking.cc:998-1010, ORBmatcher.cc:1485-1627).  The tracker never rewrites it;
+ *  - sd_tracker_set_state: [n_lanes] bit0 = the lane is initialised (mState != NOT_INITIALIZED / NO_IMAGES_YET: the monocular lane uses
+ *    mpORBextractorLeft instead of mpIniORBextractor, Tracking.cc:335-338), bit1 = `mState==OK && !mVelocity.empty()` (TrackHomo may
+ *    run, Tracking.cc:971).  NULL returns to the automatic rule (frame 0, 1 of a lane: neither; later: both). */
+int sd_tracker_set_mappoints(sd_tracker* t, const float* xw, const uint8_t* flags, const int32_t* n);
+int sd_tracker_set_state(sd_tracker* t, const int32_t* state);
 /* Batch copy of frame slots (Frame's copy constructor, src/Frame.cc:39-63) in one launch: slot src[i] -> dst[i]. */
 int sd_batch_copy_frames(sd_batch* b, int n, const int32_t* src, const int32_t* dst, void* stream);
 

@@ -1,5 +1,5 @@
 // HIP kernels of the dynamic-object cull (gfx950, wave64).  One workgroup per frame / frame pair: the
-// box sets are tiny (<= 32 boxes, tens to hundreds of keypoints each), the batch supplies the parallelism.
+// box sets are tiny (<= 64 boxes, tens to hundreds of keypoints each), the batch supplies the parallelism.
 //   k_box_separate   Frame::firstSeparate + ctor split      src/Frame.cc:555-604, 336-367
 //   k_separate       Tracking::Separate: BFMatcher(crossCheck) per box + classifyH / classifyF + box status
 //                                                            src/Tracking.cc:1093-1367
@@ -7,7 +7,7 @@
 #pragma once
 #include "k_frame.h"
 
-#define SD_MAXB 32          // boxes per frame the device tables hold
+#define SD_MAXB SD_MAX_BOXES // boxes per frame the device tables hold (64: box masks are one 64-bit word per key point)
 #define SD_BF_TCAP 2048     // train descriptors of one box staged in LDS
 
 struct SdFrameBoxes {       // per frame slot, lives in HBM
@@ -53,10 +53,11 @@ __device__ __forceinline__ int sd_block_scan256(int v, int* wsum, int& total)
 __global__ void __launch_bounds__(256) k_box_separate(SdCullPtrs A, const int* __restrict__ slots)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned* smask = (unsigned*)smem;              // [cap] box mask per keypoint (original order)
-    unsigned* dmask = smask + A.cap;                // [cap] box mask per dynamic keypoint (new order)
+    typedef unsigned long long bmask;               // bit j = the key point lies in box j (SD_MAXB <= 64)
+    bmask* smask = (bmask*)smem;                    // [cap] box mask per keypoint (original order)
+    bmask* dmask = smask + A.cap;                   // [cap] box mask per dynamic keypoint (new order); first the partition codes
     __shared__ int s_wsum[4];
-    __shared__ unsigned s_has;
+    __shared__ bmask s_has;
     __shared__ int s_nb2, s_empty, s_remap[SD_MAXB], s_kept[SD_MAXB], s_cnt[SD_MAXB], s_start[SD_MAXB + 1];
     __shared__ double s_box[SD_MAXB][4];
     const int slot = slots[blockIdx.x], tid = threadIdx.x;
@@ -72,13 +73,13 @@ __global__ void __launch_bounds__(256) k_box_separate(SdCullPtrs A, const int* _
     if (tid < nb) { s_box[tid][0] = F.boxes[tid][0]; s_box[tid][1] = F.boxes[tid][1]; s_box[tid][2] = F.boxes[tid][2]; s_box[tid][3] = F.boxes[tid][3]; }
     __syncthreads();
     // ---- box membership (cv::Rect2d::contains on the f32 keypoint position widened to f64)
-    unsigned has = 0;
+    bmask has = 0;
     for (int i = tid; i < N; i += 256) {
         const double px = (double)A.kp[base + i].x, py = (double)A.kp[base + i].y;
-        unsigned m = 0;
+        bmask m = 0;
         for (int j = 0; j < nb; j++) {
             const double x = s_box[j][0], y = s_box[j][1];
-            if (x <= px && px < x + s_box[j][2] && y <= py && py < y + s_box[j][3]) m |= 1u << j;
+            if (x <= px && px < x + s_box[j][2] && y <= py && py < y + s_box[j][3]) m |= 1ull << j;
         }
         smask[i] = m;
         has |= m;
@@ -91,7 +92,7 @@ __global__ void __launch_bounds__(256) k_box_separate(SdCullPtrs A, const int* _
         for (int j = 0; j < nb; j++) kept[j] = j;
         int empty = 0;
         for (int i = 0; i < n2; i++) {
-            if ((s_has >> i) & 1u) continue;
+            if ((s_has >> i) & 1ull) continue;
             for (int k = i; k + 1 < n2; k++) kept[k] = kept[k + 1];
             n2--;
             empty = 1;
@@ -100,7 +101,7 @@ __global__ void __launch_bounds__(256) k_box_separate(SdCullPtrs A, const int* _
         for (int j = 0; j < n2; j++) s_kept[j] = kept[j];
         int nfalse = 0;
         for (int j = 0; j < nb; j++) {
-            if (!((s_has >> j) & 1u)) nfalse++;
+            if (!((s_has >> j) & 1ull)) nfalse++;
             s_remap[j] = empty ? j - nfalse : j;      // index -= count(hasKpts[0..j] == false)
         }
     }
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(256) k_box_separate(SdCullPtrs A, const int* _
             if (i < N) {
                 const int sBefore = carry + ex;                 // static keypoints before i
                 // destination is final only once N_s is known: remember the static rank (or -(dynamic rank) - 1)
-                dmask[i] = isStatic ? (unsigned)sBefore : (unsigned)(0x80000000u | (unsigned)(i - sBefore));
+                dmask[i] = isStatic ? (bmask)(unsigned)sBefore : (bmask)(0x80000000u | (unsigned)(i - sBefore));
             }
             carry += tot;
             __syncthreads();
@@ -127,7 +128,7 @@ __global__ void __launch_bounds__(256) k_box_separate(SdCullPtrs A, const int* _
     const int Ns = nStaticTotal, Nd = N - Ns;
     // static keypoints -> staging rows (then back, compacted); dynamic ones -> the frame's dynamic arrays
     for (int i = tid; i < N; i += 256) {
-        const unsigned code = dmask[i];
+        const unsigned code = (unsigned)dmask[i];
         const bool dynk = (code & 0x80000000u) != 0;
         const int dst = (int)(code & 0x7FFFFFFFu);
         sd_keypoint k = A.kp[base + i];
@@ -149,12 +150,12 @@ __global__ void __launch_bounds__(256) k_box_separate(SdCullPtrs A, const int* _
     }
     __syncthreads();
     // masks of the dynamic keypoints in their new order (reuse smask after everyone has read it)
-    unsigned myMask[8];
+    bmask myMask[8];
     int myDst[8];
     {
         int k = 0;
         for (int i = tid; i < N && k < 8; i += 256, k++) {
-            const unsigned code = dmask[i];
+            const unsigned code = (unsigned)dmask[i];
             myMask[k] = smask[i];
             myDst[k] = (code & 0x80000000u) ? (int)(code & 0x7FFFFFFFu) : -1;
         }
@@ -180,8 +181,8 @@ __global__ void __launch_bounds__(256) k_box_separate(SdCullPtrs A, const int* _
     const int nb2 = s_nb2;
     if (tid < SD_MAXB) {
         int c = 0;
-        if (tid < nb && ((s_has >> tid) & 1u))
-            for (int i = 0; i < Nd; i++) c += (dmask[i] >> tid) & 1u;
+        if (tid < nb && ((s_has >> tid) & 1ull))
+            for (int i = 0; i < Nd; i++) c += (int)((dmask[i] >> tid) & 1ull);
         s_cnt[tid] = c;
     }
     __syncthreads();
@@ -189,18 +190,18 @@ __global__ void __launch_bounds__(256) k_box_separate(SdCullPtrs A, const int* _
         int cntNew[SD_MAXB];
         for (int b = 0; b < SD_MAXB; b++) cntNew[b] = 0;
         for (int j = 0; j < nb; j++)
-            if (((s_has >> j) & 1u) && s_remap[j] >= 0 && s_remap[j] < nb2) cntNew[s_remap[j]] = s_cnt[j];
+            if (((s_has >> j) & 1ull) && s_remap[j] >= 0 && s_remap[j] < nb2) cntNew[s_remap[j]] = s_cnt[j];
         int pos = 0;
         for (int b = 0; b < nb2; b++) { s_start[b] = pos; pos += cntNew[b]; }
         s_start[nb2] = pos;
         if (pos > A.itemsCap) atomicOr(A.errFlag, 16);
     }
     __syncthreads();
-    if (tid < nb && ((s_has >> tid) & 1u) && s_remap[tid] >= 0 && s_remap[tid] < nb2) {
+    if (tid < nb && ((s_has >> tid) & 1ull) && s_remap[tid] >= 0 && s_remap[tid] < nb2) {
         int* items = A.boxItems + (size_t)slot * A.itemsCap;
         int pos = s_start[s_remap[tid]];
         for (int i = 0; i < Nd; i++)
-            if ((dmask[i] >> tid) & 1u) { if (pos < A.itemsCap) items[pos] = i; pos++; }   // index into the dynamic arrays
+            if ((dmask[i] >> tid) & 1ull) { if (pos < A.itemsCap) items[pos] = i; pos++; }   // index into the dynamic arrays
     }
     __syncthreads();
     // ---- frame record: objects = boxes after the erase; N = N_s

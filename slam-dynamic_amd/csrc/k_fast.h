@@ -440,9 +440,42 @@ __global__ void __launch_bounds__(256) k_pyr_level0_rgb(const uint8_t* __restric
     *(sd_u4v*)(drow + SD_XOFF + X0) = o;
 }
 
+// 4-channel input (CV_RGBA2GRAY / CV_BGRA2GRAY, Tracking.cc:187-200): 16 pixels = four aligned-or-not 16-byte loads, pixel k = word k,
+// bytes 0..2 weighted as above, the alpha byte ignored.
+__device__ __forceinline__ uint32_t sd_gray4x4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, int cr, int cb)
+{
+    const uint32_t p0 = (__umul24(a & 255, cr) + __umul24((a >> 8) & 255, 9617) + __umul24((a >> 16) & 255, cb) + 8192) >> 14;
+    const uint32_t p1 = (__umul24(b & 255, cr) + __umul24((b >> 8) & 255, 9617) + __umul24((b >> 16) & 255, cb) + 8192) >> 14;
+    const uint32_t p2 = (__umul24(c & 255, cr) + __umul24((c >> 8) & 255, 9617) + __umul24((c >> 16) & 255, cb) + 8192) >> 14;
+    const uint32_t p3 = (__umul24(d & 255, cr) + __umul24((d >> 8) & 255, 9617) + __umul24((d >> 16) & 255, cb) + 8192) >> 14;
+    return p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
+}
+__global__ void __launch_bounds__(256) k_pyr_level0_rgba(const uint8_t* __restrict__ src, size_t sstride, size_t spitch, int rgbOrder,
+                                                         uint8_t* __restrict__ pyr, const SdDevPlan* __restrict__ PP, int groupsPerRow,
+                                                         uint32_t gprInv)
+{
+    const SdDevPlan& P = *PP;
+    const SdLevel& g = P.lv[0];
+    const int img = blockIdx.y;
+    const uint32_t item = blockIdx.x * 256u + threadIdx.x;
+    const int Yp = (int)__umulhi(item, gprInv);            // item / groupsPerRow
+    if (Yp >= g.H + 2 * SD_EDGE) return;
+    const int X0 = 16 * (int)(item - (uint32_t)Yp * (uint32_t)groupsPerRow);
+    const int sy = sd_reflect101(Yp - SD_EDGE, g.H);
+    const uint8_t* srow = src + (size_t)img * spitch + (size_t)sy * sstride;
+    const int cr = rgbOrder ? 4899 : 1868, cb = rgbOrder ? 1868 : 4899;
+    const sd_u128_unaligned* s = (const sd_u128_unaligned*)(srow + 4 * X0);
+    const sd_u4v a = s[0], b = s[1], c = s[2], d = s[3];
+    sd_u4v o;
+    o.x = sd_gray4x4(a.x, a.y, a.z, a.w, cr, cb); o.y = sd_gray4x4(b.x, b.y, b.z, b.w, cr, cb);
+    o.z = sd_gray4x4(c.x, c.y, c.z, c.w, cr, cb); o.w = sd_gray4x4(d.x, d.y, d.z, d.w, cr, cb);
+    uint8_t* drow = pyr + (size_t)img * P.pyrImageBytes + g.pyrOffset + (size_t)Yp * g.stride;
+    *(sd_u4v*)(drow + SD_XOFF + X0) = o;
+}
+
 __global__ void __launch_bounds__(256) k_pyr_level0_rgb_frame(const uint8_t* __restrict__ src, size_t sstride, size_t spitch, int rgbOrder,
                                                               uint8_t* __restrict__ pyr, const SdDevPlan* __restrict__ PP, int groupsPerRow,
-                                                              int tailGroups)
+                                                              int tailGroups, int bpp)
 {
     const SdDevPlan& P = *PP;
     const SdLevel& g = P.lv[0];
@@ -460,7 +493,7 @@ __global__ void __launch_bounds__(256) k_pyr_level0_rgb_frame(const uint8_t* __r
     for (int k = 0; k < 16; k++) {
         int X = X0 + k;
         X = X < -SD_EDGE ? -SD_EDGE : (X > g.W + SD_EDGE - 1 ? g.W + SD_EDGE - 1 : X);     // margin bytes: any value
-        const uint8_t* p = srow + 3 * sd_reflect101(X, g.W);
+        const uint8_t* p = srow + bpp * sd_reflect101(X, g.W);
         const uint32_t v = (__umul24((uint32_t)p[0], (uint32_t)cr) + __umul24((uint32_t)p[1], 9617u) + __umul24((uint32_t)p[2], (uint32_t)cb) + 8192u) >> 14;
         w[k >> 2] |= v << (8 * (k & 3));
     }

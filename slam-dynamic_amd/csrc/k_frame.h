@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(256) k_rgbd(const sd_keypoint* __restrict__ kp
     const float v = k.y, u = k.x;
     const T raw = depth[(size_t)img * pitchE + (size_t)(int)v * strideE + (int)u];
     float d;
-    if (sizeof(T) == 2) d = (float)raw * factor; else d = (float)raw;
+    d = (float)raw * factor;        // convertTo(CV_32F, factor) in f32 for CV_16U and CV_32F alike; factor 1 (CV_32F passed through, Tracking.cc:271-272) is exact
     float ur = -1.f, dd = -1.f;
     if (d > 0) { dd = d; ur = kpUn[(size_t)img * P.kpCap + i].x - mbf / d; }      // kpU.pt.x - mbf / d (Frame.cc:1069); the lookup above is at the DISTORTED position
     uRight[(size_t)img * P.kpCap + i] = ur;

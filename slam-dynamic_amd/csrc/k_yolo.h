@@ -761,7 +761,7 @@ __global__ void __launch_bounds__(256) k_region_decode(const T* __restrict__ hea
 // boxes = (int)(centre * frame dims) etc. as the reference truncates them, cv::dnn::NMSBoxes(conf, nms) = stable sort by
 // score (descending; equal scores keep cv::dnn's row order) + greedy keep while the overlap with every kept box is
 // <= nms (1 - jaccardDistance on cv::Rect, f64), the class filter {person, bicycle, car, bus, truck} ("motorcycle" never
-// matches coco.names' "motorbike") and rectCenterScale(box, (-0.2 w, 0.6 h)).  Output: up to 32 boxes per image as
+// matches coco.names' "motorbike") and rectCenterScale(box, (-0.2 w, 0.6 h)).  Output: up to SD_MAX_BOXES boxes per image as
 // cv::Rect2d (x, y, w, h f64) in kept order, nOut[image] (or -1 - count when a capacity was exceeded).
 #define SD_NMS_MAXDET 4096      // rows above the confidence threshold per image handled on the device
 #define SD_NMS_MAXKEEP 512      // boxes NMS may keep before the class filter
@@ -852,11 +852,11 @@ __global__ void __launch_bounds__(256) k_yolo_nms(const SdDet* __restrict__ dets
             const SdDet d = D[(int)(keys[t] & 0x1FFFu)];
             const int c = d.cls;
             if (!(c == 0 || c == 1 || c == 2 || c == 5 || c == 7)) continue;
-            if (n >= 32) { n = -1 - nk; break; }
+            if (n >= SD_MAX_BOXES) { n = -1 - nk; break; }
             const double sw = -0.2 * (double)s_w[t], sh = 0.6 * (double)s_h[t];
-            double* o = boxesOut + ((size_t)img * 32 + n) * 4;
+            double* o = boxesOut + ((size_t)img * SD_MAX_BOXES + n) * 4;
             o[0] = (double)s_x[t] - sw / 2.0; o[1] = (double)s_y[t] - sh / 2.0; o[2] = (double)s_w[t] + sw; o[3] = (double)s_h[t] + sh;
-            clsOut[img * 32 + n] = c; confOut[img * 32 + n] = d.conf;
+            clsOut[img * SD_MAX_BOXES + n] = c; confOut[img * SD_MAX_BOXES + n] = d.conf;
             n++;
         }
         nOut[img] = n;
@@ -867,7 +867,7 @@ __global__ void __launch_bounds__(256) k_yolo_nms(const SdDet* __restrict__ dets
 // (postprocess, yolo.cc:128-131), dilate with cv::getStructuringElement(MORPH_ELLIPSE, 31x31) and return
 // 1 - dilated.  One 16x16 pixel tile per workgroup; the rasterised mask of the tile + 15-px halo lives in LDS;
 // span[dy] = half-width of the ellipse row (dx such that columns c-dx .. c+dx are set).
-struct SdMaskRects { int n; int x0[32], y0[32], x1[32], y1[32]; };   // filled region [x0,x1) x [y0,y1)
+struct SdMaskRects { int n; int x0[SD_MAX_BOXES], y0[SD_MAX_BOXES], x1[SD_MAX_BOXES], y1[SD_MAX_BOXES]; };   // filled region [x0,x1) x [y0,y1)
 __global__ void __launch_bounds__(256) k_mask_dilate(SdMaskRects R, int cols, int rows, uint8_t* __restrict__ mask, size_t stride)
 {
     __shared__ uint8_t t[46][48];

@@ -238,7 +238,11 @@ static void batch_free(sd_batch* b)
     delete b;
 }
 
-int sd_batch_create(sd_batch** out, sd_extractor* ex, int width, int height, int max_images)
+static int batch_create_impl(sd_batch** out, sd_extractor* ex, int width, int height, int max_images, int minKpCap);
+int sd_batch_create(sd_batch** out, sd_extractor* ex, int width, int height, int max_images) { return batch_create_impl(out, ex, width, height, max_images, 0); }
+
+// minKpCap: row stride of the per-image result arrays at least this (a tracker whose lanes switch between two extractors)
+static int batch_create_impl(sd_batch** out, sd_extractor* ex, int width, int height, int max_images, int minKpCap)
 {
     if (!out) return SD_ERR_INVALID;
     *out = nullptr;
@@ -249,7 +253,7 @@ int sd_batch_create(sd_batch** out, sd_extractor* ex, int width, int height, int
     sd_batch* b = new sd_batch();
     b->ex = ex;
     b->maxImages = max_images;
-    if (!sd_plan_build(b->plan, ex->prm, width, height)) {
+    if (!sd_plan_build(b->plan, ex->prm, width, height, minKpCap)) {
         std::string e = b->plan.error;
         delete b;
         return set_err(SD_ERR_UNSUPPORTED, e);
@@ -448,7 +452,14 @@ int sd_batch_extract_color_device(sd_batch* b, const uint8_t* d_src, size_t stri
     return extract_impl(b, d_src, stride, image_pitch, n_images, stream_, rgb_order ? 2 : 1);
 }
 
-// colorMode 0: 8-bit gray input; 1 / 2: 3-channel BGR / RGB input converted on the way into level 0
+int sd_batch_extract_pixels_device(sd_batch* b, const uint8_t* d_src, size_t stride, size_t image_pitch, int channels, int rgb_order,
+                                   int n_images, void* stream_)
+{
+    if (channels != 1 && channels != 3 && channels != 4) return set_err(SD_ERR_INVALID, "images must have 1, 3 or 4 channels (Tracking.cc:175-200)");
+    return extract_impl(b, d_src, stride, image_pitch, n_images, stream_, channels == 1 ? 0 : (channels == 3 ? 1 : 3) + (rgb_order ? 1 : 0));
+}
+
+// colorMode 0: 8-bit gray input; 1 / 2: 3-channel BGR / RGB, 3 / 4: 4-channel BGRA / RGBA input converted on the way into level 0
 static int extract_impl(sd_batch* b, const uint8_t* d_gray, size_t stride, size_t image_pitch, int n_images, void* stream_, int colorMode)
 {
     if (!b || n_images < 0 || n_images > b->maxImages) return set_err(SD_ERR_INVALID, "bad extract arguments");
@@ -459,7 +470,8 @@ static int extract_impl(sd_batch* b, const uint8_t* d_gray, size_t stride, size_
     if (n_images == 0) return SD_OK;
     if (!d_gray) return set_err(SD_ERR_INVALID, "null image pointer");
     const SdPlan& P = b->plan;
-    if (stride < (size_t)P.W * (colorMode ? 3 : 1)) return set_err(SD_ERR_INVALID, "stride smaller than width");
+    const int bpp = colorMode == 0 ? 1 : (colorMode <= 2 ? 3 : 4), rgbOrder = (colorMode == 2 || colorMode == 4) ? 1 : 0;
+    if (stride < (size_t)P.W * bpp) return set_err(SD_ERR_INVALID, "stride smaller than width");
     const int nl = P.nlevels;
     {
         ProfScope ps(b, s, K_PYR0);
@@ -472,10 +484,11 @@ static int extract_impl(sd_batch* b, const uint8_t* d_gray, size_t stride, size_
             const dim3 gi((unsigned)((size_t)rows * gpr + 255) / 256, n_images), gf((unsigned)(rows * (2 + tail) + 255) / 256, n_images);
             if (gpr > 0) {
                 const uint32_t gprInv = 0xFFFFFFFFu / (uint32_t)gpr + 1u;
-                if (colorMode) hipLaunchKernelGGL(k_pyr_level0_rgb, gi, dim3(256), 0, s, d_gray, stride, image_pitch, colorMode == 2 ? 1 : 0, b->d_pyr, b->d_plan, gpr, gprInv);
+                if (bpp == 4) hipLaunchKernelGGL(k_pyr_level0_rgba, gi, dim3(256), 0, s, d_gray, stride, image_pitch, rgbOrder, b->d_pyr, b->d_plan, gpr, gprInv);
+                else if (bpp == 3) hipLaunchKernelGGL(k_pyr_level0_rgb, gi, dim3(256), 0, s, d_gray, stride, image_pitch, rgbOrder, b->d_pyr, b->d_plan, gpr, gprInv);
                 else hipLaunchKernelGGL(k_pyr_level0_gray, gi, dim3(256), 0, s, d_gray, stride, image_pitch, b->d_pyr, b->d_plan, gpr, gprInv);
             }
-            if (colorMode) hipLaunchKernelGGL(k_pyr_level0_rgb_frame, gf, dim3(256), 0, s, d_gray, stride, image_pitch, colorMode == 2 ? 1 : 0, b->d_pyr, b->d_plan, gpr, tail);
+            if (colorMode) hipLaunchKernelGGL(k_pyr_level0_rgb_frame, gf, dim3(256), 0, s, d_gray, stride, image_pitch, rgbOrder, b->d_pyr, b->d_plan, gpr, tail, bpp);
             else hipLaunchKernelGGL(k_pyr_level0_gray_frame, gf, dim3(256), 0, s, d_gray, stride, image_pitch, b->d_pyr, b->d_plan, gpr, tail);
         }
     }
@@ -802,6 +815,12 @@ int sd_batch_rgbd_from_u16(sd_batch* b, const uint16_t* d_depth, size_t stride_e
 int sd_batch_rgbd_from_f32(sd_batch* b, const float* d_depth, size_t stride_elems, size_t image_pitch_elems, int n_images,
                            float mbf, void* stream_)
 {
+    return sd_batch_rgbd_from_f32_scaled(b, d_depth, stride_elems, image_pitch_elems, n_images, 1.0f, mbf, stream_);
+}
+
+int sd_batch_rgbd_from_f32_scaled(sd_batch* b, const float* d_depth, size_t stride_elems, size_t image_pitch_elems, int n_images,
+                                  float depth_factor, float mbf, void* stream_)
+{
     if (!b || !d_depth || n_images < 0) return SD_ERR_INVALID;
     if (n_images > b->nExtracted) return set_err(SD_ERR_STATE, "rgbd lookup needs extracted images");
     hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
@@ -811,7 +830,7 @@ int sd_batch_rgbd_from_f32(sd_batch* b, const float* d_depth, size_t stride_elem
         ProfScope ps(b, s, K_RGBD);
         dim3 grd((b->plan.kpCap + 255) / 256, n_images);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rgbd<float>), grd, dim3(256), 0, s, b->d_kp, KPUN(b), b->d_count, d_depth, stride_elems,
-                           image_pitch_elems, 1.0f, mbf, b->d_uright, b->d_depth, b->d_plan);
+                           image_pitch_elems, depth_factor, mbf, b->d_uright, b->d_depth, b->d_plan);
     }
     LAUNCH_CHECK("k_rgbd");
     return SD_OK;
@@ -1726,7 +1745,7 @@ int sd_batch_first_separate(sd_batch* b, int n_frames, const int32_t* slots, con
     h.resize(n_frames);
     for (int f = 0; f < n_frames; f++) {
         if (!slot_ok(b, slots[f])) return set_err(SD_ERR_STATE, "first_separate: slot holds no results");
-        if (n_boxes[f] < 0 || n_boxes[f] > SD_MAXB) return set_err(SD_ERR_CAPACITY, "more than 32 boxes in a frame");
+        if (n_boxes[f] < 0 || n_boxes[f] > SD_MAXB) return set_err(SD_ERR_CAPACITY, "more than SD_MAX_BOXES boxes in a frame");
         memset(&h[f], 0, sizeof(SdFrameBoxes));
         h[f].nb = n_boxes[f];
         for (int j = 0; j < n_boxes[f]; j++) {
@@ -1740,7 +1759,7 @@ int sd_batch_first_separate(sd_batch* b, int n_frames, const int32_t* slots, con
     HIPCHK(hipMemcpyAsync(b->d_slots, slots, (size_t)n_frames * 4, hipMemcpyHostToDevice, s));
     {
         ProfScope ps(b, s, K_BOXSEP);
-        const size_t lds = (size_t)b->plan.kpCap * 8 + 64;
+        const size_t lds = (size_t)b->plan.kpCap * 16 + 64;      // two 64-bit box masks per key point
         hipLaunchKernelGGL(k_box_separate, dim3(n_frames), dim3(256), lds, s, cull_ptrs(b), b->d_slots);
     }
     LAUNCH_CHECK("k_box_separate");

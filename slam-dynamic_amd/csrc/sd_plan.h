@@ -109,7 +109,7 @@ struct SdPlan {
 static inline int sd_align(int v, int a) { return (v + a - 1) / a * a; }
 
 // Returns false (plan.error set) when the geometry is outside what the kernels support.
-static inline bool sd_plan_build(SdPlan& P, const SdParams& prm, int W, int H)
+static inline bool sd_plan_build(SdPlan& P, const SdParams& prm, int W, int H, int minKpCap = 0)
 {
     P = SdPlan();
     P.W = W; P.H = H; P.nlevels = prm.nlevels;
@@ -219,7 +219,7 @@ static inline bool sd_plan_build(SdPlan& P, const SdParams& prm, int W, int H)
     P.cellListCap = listOff;
     P.candCapTotal = listOff;
     P.kpCapLevels = kpOff;
-    P.kpCap = kpOff;
+    P.kpCap = kpOff > minKpCap ? kpOff : sd_align(minKpCap, 8);      // row stride of the per-image result arrays (a tracker with a second, larger extractor shares slots)
     if (P.tabs.empty()) P.tabs.resize(4, 0);
     return true;
 }

@@ -552,7 +552,7 @@ int sd_yolo_mask_device(sd_yolo* y, int image, int frame_cols, int frame_rows, f
     std::vector<SdDet> d; std::vector<YRect> rects; std::vector<int> kept;
     int rc = yolo_nms(y, image, frame_cols, frame_rows, conf_threshold, nms_threshold, d, rects, kept);
     if (rc != SD_OK) return rc;
-    if (kept.size() > 32) return set_err(SD_ERR_CAPACITY, "more than 32 kept boxes");
+    if (kept.size() > SD_MAX_BOXES) return set_err(SD_ERR_CAPACITY, "more than SD_MAX_BOXES kept boxes");
     if (no_target) *no_target = kept.empty();
     SdMaskRects R;
     R.n = (int)kept.size();
@@ -626,7 +626,7 @@ int sd_yolo_mask_host(sd_yolo* y, int frame_cols, int frame_rows, float conf_thr
 }
 
 // postprocess_ for the first n_images of the last forward pass, entirely on the device (k_yolo_nms): one launch, and
-// with the host form one download of n_images x (32 boxes + count) instead of a synchronisation per image.
+// with the host form one download of n_images x (SD_MAX_BOXES boxes + count) instead of a synchronisation per image.
 int sd_yolo_boxes_device(sd_yolo* y, int n_images, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold,
                          double* d_boxes, int32_t* d_class_ids, float* d_confidences, int32_t* d_n_boxes, void* stream_)
 {
@@ -647,22 +647,22 @@ int sd_yolo_boxes_batch(sd_yolo* y, int n_images, int frame_cols, int frame_rows
     if (!y || !boxes || !n_boxes || n_images < 0 || n_images > y->maxBatch) return set_err(SD_ERR_INVALID, "bad yolo_boxes_batch arguments");
     if (!y->d_nmsBoxes) {
         const size_t nB = (size_t)y->maxBatch;
-        HIPCHK(hipMalloc((void**)&y->d_nmsBoxes, nB * 32 * 4 * 8)); y->owned.push_back(y->d_nmsBoxes);
-        HIPCHK(hipMalloc((void**)&y->d_nmsCls, nB * 32 * 4)); y->owned.push_back(y->d_nmsCls);
-        HIPCHK(hipMalloc((void**)&y->d_nmsConf, nB * 32 * 4)); y->owned.push_back(y->d_nmsConf);
+        HIPCHK(hipMalloc((void**)&y->d_nmsBoxes, nB * SD_MAX_BOXES * 4 * 8)); y->owned.push_back(y->d_nmsBoxes);
+        HIPCHK(hipMalloc((void**)&y->d_nmsCls, nB * SD_MAX_BOXES * 4)); y->owned.push_back(y->d_nmsCls);
+        HIPCHK(hipMalloc((void**)&y->d_nmsConf, nB * SD_MAX_BOXES * 4)); y->owned.push_back(y->d_nmsConf);
         HIPCHK(hipMalloc((void**)&y->d_nmsN, nB * 4)); y->owned.push_back(y->d_nmsN);
     }
     int rc = sd_yolo_boxes_device(y, n_images, frame_cols, frame_rows, conf_threshold, nms_threshold, y->d_nmsBoxes, y->d_nmsCls, y->d_nmsConf,
                                   y->d_nmsN, stream_);
     if (rc != SD_OK || n_images == 0) return rc;
     hipStream_t s = stream_ ? (hipStream_t)stream_ : y->stream;
-    HIPCHK(hipMemcpyAsync(boxes, y->d_nmsBoxes, (size_t)n_images * 32 * 4 * 8, hipMemcpyDeviceToHost, s));
-    if (class_ids) HIPCHK(hipMemcpyAsync(class_ids, y->d_nmsCls, (size_t)n_images * 32 * 4, hipMemcpyDeviceToHost, s));
-    if (confidences) HIPCHK(hipMemcpyAsync(confidences, y->d_nmsConf, (size_t)n_images * 32 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(boxes, y->d_nmsBoxes, (size_t)n_images * SD_MAX_BOXES * 4 * 8, hipMemcpyDeviceToHost, s));
+    if (class_ids) HIPCHK(hipMemcpyAsync(class_ids, y->d_nmsCls, (size_t)n_images * SD_MAX_BOXES * 4, hipMemcpyDeviceToHost, s));
+    if (confidences) HIPCHK(hipMemcpyAsync(confidences, y->d_nmsConf, (size_t)n_images * SD_MAX_BOXES * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(n_boxes, y->d_nmsN, (size_t)n_images * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     for (int i = 0; i < n_images; i++)
-        if (n_boxes[i] < 0) return set_err(SD_ERR_CAPACITY, "postprocess on device: more than 4096 rows above the threshold or more than 32 kept boxes");
+        if (n_boxes[i] < 0) return set_err(SD_ERR_CAPACITY, "postprocess on device: more than 4096 rows above the threshold or more than SD_MAX_BOXES kept boxes");
     return SD_OK;
 }
 

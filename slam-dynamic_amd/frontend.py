@@ -474,8 +474,8 @@ class Batch:
         return out
 
 
+MAXB = 64             # SD_MAX_BOXES (include/sd_frontend.h)
 CLOUD_POINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("b", "u1"), ("g", "u1"), ("r", "u1"), ("a", "u1")])     # sd_cloud_point
-MAXB = 32
 SENSOR_MONOCULAR, SENSOR_STEREO, SENSOR_RGBD = 0, 1, 2
 
 
@@ -495,8 +495,8 @@ class LaneResult(C.Structure):
     _fields_ = [("frame_id", C.c_int32), ("cur_slot", C.c_int32), ("last_slot", C.c_int32), ("ref_slot", C.c_int32), ("ref_frame_id", C.c_int32),
                 ("track_flag", C.c_int32), ("separate_ret", C.c_int32), ("n_track_matches", C.c_int32), ("n_track_pairs", C.c_int32),
                 ("n_h", C.c_int32), ("n_f", C.c_int32), ("n_last_matches", C.c_int32), ("N", C.c_int32), ("N_s", C.c_int32), ("N_d", C.c_int32),
-                ("n_boxes", C.c_int32), ("box_idx", C.c_int32 * 32), ("box_status", C.c_int32 * 32), ("omit", C.c_uint8 * 32), ("pad_", C.c_uint8 * 4),
-                ("objects", (C.c_double * 4) * 32), ("box_velocity", (C.c_double * 2) * 32)]
+                ("n_boxes", C.c_int32), ("box_idx", C.c_int32 * MAXB), ("box_status", C.c_int32 * MAXB), ("omit", C.c_uint8 * MAXB), ("pad_", C.c_uint8 * 4),
+                ("objects", (C.c_double * 4) * MAXB), ("box_velocity", (C.c_double * 2) * MAXB)]
 
 
 class Tracker:
@@ -539,7 +539,7 @@ class Tracker:
 
     def track(self, d_images, stride, image_pitch, timestamps, boxes=None, n_boxes=None, d_depth=0, depth_stride=0, depth_pitch=0,
               Tcw=None, Twc=None, stream=None):
-        """boxes: (n_lanes, 32, 4) f64 with n_boxes (n_lanes,) int32 (-1 = the constructor without boxes), or a list of (k, 4) arrays / None per lane."""
+        """boxes: (n_lanes, MAXB, 4) f64 with n_boxes (n_lanes,) int32 (-1 = the constructor without boxes), or a list of (k, 4) arrays / None per lane."""
         S = self.n_lanes
         ts = np.ascontiguousarray(timestamps, np.float64).reshape(S)
         if boxes is not None and n_boxes is None:
@@ -651,7 +651,7 @@ def hamming_matrix_device(d_a, na, d_b, nb, d_out, stream=None):
                                          C.c_void_p(stream or 0)))
 
 
-FRAME_BOXES_BYTES = 16 + 32 * 32 + 3 * 32 * 4 + 33 * 4 + 4        # sizeof(sd_frame_boxes)
+FRAME_BOXES_BYTES = 16 + MAXB * 32 + 3 * MAXB * 4 + (MAXB + 1) * 4 + 4        # sizeof(sd_frame_boxes)
 
 
 def batch_boxes_device(batch):

@@ -177,7 +177,7 @@ private:
         double bx[SD_MAX_BOXES][4];
         int32_t nb = -1;
         if (boxes) {
-            if (boxes->size() > SD_MAX_BOXES) throw std::runtime_error("more than 32 boxes in a frame");
+            if (boxes->size() > SD_MAX_BOXES) throw std::runtime_error("more than SD_MAX_BOXES boxes in a frame");
             nb = (int32_t)boxes->size();
             for (int j = 0; j < nb; j++) { bx[j][0] = (*boxes)[j].x; bx[j][1] = (*boxes)[j].y; bx[j][2] = (*boxes)[j].width; bx[j][3] = (*boxes)[j].height; }
         }

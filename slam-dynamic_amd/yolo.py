@@ -211,14 +211,15 @@ class Detector:
 
     def boxes_batch(self, n_images, frame_cols, frame_rows, conf=0.5, nms=0.4, stream=None):
         """postprocess_ of every image of the last forward pass, NMS on the device, one download -> list of (boxes, cls, conf)."""
-        b = np.zeros((n_images, 32, 4), np.float64); cid = np.zeros((n_images, 32), np.int32); cf = np.zeros((n_images, 32), np.float32)
+        M = fe.MAXB
+        b = np.zeros((n_images, M, 4), np.float64); cid = np.zeros((n_images, M), np.int32); cf = np.zeros((n_images, M), np.float32)
         nb = np.zeros(n_images, np.int32)
         fe.check(fe.lib().sd_yolo_boxes_batch(self.h, n_images, frame_cols, frame_rows, C.c_float(conf), C.c_float(nms), fe._p(b), fe._p(cid),
                                               fe._p(cf), fe._p(nb), C.c_void_p(stream or 0)))
         return [(b[i, :nb[i]].copy(), cid[i, :nb[i]].copy(), cf[i, :nb[i]].copy()) for i in range(n_images)]
 
     def boxes_device(self, n_images, frame_cols, frame_rows, d_boxes, d_cls, d_conf, d_n, conf=0.5, nms=0.4, stream=None):
-        """The same post-processing into caller-owned DEVICE buffers ([n][32][4] f64, [n][32] i32, [n][32] f32, [n] i32), no synchronisation."""
+        """The same post-processing into caller-owned DEVICE buffers ([n][MAXB][4] f64, [n][MAXB] i32, [n][MAXB] f32, [n] i32; MAXB = SD_MAX_BOXES), no synchronisation."""
         L = fe.lib()
         L.sd_yolo_boxes_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         fe.check(L.sd_yolo_boxes_device(self.h, n_images, frame_cols, frame_rows, conf, nms, C.c_void_p(d_boxes), C.c_void_p(d_cls), C.c_void_p(d_conf),
