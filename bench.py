@@ -14,6 +14,9 @@ quoted on:
   stereo        the same without detector and boxes (Frame.cc:66-126)
   rgbd          BASELINE configs[1]: KITTI-03 RGB-D 1241x376, TrackRGBD(im, depth, t), no boxes / mask (Frame.cc:240-294)
   rgbd-cull     RGB-D 1241x376 with 3 given boxes per frame (rgbd_my.cc's yolov5 box files): the cull without a detector
+  rgbd-bow      rgbd + Frame::ComputeBoW (Frame.cc:803-810) of the current frame and of the frame 0.2 s back, then
+                ORBmatcher::SearchByBoW (ORBmatcher.cc:159-288) between the two: the timed consumer of the vocabulary that
+                rank 0 broadcasts over RCCL at start-up
   tum-mask      BASELINE configs[3]: TUM3 640x480 RGB-D, DepthMapFactor 5000, mask + boxes, cull + dense back-projection
                 of the unmasked pixels (pointcloudmapping.cc:59-103) -- the consumer of the semantic mask
   kitti-batch   BASELINE configs[4]: 11 sequences x 256 stereo frames with boxes, WHOLE sequences assigned to ranks
@@ -43,7 +46,7 @@ import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming)
 MFMA_PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3}   # dense peaks, MI355X_MICROARCH.md
-WORKLOADS = ["stereo-yolo", "stereo-yolo-f16", "stereo", "rgbd", "rgbd-cull", "tum-mask", "kitti-batch"]
+WORKLOADS = ["stereo-yolo", "stereo-yolo-f16", "stereo", "rgbd", "rgbd-cull", "rgbd-bow", "tum-mask", "kitti-batch"]
 
 
 # --------------------------------------------------------------------------- host logic (also used by CPU tests)
@@ -76,9 +79,45 @@ def algorithmic_bytes(width, height, inv_scale, n_features, channels=1):
         "k_orient": n_features * 749,
         "k_describe": n_features * 512 + n_features * 32,
     }
+    b["k_stereo_match"] = 2 * n_features * 32 + n_features * 11 * (11 + 21)      # per FRAME: both descriptor sets + the SAD windows
     b["image_total"] = (channels * width * height + sum(padded) + sum(interior[:-1]) + 3 * sum(interior) + n_features * 749 +
                         n_features * 512 + n_features * 60)
     return b
+
+
+KERNEL_SYMBOL = {"k_fast_cells": "k_fast_cells_staged", "k_blur": "k_blur_wide", "k_pyr_level": "k_pyr_level_tiles", "k_pyr_level0": "k_pyr_level0_rgb"}
+
+
+def load_pmc_traffic(workload):
+    """profiles/pmc_traffic.json: {workload: {kernel symbol: {hbm_bytes_per_launch, batch_images, profile}}} written by tools/summarize_prof.py
+    from the separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of THIS workload."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        return j.get(workload, {})
+    except Exception:
+        return {}
+
+
+def kernel_roofline_table(kt, prof_steps, alg, n_img, n_frames, pmc):
+    """Per-kernel {alg_bytes, ms, GB/s, frac, traffic} of the HBM-bound front-end kernels from the in-library hipEvent times (untimed pass).
+    One "launch" of k_pyr_level is the 7 dependent level launches of a step taken together."""
+    out = {}
+    for k, (ms, launches) in kt.items():
+        if launches <= 0 or alg.get(k, 0) <= 0:
+            continue
+        units = n_frames if k == "k_stereo_match" else n_img
+        ms_step = ms / prof_steps
+        per_step = alg[k] * units
+        gbs = per_step / (ms_step * 1e-3) / 1e9
+        e = pmc.get(k) or pmc.get(KERNEL_SYMBOL.get(k, k))
+        traffic, prof = None, None
+        if e and e.get("batch_images") == n_img:
+            traffic = int(e["hbm_bytes_per_launch"] * (launches / prof_steps if k == "k_pyr_level" else 1))
+            prof = e.get("profile")
+        out[k] = {"alg_bytes_per_step": int(per_step), "ms_per_step": round(ms_step, 4), "launches_per_step": round(launches / prof_steps, 2),
+                  "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic_bytes_per_step": traffic,
+                  "traffic_over_alg": round(traffic / per_step, 2) if traffic else None, "traffic_profile": prof}
+    return out
 
 
 def max_over_ranks(dist, seconds, device):
@@ -355,7 +394,7 @@ def cpu_all_cores(cfg, kind, sensor, with_boxes, pkg, threads, frames_per_thread
 
 # --------------------------------------------------------------------------- one workload on this rank
 class Workload:
-    def __init__(self, name, args, rank, world, dev, pkg, dist):
+    def __init__(self, name, args, rank, world, dev, pkg, dist, vocab=None):
         import torch
         self.torch = torch
         fe, synth = pkg.frontend, pkg.synth
@@ -364,6 +403,11 @@ class Workload:
         self.det_prec = "f16" if name == "stereo-yolo-f16" else "f32"      # f32 = the reference's arithmetic (cv::dnn on the CPU computes in f32)
         self.with_boxes = name in ("stereo-yolo", "stereo-yolo-f16", "rgbd-cull", "tum-mask", "kitti-batch")
         self.kind = "stereo" if name in ("stereo-yolo", "stereo-yolo-f16", "stereo", "kitti-batch") else "rgbd"
+        self.bow = name == "rgbd-bow"
+        self.vocab = vocab
+        self.bow_history = []             # per step: the lanes' ring slots (the copies q_frame holds)
+        if self.bow and vocab is None:
+            raise SystemExit("rgbd-bow needs the vocabulary")
         self.cfg = synth.TUM3 if name == "tum-mask" else (synth.KITTI_STEREO if self.kind == "stereo" else synth.KITTI03_RGBD)
         self.sensor = fe.SENSOR_STEREO if self.kind == "stereo" else fe.SENSOR_RGBD
         self.ipl = 2 if self.kind == "stereo" else 1
@@ -489,6 +533,19 @@ class Workload:
         res = self.trk.track(fr["images"].data_ptr(), W * 3, W * H * 3, fr["stamps"], boxes=boxes, n_boxes=n_boxes,
                              d_depth=fr["depth"].data_ptr() if fr["depth"] is not None else 0, depth_stride=W, depth_pitch=W * H,
                              stream=self.main.cuda_stream)
+        if self.bow:
+            # Frame::ComputeBoW of mCurrentFrame and of the queued frame two steps (0.2 s at 10 fps) back -- its ring slot is still
+            # q_frame's oldest entry after this step --, then SearchByBoW(that frame as the key frame, mCurrentFrame)
+            cur = np.array([r.cur_slot for r in res], np.int32)
+            self.bow_history.append(np.array([r.last_slot for r in res], np.int32))
+            if len(self.bow_history) > 3:
+                self.bow_history.pop(0)
+            if len(self.bow_history) == 3:
+                ref = self.bow_history[0]
+                self.batch.compute_bow(self.vocab, np.concatenate([cur, ref]), 4, stream=self.main.cuda_stream)
+                self.batch.search_by_bow(ref, cur, 0.7, True, stream=self.main.cuda_stream)
+            else:
+                self.batch.compute_bow(self.vocab, cur, 4, stream=self.main.cuda_stream)
         if self.cloud:
             self.batch.backproject_dense(np.arange(S, dtype=np.int32), fr["images"].data_ptr(), W * 3, W * H * 3, fr["depth"].data_ptr(), W, W * H,
                                          self.depth_factor, fr["mask"].data_ptr(), W, W * H, self.cam, self.Twc64, self.d_pts.data_ptr(), self.cap_pts,
@@ -523,13 +580,13 @@ class Workload:
                 d_.close()
 
 
-def run_workload(name, args, rank, world, dev, pkg, dist, headline):
+def run_workload(name, args, rank, world, dev, pkg, dist, headline, vocab=None):
     """-> dict with the measured figures of one workload (rank 0 fills everything, other ranks only take part)."""
     import torch
     fe = pkg.frontend
-    wl = Workload(name, args, rank, world, dev, pkg, dist)
+    wl = Workload(name, args, rank, world, dev, pkg, dist, vocab=vocab)
     steps, warm = (args.steps, args.warmup) if headline else (args.extra_steps, 1)
-    prof_steps = 4 if (headline and not args.no_profile) else 0
+    prof_steps = 4 if (not args.no_profile and (headline or name in ("stereo", "rgbd-bow"))) else 0
     if wl.strong:
         steps, warm, prof_steps = wl.T - 1, 0, 0
     wl.prepare(1 + warm + steps + prof_steps + 1)
@@ -640,27 +697,23 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline):
             per_launch = alg[dom] * n_img / per_step_launches
             avg_ms = ms / launches
             achieved = per_launch / (avg_ms * 1e-3) / 1e9
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc):
-                try:
-                    j = json.load(open(pmc))
-                    e = j.get(dom) or j.get({"k_fast_cells": "k_fast_cells_staged", "k_blur": "k_blur_wide", "k_pyr_level": "k_pyr_level_tiles",
-                                             "k_pyr_level0": "k_pyr_level0_rgb"}.get(dom, dom))      # in-library ids vs kernel symbols
-                    if e and e.get("batch_images") == n_img:
-                        traffic = e.get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
+            pmc = load_pmc_traffic(name)
+            table = kernel_roofline_table(kt, prof_steps, alg, n_img, wl.S, pmc)
+            e = pmc.get(dom) or pmc.get(KERNEL_SYMBOL.get(dom, dom))
+            traffic = e.get("hbm_bytes_per_launch") if (e and e.get("batch_images") == n_img) else None
+            traffic_profile = e.get("profile") if traffic is not None else None
             fe_ms = sum(v[0] for v in kt.values()) / prof_steps
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "algorithmic_bytes_per_launch": int(per_launch),
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_profile": traffic_profile, "algorithmic_bytes_per_launch": int(per_launch),
                     "avg_launch_ms": round(avg_ms, 4), "images_per_launch": int(n_img / per_step_launches),
+                    "kernels": table,
                     "kernels_ms_per_step": {k: round(v[0] / prof_steps, 4) for k, v in kt.items() if v[1] > 0},
                     "front_end_kernels_ms_per_step": round(fe_ms, 4),
                     "front_end_algorithmic_GBs_while_running": round(alg["image_total"] * n_img / (fe_ms * 1e-3) / 1e9, 2),
                     "pipeline_achieved_GBs": round(alg["image_total"] * wl.ipl * out["value"] / world / 1e9, 2),
                     "measured": "separate untimed pass of %d steps run like the timed ones, hipEvents around every kernel on its own stream" % prof_steps,
-                    "note": "the step is bound by the detector (the MFMA object above this one): the front-end kernels run beside it on their own stream"
+                    "note": "the step is bound by the detector (the MFMA object above this one): the front-end kernels run beside it on their own stream, "
+                            "their times here are CONTENDED (CU slots held by convolution workgroups) -- the uncontended per-kernel figures are under extra.stereo.roofline"
                             if wl.det is not None else None}
             if det_ms is not None:
                 fl = wl.det.flops()
@@ -670,17 +723,15 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline):
                 # time), so IT is the roofline object; one "launch" = the convolution launches of one detector batch, timed alone on the
                 # detector's stream.  The dominant HBM-bound kernel of the front end stays beside it under "front_end".
                 n_conv = int((wl.det.layers["type"] == 0).sum())                  # yolo.CONV
-                det_traffic = None
-                try:
-                    e = json.load(open(pmc)).get("k_conv_f32" if prec == "f32" else "")
-                    if e and e.get("batch_images") == n_img:
-                        det_traffic = int(e["hbm_bytes_per_launch"]) * n_conv * wl.n_det       # the profile's launches are sub-batch launches
-                except Exception:
-                    det_traffic = None
+                det_traffic, det_prof = None, None
+                e = pmc.get("k_conv_f32" if prec == "f32" else "")
+                if e and e.get("batch_images") == n_img:
+                    det_traffic = int(e["hbm_bytes_per_launch"]) * n_conv * wl.n_det       # the profile's launches are sub-batch launches
+                    det_prof = e.get("profile")
                 top = {"bound": "mfma", "kernel": "k_conv_f32 x %d launches = the convolutions of one %d-image detector batch" % (n_conv * wl.n_det, wl.S) if prec == "f32"
                                                   else "the f16 convolution kernels of one %d-image detector batch" % wl.S,
                        "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS[prec], "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS[prec], 4),
-                       "traffic": det_traffic, "algorithmic_flops_per_launch": int(fl * wl.S), "avg_launch_ms": round(det_ms, 3),
+                       "traffic": det_traffic, "traffic_profile": det_prof, "algorithmic_flops_per_launch": int(fl * wl.S), "avg_launch_ms": round(det_ms, 3),
                        "algorithmic_bytes_per_launch": detector_algorithmic_bytes(wl.det.layers, wl.det.net_w, wl.det.net_h, wl.S, 4 if prec == "f32" else 2),
                        "operands": prec, "images_per_s": round(wl.S / (det_ms * 1e-3), 1), "gflop_per_image": round(fl / 1e9, 2), "batch": wl.S,
                        "measured": "3 detector passes alone (%d sub-batch(es) of %d images on their own streams, as in the timed steps) between events on those streams (untimed pass)" % (wl.n_det, wl.S_det),
@@ -700,6 +751,8 @@ WORKLOAD_TEXT = {
                        "(tests/test_gpu_yolo.py counts them), so this is NOT the parity configuration",
     "stereo": "KITTI stereo 1241x376 colour pairs, 2000 feat/image: cvtColor + 2x ORB extract + stereo match + projection match vs the last frame, no detector / boxes",
     "rgbd": "KITTI-03 RGB-D 1241x376, 2000 feat/frame: cvtColor + ORB extract + RGB-D stereo + projection match vs the last frame, no semantic mask (BASELINE configs[1])",
+    "rgbd-bow": "KITTI-03 RGB-D 1241x376, 2000 feat/frame: the rgbd chain + ComputeBoW (6-level x 10-way descent of the RCCL-broadcast vocabulary, BowVector / "
+                "FeatureVector) of the current frame and of the queued frame 0.2 s back + SearchByBoW between them",
     "rgbd-cull": "KITTI-03 RGB-D 1241x376, 2000 feat/frame, 3 given boxes per frame: extract + match + boxTrack + firstSeparate + TrackHomo + Separate + UpdateFrame",
     "tum-mask": "TUM3 RGB-D 640x480, 1000 feat/frame, DepthMapFactor 5000, 30 fps, mask + 3 boxes per frame: extract + match + cull + dense back-projection of the "
                 "pixels outside (dynamic box AND mask) (BASELINE configs[3])",
@@ -784,11 +837,11 @@ def main():
         vocab = voc0
     assert vocab.info()["n_nodes"] == int(n_nodes_t.item()) and vocab.info()["k"] == 10 and vocab.info()["L"] == 6
 
-    head, wl = run_workload(args.workload, args, rank, world, dev, pkg, dist, headline=True)
+    head, wl = run_workload(args.workload, args, rank, world, dev, pkg, dist, headline=True, vocab=vocab)
     extras = {}
     names = []
     if args.extra == "auto":
-        names = [w for w in ("stereo-yolo-f16", "stereo", "rgbd", "rgbd-cull", "tum-mask", "kitti-batch") if w != args.workload] if world == 1 else []
+        names = [w for w in ("stereo-yolo-f16", "stereo", "rgbd", "rgbd-cull", "rgbd-bow", "tum-mask", "kitti-batch") if w != args.workload] if world == 1 else []
     elif args.extra != "none":
         names = [w for w in args.extra.split(",") if w]
     for w in names:
@@ -797,11 +850,13 @@ def main():
         kf = args.kitti_frames
         if w == "kitti-batch" and args.extra == "auto":
             args.kitti_frames = min(kf, 64)          # a bounded sample of configs[4] (the host generates every frame of every sequence): the text says how many
-        o, _ = run_workload(w, args, rank, world, dev, pkg, dist, headline=False)
+        o, _ = run_workload(w, args, rank, world, dev, pkg, dist, headline=False, vocab=vocab)
         if rank == 0:
             extras[w] = {"value": o["value"], "unit": "frames/s", "ms_per_step": o["ms_per_step"], "steps": o["steps"], "lanes_per_gpu": o["lanes_per_gpu"],
                          "scaling": "strong" if w == "kitti-batch" else "weak",
                          "workload": WORKLOAD_TEXT[w] % args.kitti_frames if w == "kitti-batch" else WORKLOAD_TEXT[w], "lane0_last_frame": o["lane0_last_frame"]}
+            if "roofline" in o:
+                extras[w]["roofline"] = o["roofline"]
         args.kitti_frames = kf
 
     if rank == 0:

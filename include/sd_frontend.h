@@ -377,7 +377,7 @@ typedef struct sd_tracker_params {
     float th_depth;         /* ThDepth (kept for the caller; not used on this path) */
     int32_t ini_features;   /* monocular: nFeatures of mpIniORBextractor (Tracking.cc:127-128: 2 * nFeatures), used while a lane is not
                              * initialised (Tracking.cc:335-338); 0 = one extractor for every frame */
-    int32_t reserved2;
+    int32_t lookahead;      /* > 0: frames per lane sd_tracker_prefetch may extract ahead in one call (two such blocks can be outstanding) */
 } sd_tracker_params;
 #define SD_DEPTH_U16 0
 #define SD_DEPTH_F32 1
@@ -416,6 +416,17 @@ int sd_tracker_track(sd_tracker* t, const uint8_t* d_images, size_t stride, size
 int sd_tracker_track_host(sd_tracker* t, const uint8_t* const* images, size_t stride, const void* const* depth,
                           size_t depth_stride_elems, const double* boxes, const int32_t* n_boxes, const double* timestamps,
                           const float* Tcw, const float* Twc, sd_lane_result* results);
+/* Time-batched mode (BASELINE configs[4]: whole sequences, few lanes per GPU).  A frame's work splits into a history-free part --
+ * GrabImage*'s cvtColor, ORB extraction of both eyes, UndistortKeyPoints, ComputeStereoMatches / ComputeStereoFromRGBD: more than 95 % of
+ * the front end's time -- and the recurrence along the stream (boxTrack -> firstSeparate -> TrackHomo vs the queued frame -> Separate ->
+ * UpdateFrame -> match vs mLastFrame), whose box ids (`max + 1`, Frame.cc:545-550) depend on the stream's whole history, so a stream
+ * cannot be cut into independently processed chunks.  sd_tracker_prefetch runs the history-free part for the NEXT n_frames frames of every
+ * lane in one batch (image e of frame k of lane s at d_images + ((k * n_lanes + s) * images_per_lane + e) * image_pitch, depth image of
+ * frame k of lane s at d_depth + (k * n_lanes + s) * depth_pitch_elems), asynchronously on `stream`; the following n_frames calls of
+ * sd_tracker_track with d_images == NULL consume them in order and run only the recurrence.  Results are identical to n_frames plain
+ * calls.  Needs params.lookahead >= n_frames; two blocks may be outstanding (extract block b + 1 while block b is tracked). */
+int sd_tracker_prefetch(sd_tracker* t, const uint8_t* d_images, size_t stride, size_t image_pitch, const void* d_depth,
+                        size_t depth_stride_elems, size_t depth_pitch_elems, int n_frames, void* stream);
 /* The SLAM state a caller with a live back end owns, handed over the boundary (all optional; without them the tracker runs in its
  * sharded batch mode):
  *  - the pose prior is the Tcw / Twc argument of sd_tracker_track: `mCurrentFrame.SetPose(mVelocity*mLastFrame.mTcw)` (Tracking.cc:982)

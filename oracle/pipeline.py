@@ -21,6 +21,33 @@ import numpy as np
 SENSOR_MONOCULAR, SENSOR_STEREO, SENSOR_RGBD = 0, 1, 2        # System::eSensor, include/System.h:60-64
 
 
+def pose_mul(a, b):
+    """cv::Mat product of two 4x4 CV_32F matrices, as `mVelocity*mLastFrame.mTcw` (Tracking.cc:982) [OpenCV-recall: gemm accumulates CV_32F
+    products in double, k ascending, and narrows once]."""
+    a = np.asarray(a, np.float32).reshape(4, 4); b = np.asarray(b, np.float32).reshape(4, 4)
+    r = np.zeros((4, 4), np.float32)
+    for i in range(4):
+        for j in range(4):
+            s = 0.0
+            for k in range(4):
+                s += float(a[i, k]) * float(b[k, j])
+            r[i, j] = np.float32(s)
+    return r
+
+
+def pose_inverse(Tcw):
+    """Frame::UpdatePoseMatrices (Frame.cc:669-675): mRwc = mRcw.t(), mOw = -mRcw.t()*mtcw, as the 4x4 [mRwc | mOw]."""
+    T = np.asarray(Tcw, np.float32).reshape(4, 4)
+    r = np.eye(4, dtype=np.float32)
+    for i in range(3):
+        s = 0.0
+        for k in range(3):
+            r[i, k] = T[k, i]
+            s += float(T[k, i]) * float(T[k, 3])
+        r[i, 3] = -np.float32(s)
+    return r
+
+
 class FrameState:
     """The members of ORB_SLAM2::Frame this path produces (include/Frame.h:113-210)."""
 
@@ -46,12 +73,15 @@ class FrameState:
 class SequenceOracle:
     """One camera stream through Tracking's front end, frame by frame."""
 
-    def __init__(self, orc, cfg, sensor, rgb_order=True, track_last=True, threads=1):
+    def __init__(self, orc, cfg, sensor, rgb_order=True, track_last=True, threads=1, ini_features=0):
         self.orc, self.cfg, self.sensor = orc, cfg, sensor
         self.threads = threads               # 2: left / right extraction in two threads, as Frame.cc:87-90 / 151-154
-        mk = lambda: orc.Extractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+        mk = lambda nf=cfg["n_features"]: orc.Extractor(nf, cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
         self.exL = mk()
         self.exR = mk() if sensor == SENSOR_STEREO else None
+        # mpIniORBextractor = new ORBextractor(2*nFeatures, ...) for the monocular sensor (Tracking.cc:127-128), used by
+        # GrabImageMonocular while mState is NOT_INITIALIZED / NO_IMAGES_YET (Tracking.cc:335-338)
+        self.exIni = mk(ini_features) if (sensor == SENSOR_MONOCULAR and ini_features and ini_features != cfg["n_features"]) else None
         fx = np.float32(cfg["fx"]); bf = np.float32(cfg["bf"])
         self.K4 = np.array([fx, cfg["fy"], cfg["cx"], cfg["cy"]], np.float32)
         self.dist5 = np.array([cfg.get(k, 0.0) for k in ("k1", "k2", "p1", "p2", "k3")], np.float32)
@@ -59,7 +89,8 @@ class SequenceOracle:
         self.cam10 = np.array([fx, cfg["fy"], cfg["cx"], cfg["cy"], bf, np.float32(bf / fx), b[0], b[1], b[2], b[3]], np.float32)
         self.rgb_order = rgb_order
         self.track_last = track_last
-        self.depth_factor = float(np.float32(1.0) / np.float32(cfg.get("depth_map_factor", 1.0)))   # Tracking.cc:141-146
+        dmf = np.float32(cfg.get("depth_map_factor", 1.0))
+        self.depth_factor = float(np.float32(1.0) if abs(dmf) < 1e-5 else np.float32(1.0) / dmf)   # Tracking.cc:141-146
         self.q_frame = []                    # Tracking::q_frame (Tracking.h:109), front = index 0
         self.mLastFrame = None
         self.mMaxFrames = cfg["fps"]         # Tracking.cc:93-98: mMaxFrames = fps
@@ -76,12 +107,12 @@ class SequenceOracle:
 
     # ------------------------------------------------------------------ Frame::Frame
     def _gray(self, im):
-        if im.ndim == 3:
+        if im.ndim == 3:              # 3 or 4 channels: CV_RGB2GRAY / CV_BGR2GRAY / CV_RGBA2GRAY / CV_BGRA2GRAY (Tracking.cc:175-200)
             return self.orc.cvt_gray(im, 1 if self.rgb_order else 0)
         return np.ascontiguousarray(im, np.uint8)
 
-    def construct(self, im, im2, boxes, timestamp):
-        """GrabImage* + the Frame ctor.  im2 = right image (stereo), u16 depth (RGB-D) or None (mono);
+    def construct(self, im, im2, boxes, timestamp, initialised=True):
+        """GrabImage* + the Frame ctor.  im2 = right image (stereo), u16 or f32 depth (RGB-D) or None (mono);
         boxes = (n, 4) f64 rows x, y, w, h, or None for the ctors without boxes."""
         orc, cfg = self.orc, self.cfg
         F = FrameState()
@@ -96,7 +127,8 @@ class SequenceOracle:
             th.join()
             kpR, descR = box["r"]
         else:
-            kp, desc = self.exL(self._gray(im))
+            ex = self.exIni if (self.exIni is not None and not initialised) else self.exL
+            kp, desc = ex(self._gray(im))
             if self.sensor == SENSOR_STEREO:
                 kpR, descR = self.exR(self._gray(im2))
         N = len(kp)
@@ -110,7 +142,11 @@ class SequenceOracle:
         if self.sensor == SENSOR_STEREO:
             ur, dep, _, _ = orc.stereo_matches(self.exL, self.exR, kp, desc, kpR, descR, cfg["bf"], cfg["fx"])
         elif self.sensor == SENSOR_RGBD:
-            dep32 = orc.depth_to_f32(im2, self.depth_factor)
+            # `if((fabs(mDepthMapFactor-1.0f)>1e-5) || imDepth.type()!=CV_32F) imDepth.convertTo(imDepth,CV_32F,mDepthMapFactor)` (Tracking.cc:271-272)
+            if im2.dtype == np.float32:
+                dep32 = im2 if not abs(np.float32(self.depth_factor) - np.float32(1.0)) > 1e-5 else (im2 * np.float32(self.depth_factor)).astype(np.float32)
+            else:
+                dep32 = orc.depth_to_f32(im2, self.depth_factor)
             ur, dep = orc.stereo_from_rgbd(kp, dep32, cfg["bf"])           # depth looked up at the DISTORTED position (Frame.cc:1062-1065)
             if self.dist5[0] != 0:                                         # mvuRight[i] = kpU.pt.x - mbf / d (Frame.cc:1069), f32
                 kun = self._undistort(kp)
@@ -160,17 +196,29 @@ class SequenceOracle:
         return F.motion["flag"]
 
     # ------------------------------------------------------------------ Tracking::Track_new
-    def track(self, im, im2, boxes, timestamp, Tcw=None, Twc=None):
+    def set_mappoints(self, xw, flags):
+        """The back end's MapPoints of the frame just tracked (mvpMapPoints after TrackWithMotionModel / TrackLocalMap): they replace the
+        stereo points of mLastFrame, which is the same object as the newest q_frame entry."""
+        L = self.mLastFrame
+        n = len(flags)
+        L.xw = np.zeros((max(n, L.N), 3), np.float32); L.mp_flags = np.zeros(max(n, L.N), np.uint8)
+        L.xw[:n] = np.asarray(xw, np.float32).reshape(n, 3); L.mp_flags[:n] = flags
+
+    def track(self, im, im2, boxes, timestamp, Tcw=None, Twc=None, state=None):
         """-> FrameState of mCurrentFrame after the dynamic block.  Tcw / Twc: pose of the current frame and its inverse
-        (mVelocity * mLastFrame.mTcw in the reference; identity when omitted); the reference frame's pose is the one it was tracked with."""
+        (mVelocity * mLastFrame.mTcw in the reference; identity when omitted); the reference frame's pose is the one it was tracked with.
+        state: the caller's SLAM state, bit0 = initialised, bit1 = mState == OK && !mVelocity.empty(); None = the automatic rule of the
+        sharded batch mode (frame 0: not initialised -- the monocular sensor also on frame 1; velocity from frame 2 on)."""
         orc = self.orc
-        F = self.construct(im, im2, boxes, timestamp)
+        if state is None:
+            first, have_velocity, mono_init = self.n_frames == 0, self.n_frames >= 2, self.n_frames >= 2
+        else:
+            first, have_velocity, mono_init = not (state & 1), bool(state & 2), bool(state & 1)
+        F = self.construct(im, im2, boxes, timestamp, initialised=mono_init)
         F.Tcw = self.I if Tcw is None else np.asarray(Tcw, np.float32).reshape(4, 4)
         F.Twc = self.I if Twc is None else np.asarray(Twc, np.float32).reshape(4, 4)
-        first = self.n_frames == 0
         if first:
             self.q_frame = []                                   # Tracking.cc:600-605
-        have_velocity = self.n_frames >= 2
         if not first and len(F.objects) > 0 and len(self.q_frame) > 0:                    # Tracking.cc:622
             while len(self.q_frame) > 0 and F.mTimeStamp - self.q_frame[0].mTimeStamp > np.float32(0.2):
                 R = self.q_frame[0]

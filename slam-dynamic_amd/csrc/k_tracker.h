@@ -27,6 +27,21 @@ __global__ void __launch_bounds__(256) k_copy_frames(SdCopyTable T, const int2* 
     for (unsigned i = (quads << 4) + blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) d[i] = s[i];
 }
 
+// The same between two workspaces with the same row stride (sd_tracker_prefetch's pool -> the lanes' current slots): lane l copies slot
+// srcFirst + l * slotStep of the source arrays to slot l * slotStep of the destination arrays.
+struct SdCopyTableX { const char* src[SD_COPY_SEGS]; char* dst[SD_COPY_SEGS]; unsigned slotBytes[SD_COPY_SEGS]; int n; };
+__global__ void __launch_bounds__(256) k_copy_frames_x(SdCopyTableX T, int srcFirst, int slotStep)
+{
+    const int seg = blockIdx.y, l = blockIdx.z;
+    const unsigned n = T.slotBytes[seg];
+    const char* s = T.src[seg] + (size_t)(srcFirst + l * slotStep) * n;
+    char* d = T.dst[seg] + (size_t)(l * slotStep) * n;
+    const bool a16 = ((((size_t)s) | ((size_t)d)) & 15) == 0;
+    const unsigned quads = a16 ? n >> 4 : 0;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < quads; i += gridDim.x * 256) ((uint4*)d)[i] = ((const uint4*)s)[i];
+    for (unsigned i = (quads << 4) + blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) d[i] = s[i];
+}
+
 __global__ void k_lane_gate(const SdFrameBoxes* __restrict__ fb, const int* __restrict__ want, int* __restrict__ active, int n, int slotStep)
 {
     const int s = blockIdx.x * 64 + threadIdx.x;

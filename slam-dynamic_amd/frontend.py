@@ -56,6 +56,10 @@ def lib():
         L.sd_batch_kp_capacity.argtypes = [vp, C.POINTER(i)]
         L.sd_batch_extract_device.argtypes = [vp, vp, sz, sz, i, vp]
         L.sd_batch_extract_color_device.argtypes = [vp, vp, sz, sz, i, i, vp]
+        L.sd_batch_extract_pixels_device.argtypes = [vp, vp, sz, sz, i, i, i, vp]
+        L.sd_batch_rgbd_from_f32_scaled.argtypes = [vp, vp, sz, sz, i, f, f, vp]
+        L.sd_tracker_set_mappoints.argtypes = [vp, vp, vp, vp]
+        L.sd_tracker_set_state.argtypes = [vp, vp]
         L.sd_batch_extract_host.argtypes = [vp, vp, sz, sz, i]
         L.sd_batch_results_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i)]
         L.sd_batch_counts.argtypes = [vp, vp, i]
@@ -215,6 +219,11 @@ class Batch:
         """cvtColor + operator() for 3-channel images in HBM (GrabImageRGBD's conversion fused into pyramid level 0)."""
         check(lib().sd_batch_extract_color_device(self.h, C.c_void_p(d_ptr), stride, pitch, int(bool(rgb_order)), n,
                                                   C.c_void_p(stream or 0)))
+
+    def extract_pixels_device(self, d_ptr, stride, pitch, n, channels, rgb_order=True, stream=None):
+        """Any input GrabImage* accepts: 1 (gray), 3 or 4 channels (Tracking.cc:175-200)."""
+        check(lib().sd_batch_extract_pixels_device(self.h, C.c_void_p(d_ptr), stride, pitch, channels, int(bool(rgb_order)), n,
+                                                   C.c_void_p(stream or 0)))
 
     def sync(self):
         check(lib().sd_batch_sync(self.h))
@@ -486,8 +495,8 @@ class _Camera(C.Structure):
 class TrackerParams(C.Structure):
     """sd_tracker_params (include/sd_frontend.h)."""
     _fields_ = [("sensor", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32), ("rgb_order", C.c_int32),
-                ("n_lanes", C.c_int32), ("track_last", C.c_int32), ("reserved", C.c_int32), ("cam", _Camera), ("dist", C.c_float * 5),
-                ("fps", C.c_float), ("depth_map_factor", C.c_float), ("th_depth", C.c_float)]
+                ("n_lanes", C.c_int32), ("track_last", C.c_int32), ("depth_type", C.c_int32), ("cam", _Camera), ("dist", C.c_float * 5),
+                ("fps", C.c_float), ("depth_map_factor", C.c_float), ("th_depth", C.c_float), ("ini_features", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class LaneResult(C.Structure):
@@ -503,8 +512,11 @@ class Tracker:
     """sd_tracker: System::TrackStereo / TrackRGBD / TrackMonocular for n_lanes independent camera streams, one frame per lane per call
     (Tracking::GrabImage* -> Frame::Frame -> Track_new's dynamic block -> match vs mLastFrame -> q_frame)."""
 
-    def __init__(self, extractor, cfg, sensor, n_lanes, channels=1, rgb_order=True, track_last=True):
+    def __init__(self, extractor, cfg, sensor, n_lanes, channels=1, rgb_order=True, track_last=True, depth_f32=False, ini_features=0):
+        """depth_f32: the depth images are CV_32F (Tracking.cc:271-272); ini_features: nFeatures of mpIniORBextractor for monocular lanes
+        that are not initialised (Tracking.cc:127-128, 335-338), 0 = none."""
         p = TrackerParams()
+        p.depth_type, p.ini_features = int(bool(depth_f32)), int(ini_features)
         p.sensor, p.width, p.height, p.channels, p.rgb_order = sensor, cfg["width"], cfg["height"], channels, int(bool(rgb_order))
         p.n_lanes, p.track_last = n_lanes, int(bool(track_last))
         cam = make_camera(cfg)
@@ -536,6 +548,26 @@ class Tracker:
 
     def reset(self):
         check(lib().sd_tracker_reset(self.h))
+
+    def set_state(self, state):
+        """state: per lane, bit0 = initialised, bit1 = mState == OK && !mVelocity.empty(); None = the automatic rule."""
+        if state is None:
+            check(lib().sd_tracker_set_state(self.h, None))
+        else:
+            st = np.ascontiguousarray(state, np.int32).reshape(self.n_lanes)
+            check(lib().sd_tracker_set_state(self.h, _p(st)))
+
+    def set_mappoints(self, xw_list, flags_list):
+        """The back end's MapPoints of the frames just tracked: per lane (n, 3) f32 world positions + (n,) u8 flags, or None to keep the
+        lane's own stereo points."""
+        S, cap = self.n_lanes, self.batch.cap
+        xw = np.zeros((S, cap, 3), np.float32); fl = np.zeros((S, cap), np.uint8); n = np.full(S, -1, np.int32)
+        for l in range(S):
+            if xw_list[l] is None:
+                continue
+            k = len(flags_list[l]); n[l] = k
+            xw[l, :k] = np.asarray(xw_list[l], np.float32).reshape(k, 3); fl[l, :k] = flags_list[l]
+        check(lib().sd_tracker_set_mappoints(self.h, _p(xw), _p(fl), _p(n)))
 
     def track(self, d_images, stride, image_pitch, timestamps, boxes=None, n_boxes=None, d_depth=0, depth_stride=0, depth_pitch=0,
               Tcw=None, Twc=None, stream=None):

@@ -29,11 +29,41 @@ struct Image {                  // the subset of cv::Mat this path reads
     const uint8_t* data = nullptr;
     int cols = 0, rows = 0, nch = 1;
     size_t step = 0;            // bytes per row
-    int elem = 1;               // bytes per channel element (2 for a CV_16U depth map)
+    int elem = 1;               // bytes per channel element (2 for a CV_16U depth map, 4 for CV_32F)
     int channels() const { return nch; }
+    size_t elemSize1() const { return (size_t)elem; }
     bool empty() const { return !data || cols <= 0 || rows <= 0; }
 };
-struct Pose { float m[16]; Pose() { for (int i = 0; i < 16; i++) m[i] = (i % 5 == 0) ? 1.f : 0.f; } bool empty() const { return false; } };
+// a 4x4 CV_32F cv::Mat as Tracking uses it for mTcw / mVelocity; `valid == false` plays cv::Mat::empty()
+struct Pose {
+    float m[16]; bool valid = true;
+    Pose() { for (int i = 0; i < 16; i++) m[i] = (i % 5 == 0) ? 1.f : 0.f; }
+    static Pose none() { Pose p; p.valid = false; return p; }
+    bool empty() const { return !valid; }
+};
+// cv::Mat product of two 4x4 CV_32F matrices [OpenCV-recall: gemm accumulates CV_32F products in double, k ascending] -- mVelocity*mLastFrame.mTcw
+inline Pose mul(const Pose& a, const Pose& b)
+{
+    Pose r;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double s = 0.0;
+            for (int k = 0; k < 4; k++) s += (double)a.m[4 * i + k] * (double)b.m[4 * k + j];
+            r.m[4 * i + j] = (float)s;
+        }
+    return r;
+}
+// Frame::UpdatePoseMatrices (src/Frame.cc:669-675): mRwc = mRcw.t(), mOw = -mRcw.t()*mtcw, returned as the 4x4 [mRwc | mOw]
+inline Pose inverse_of(const Pose& Tcw)
+{
+    Pose r;
+    for (int i = 0; i < 3; i++) {
+        double s = 0.0;
+        for (int k = 0; k < 3; k++) { r.m[4 * i + k] = Tcw.m[4 * k + i]; s += (double)Tcw.m[4 * k + i] * (double)Tcw.m[4 * k + 3]; }
+        r.m[4 * i + 3] = -(float)s;
+    }
+    return r;
+}
 struct Settings {               // the YAML entries Tracking::Tracking reads (src/Tracking.cc:56-150)
     float fx = 0, fy = 0, cx = 0, cy = 0, k1 = 0, k2 = 0, p1 = 0, p2 = 0, k3 = 0, bf = 0, fps = 30, ThDepth = 40, DepthMapFactor = 1;
     int RGB = 1, width = 0, height = 0;
@@ -106,12 +136,16 @@ public:
 class Tracking {
 public:
     enum { MONOCULAR = 0, STEREO = 1, RGBD = 2 };       // System::eSensor
-    Tracking(const sdfe::Settings& s, int sensor, int channels)
-        : mSensor(sensor), set_(s), ex_(s.nFeatures, s.scaleFactor, s.nLevels, s.iniThFAST, s.minThFAST)
+    enum eTrackingState { AUTOMATIC = -2, SYSTEM_NOT_READY = -1, NO_IMAGES_YET = 0, NOT_INITIALIZED = 1, OK = 2, LOST = 3 };   // include/Tracking.h:92-98
+    // channels: 1, 3 or 4 (Tracking.cc:175-200); depthIsFloat: the depth images are CV_32F instead of CV_16U (Tracking.cc:271-272)
+    Tracking(const sdfe::Settings& s, int sensor, int channels, bool depthIsFloat = false)
+        : mSensor(sensor), set_(s), ex_(s.nFeatures, s.scaleFactor, s.nLevels, s.iniThFAST, s.minThFAST), depthElem_(depthIsFloat ? 4 : 2)
     {
         sd_tracker_params p;
         std::memset(&p, 0, sizeof(p));
         p.sensor = sensor; p.width = s.width; p.height = s.height; p.channels = channels; p.rgb_order = s.RGB; p.n_lanes = 1; p.track_last = 1;
+        p.depth_type = depthIsFloat ? SD_DEPTH_F32 : SD_DEPTH_U16;
+        p.ini_features = sensor == MONOCULAR ? 2 * s.nFeatures : 0;       // mpIniORBextractor = new ORBextractor(2*nFeatures, ...) (Tracking.cc:127-128)
         p.cam.fx = s.fx; p.cam.fy = s.fy; p.cam.cx = s.cx; p.cam.cy = s.cy; p.cam.mbf = s.bf; p.cam.mb = s.bf / s.fx;
         const float K4[4] = {s.fx, s.fy, s.cx, s.cy}, d5[5] = {s.k1, s.k2, s.p1, s.p2, s.k3};
         float b4[4];
@@ -147,14 +181,14 @@ public:
     sdfe::Pose GrabImageRGBD(const MatT& imRGB, const MatT& imD, const MatT& /*mask*/, std::vector<RectT>& boxes, const double& timestamp)
     {
         const uint8_t* im[1] = {(const uint8_t*)imRGB.data};
-        return grab(im, (size_t)imRGB.step, (const uint16_t*)imD.data, (size_t)imD.step / 2, &boxes, timestamp);
+        return grab(im, (size_t)imRGB.step, (const void*)imD.data, (size_t)imD.step / depthElem(imD), &boxes, timestamp);
     }
     // cv::Mat GrabImageRGBD(imRGB, imD, timestamp)                         src/Tracking.cc:251-280
     template <class MatT>
     sdfe::Pose GrabImageRGBD(const MatT& imRGB, const MatT& imD, const double& timestamp)
     {
         const uint8_t* im[1] = {(const uint8_t*)imRGB.data};
-        return grab<sdfe::Rect2d>(im, (size_t)imRGB.step, (const uint16_t*)imD.data, (size_t)imD.step / 2, nullptr, timestamp);
+        return grab<sdfe::Rect2d>(im, (size_t)imRGB.step, (const void*)imD.data, (size_t)imD.step / depthElem(imD), nullptr, timestamp);
     }
     // cv::Mat GrabImageMonocular(im, timestamp)                            src/Tracking.cc:316-343
     template <class MatT>
@@ -166,12 +200,36 @@ public:
 
     Frame mCurrentFrame, mLastFrame;
     int mSensor;
+    // The SLAM state the pose side owns (include/Tracking.h:92-98,214-215), read at the next GrabImage*: mState (AUTOMATIC = the
+    // sharded batch rule of DESIGN.md Q14) and mVelocity (empty until the motion model has one).  TrackHomo predicts the pose of the
+    // new frame with `mCurrentFrame.SetPose(mVelocity*mLastFrame.mTcw)` (Tracking.cc:982); the pose side then overwrites
+    // mCurrentFrame.mTcw with its estimate before the next frame arrives.
+    int mState = AUTOMATIC;
+    sdfe::Pose mVelocity = sdfe::Pose::none();
+    // mCurrentFrame.mvpMapPoints as the pose side left them (TrackWithMotionModel / TrackLocalMap): world positions + flags (bit0: the
+    // point exists and is not an outlier, bit1: Observations() > 0) of key points [0, n).  They become the points later frames project
+    // from mLastFrame / q_frame (Tracking.cc:998-1010, 1714-1741) instead of the frame's own stereo points.
+    void CommitMapPoints(const float* xw, const uint8_t* flags, int n)
+    {
+        int cap = 0;
+        sd_batch_kp_capacity(batch_, &cap);
+        if (n > cap) throw std::runtime_error("more map points than key points");
+        std::vector<float> x((size_t)cap * 3, 0.f); std::vector<uint8_t> f((size_t)cap, 0);
+        std::memcpy(x.data(), xw, (size_t)n * 12); std::memcpy(f.data(), flags, (size_t)n);
+        const int32_t nn = n;
+        sdfe::check(sd_tracker_set_mappoints(trk_, x.data(), f.data(), &nn), "Tracking::CommitMapPoints");
+    }
     sd_batch* batch() { return batch_; }
     int current_slot() const { return res_.cur_slot; }
 
 private:
+    template <class MatT> size_t depthElem(const MatT& imD) const
+    {
+        if ((size_t)imD.elemSize1() != depthElem_) throw std::runtime_error("depth image type differs from the one the tracker was created for");
+        return depthElem_;
+    }
     template <class RectT>
-    sdfe::Pose grab(const uint8_t* const* images, size_t stride, const uint16_t* depth, size_t depthStrideElems, std::vector<RectT>* boxes,
+    sdfe::Pose grab(const uint8_t* const* images, size_t stride, const void* depth, size_t depthStrideElems, std::vector<RectT>* boxes,
                     const double& timestamp)
     {
         double bx[SD_MAX_BOXES][4];
@@ -181,11 +239,22 @@ private:
             nb = (int32_t)boxes->size();
             for (int j = 0; j < nb; j++) { bx[j][0] = (*boxes)[j].x; bx[j][1] = (*boxes)[j].y; bx[j][2] = (*boxes)[j].width; bx[j][3] = (*boxes)[j].height; }
         }
-        const uint16_t* dp[1] = {depth};
+        const void* dp[1] = {depth};
+        // the pose prior: mVelocity * mLastFrame.mTcw when there is a velocity (Tracking.cc:982), the last pose otherwise
+        const bool haveLast = frames_ > 0;                 // mCurrentFrame still is the previous frame here (the reference's mLastFrame)
+        sdfe::Pose Tcw = haveLast ? mCurrentFrame.mTcw : sdfe::Pose();
+        if (!mVelocity.empty() && haveLast) Tcw = sdfe::mul(mVelocity, mCurrentFrame.mTcw);
+        const sdfe::Pose Twc = sdfe::inverse_of(Tcw);
+        if (mState != AUTOMATIC) {
+            const int32_t st = ((mState == OK || mState == LOST) ? 1 : 0) | ((mState == OK && !mVelocity.empty()) ? 2 : 0);
+            sdfe::check(sd_tracker_set_state(trk_, &st), "Tracking::GrabImage");
+        } else sdfe::check(sd_tracker_set_state(trk_, nullptr), "Tracking::GrabImage");
         sdfe::check(sd_tracker_track_host(trk_, images, stride, depth ? dp : nullptr, depthStrideElems, boxes ? &bx[0][0] : nullptr, boxes ? &nb : nullptr,
-                                          &timestamp, nullptr, nullptr, &res_), "Tracking::GrabImage");
+                                          &timestamp, Tcw.m, Twc.m, &res_), "Tracking::GrabImage");
         mLastFrame = mCurrentFrame;
         fill(mCurrentFrame, timestamp);
+        mCurrentFrame.mTcw = Tcw;
+        frames_++;
         if (boxes) {                                    // boxTrack / firstSeparate rewrite the caller's vector (they take it by reference)
             boxes->resize(mCurrentFrame.objects.size());
             for (size_t j = 0; j < boxes->size(); j++) {
@@ -193,7 +262,7 @@ private:
                 (*boxes)[j].width = mCurrentFrame.objects[j].width; (*boxes)[j].height = mCurrentFrame.objects[j].height;
             }
         }
-        return sdfe::Pose();
+        return Tcw;
     }
 
     void fill(Frame& F, double timestamp)
@@ -262,13 +331,16 @@ private:
     sd_batch* batch_ = nullptr;
     sd_camera cam_;
     sd_lane_result res_;
+    size_t depthElem_ = 2;
+    long frames_ = 0;
 };
 
 // ORB_SLAM2::System's tracking entry points (include/System.h:66-79, src/System.cc:119-375) with the reference's argument lists.
 class System {
 public:
     enum eSensor { MONOCULAR = 0, STEREO = 1, RGBD = 2 };
-    System(const sdfe::Settings& settings, const eSensor sensor, int channels = 3) : mSensor(sensor), mpTracker(new Tracking(settings, (int)sensor, channels)) {}
+    System(const sdfe::Settings& settings, const eSensor sensor, int channels = 3, bool depthIsFloat = false)
+        : mSensor(sensor), mpTracker(new Tracking(settings, (int)sensor, channels, depthIsFloat)) {}
     ~System() { delete mpTracker; }
     System(const System&) = delete;
     System& operator=(const System&) = delete;

@@ -87,13 +87,34 @@ def _read_frame_dump(buf, off, fe):
         out["boxes"].append(dict(rect=r, idx=idx, status=st, omit=om, vel=vel, kp=take(fe.KP_DTYPE, k), kpUn=take(fe.KP_DTYPE, k), desc=take(np.uint8, 32 * k).reshape(k, 32),
                                  ur=take(np.float32, k), dep=take(np.float32, k)))
     out["cell"] = take(np.int32, N)
+    out["Tcw"] = take(np.float32, 16).reshape(4, 4)
     return out, off
 
 
-@pytest.mark.parametrize("kind", ["stereo", "rgbd", "rgbd-tum1"])
+def _yaw(cfg, px=3.0):
+    a = px / float(cfg["fx"])
+    V = np.eye(4, dtype=np.float32)
+    V[0, 0] = np.float32(np.cos(a)); V[0, 2] = np.float32(np.sin(a)); V[2, 0] = np.float32(-np.sin(a)); V[2, 2] = np.float32(np.cos(a))
+    return V
+
+
+def _commit(t, F, seed):
+    rng = np.random.default_rng(1000 * seed + t)
+    xw = F.xw.copy(); fl = F.mp_flags.copy()
+    xw += rng.normal(0, 0.01, xw.shape).astype(np.float32)
+    fl[rng.random(len(fl)) < 0.15] = 0
+    fl[(rng.random(len(fl)) < 0.4) & (fl != 0)] |= 2
+    return xw, fl
+
+
+@pytest.mark.parametrize("kind", ["stereo", "rgbd", "rgbd-tum1", "stereo-moving", "rgbd-rgba-f32", "mono"])
 def test_cpp_system_track_matches_frame_oracle(gpu, fe, orc, synth, tmp_path, kind):
-    """host/Frame.h: ORB_SLAM2::System::TrackStereo / TrackRGBD (C++, g++, no OpenCV) frame by frame against the frame-level oracle:
-    every public Frame member this path produces, bit for bit (stereo: KITTI configs[2]; RGB-D: TUM3 configs[3] with mask + boxes)."""
+    """host/Frame.h: ORB_SLAM2::System::TrackStereo / TrackRGBD / TrackMonocular (C++, g++, no OpenCV) frame by frame against the frame-level
+    oracle: every public Frame member this path produces, bit for bit (stereo: KITTI configs[2]; RGB-D: TUM3 configs[3] with mask + boxes).
+      stereo-moving   the pose side's state through the mirror: Tracking::mState, mVelocity (the mirror predicts mVelocity * mLastFrame.mTcw as
+                      Tracking.cc:982 does and hands Tcw / Twc on) and the MapPoints it commits after every frame (Tracking.cc:998-1010)
+      rgbd-rgba-f32   4-channel colour + CV_32F depth still to be scaled by DepthMapFactor (Tracking.cc:187-200, 271-272), with a velocity
+      mono            TrackMonocular: mpIniORBextractor (2 * nFeatures) for the first two frames (Tracking.cc:127-128, 335-338)"""
     import importlib.util
     spec = importlib.util.spec_from_file_location("sd_oracle_pipeline_m", os.path.join(ROOT, "oracle", "pipeline.py"))
     P = importlib.util.module_from_spec(spec); spec.loader.exec_module(P)
@@ -101,31 +122,61 @@ def test_cpp_system_track_matches_frame_oracle(gpu, fe, orc, synth, tmp_path, ki
     libdir = os.path.join(ROOT, "slam-dynamic_amd", "lib")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "slam-dynamic_amd", "host"),
                            os.path.join(ROOT, "tests/cpp/frame_mirror_main.cpp"), "-L" + libdir, "-lsd_frontend", "-Wl,-rpath," + libdir, "-o", exe])
-    stereo = kind == "stereo"
+    variant = kind
+    stereo = kind in ("stereo", "stereo-moving")
+    mono = kind == "mono"
+    ext = kind in ("stereo-moving", "rgbd-rgba-f32")
+    f32d = kind == "rgbd-rgba-f32"
     cfg = synth.KITTI_STEREO if stereo else (synth.TUM1 if kind == "rgbd-tum1" else synth.TUM3)      # TUM1: Camera.k1 != 0, mvKeysUn != mvKeys
-    kind = "stereo" if stereo else "rgbd"
-    T = 5 if stereo else 9
-    ch = 1 if stereo else 3
+    kind = "stereo" if stereo else ("mono" if mono else "rgbd")
+    T = (8 if ext else 5) if stereo else (4 if mono else 9)
+    ch = 1 if stereo else (4 if f32d else 3)
     W, H = cfg["width"], cfg["height"]
-    o = P.SequenceOracle(orc, cfg, P.SENSOR_STEREO if stereo else P.SENSOR_RGBD)
-    blob, ref = [], []
+    o = P.SequenceOracle(orc, cfg, P.SENSOR_STEREO if stereo else (P.SENSOR_MONOCULAR if mono else P.SENSOR_RGBD), ini_features=2 * cfg["n_features"] if mono else 0)
+    blob, ref, poses = [], [], []
+    V = _yaw(cfg)
+    Tcw = np.eye(4, dtype=np.float32)
     for t in range(T):
         ts = t / cfg["fps"]
         rows = synth.boxes_for_frame(71, t, cfg)
-        boxes = synth.rows_to_rects(rows) if t != 1 else None          # frame 1 goes through the overload without boxes
+        boxes = synth.rows_to_rects(rows) if (t != 1 and not mono) else None          # frame 1 goes through the overload without boxes
         if stereo:
             a, b, _ = synth.stereo_frame_dyn(71, t, cfg); extra = b""
+        elif mono:
+            a = synth.rgbd_frame_dyn(71, t, cfg)[0]; b = None; extra = b""
         else:
             a, b, _ = synth.rgbd_frame_dyn(71, t, cfg); extra = synth.mask_from_boxes(rows, W, H).tobytes()
-        blob.append(np.array([ts], np.float64).tobytes() + np.array([-1 if boxes is None else len(boxes)], np.int32).tobytes() +
-                    (b"" if boxes is None else boxes.tobytes()) + a.tobytes() + b.tobytes() + extra)
-        ref.append(o.track(a, b, boxes, ts))
+            if f32d:
+                a = np.ascontiguousarray(np.concatenate([a, np.full(a.shape[:2] + (1,), 200, np.uint8)], -1))
+                b = b.astype(np.float32)                               # CV_32F, still in DepthMapFactor units: convertTo scales it
+        head = b""
+        state = None
+        if ext:                                                        # the pose side: NOT_INITIALIZED, then OK; a velocity from the third frame on
+            mstate, hv = (1, 0) if t == 0 else (2, 1 if t >= 2 else 0)
+            if variant == "stereo-moving" and t == 5:
+                mstate = 3                                             # LOST on frame 5: no TrackHomo
+            if hv:
+                Tcw = P.pose_mul(V, Tcw)                               # mCurrentFrame.SetPose(mVelocity*mLastFrame.mTcw) (Tracking.cc:982)
+            head = np.array([mstate, hv], np.int32).tobytes() + V.tobytes()
+            state = (1 if mstate in (2, 3) else 0) | (2 if (mstate == 2 and hv) else 0)
+        F = o.track(a, b, boxes, ts, Tcw=Tcw if ext else None, Twc=P.pose_inverse(Tcw) if ext else None, state=state)
+        tail = b""
+        if ext:
+            if variant == "stereo-moving":
+                xw, fl = _commit(t, F, 71)
+                o.set_mappoints(xw, fl)
+                tail = np.array([len(fl)], np.int32).tobytes() + xw.tobytes() + fl.tobytes()
+            else:
+                tail = np.array([-1], np.int32).tobytes()
+        blob.append(head + np.array([ts], np.float64).tobytes() + np.array([-1 if boxes is None else len(boxes)], np.int32).tobytes() +
+                    (b"" if boxes is None else boxes.tobytes()) + a.tobytes() + (b"" if b is None else b.tobytes()) + extra + tail)
+        ref.append(F); poses.append(Tcw.copy())
     inp = tmp_path / "in.bin"; out = tmp_path / "out.bin"
     inp.write_bytes(b"".join(blob))
     subprocess.check_call([exe, kind, str(W), str(H), str(ch), str(T), str(inp), str(out), repr(float(np.float32(cfg["fx"]))), repr(float(np.float32(cfg["fy"]))),
                            repr(float(np.float32(cfg["cx"]))), repr(float(np.float32(cfg["cy"]))), repr(float(np.float32(cfg["bf"]))), str(cfg["fps"]),
                            str(cfg.get("depth_map_factor", 1.0)), str(cfg["n_features"]), str(cfg["ini_th_fast"])] +
-                          [repr(float(np.float32(cfg.get(k, 0.0)))) for k in ("k1", "k2", "p1", "p2", "k3")])
+                          [repr(float(np.float32(cfg.get(k, 0.0)))) for k in ("k1", "k2", "p1", "p2", "k3")] + [str(int(ext)), str(int(f32d))])
     buf = out.read_bytes()
     off = 0
     ran = 0
@@ -137,6 +188,8 @@ def test_cpp_system_track_matches_frame_oracle(gpu, fe, orc, synth, tmp_path, ki
         assert g["kp"].tobytes() == F.kp.tobytes() and g["kpUn"].tobytes() == F.kpUn.tobytes() and np.array_equal(g["desc"], F.desc), tag + ": mvKeys / mvKeysUn / mDescriptors"
         assert np.array_equal(g["ur"].view(np.uint32), F.ur.view(np.uint32)) and np.array_equal(g["dep"].view(np.uint32), F.dep.view(np.uint32)), tag
         assert np.array_equal(g["cell"], F.cells), tag + ": mGrid"
+        if ext:
+            assert g["Tcw"].tobytes() == poses[t].tobytes(), tag + ": the pose prior mVelocity * mLastFrame.mTcw"
         for j, bx in enumerate(g["boxes"]):
             assert np.array_equal(bx["rect"], F.objects[j]) and (bx["idx"], bx["status"], bx["omit"]) == (F.box_idx[j], F.box_status[j], F.omit[j]), tag
             assert np.array_equal(bx["vel"], F.velocity[j]), tag
@@ -145,4 +198,8 @@ def test_cpp_system_track_matches_frame_oracle(gpu, fe, orc, synth, tmp_path, ki
             assert bx["kpUn"].tobytes() == F.dyn_kpUn[it].tobytes(), tag + ": mvdynKeysUn"
             assert np.array_equal(bx["ur"].view(np.uint32), F.dyn_ur[it].view(np.uint32)) and np.array_equal(bx["dep"].view(np.uint32), F.dyn_dep[it].view(np.uint32)), tag
         ran += F.track_flag != 0
-    assert off == len(buf) and ran >= 1, "the dynamic block must have run at least once"
+    assert off == len(buf) and (ran >= 1 or mono), "the dynamic block must have run at least once"
+    if variant == "stereo-moving":
+        assert ref[5].track_flag == 0 and ref[6].track_flag != 0, "LOST on frame 5 (no TrackHomo), tracking again on frame 6"
+    if mono:
+        assert ref[0].N > 1.5 * cfg["n_features"] and ref[1].N > 1.5 * cfg["n_features"] and ref[2].N < 1.2 * cfg["n_features"], "mpIniORBextractor on the first two frames"

@@ -89,16 +89,21 @@ def _check_frame(fe, trk, lane, R, F, tag):
         assert nm == F.n_last_matches and np.array_equal(m[:F.N], F.last_match), tag + ": mvpMapPoints after SearchByProjection(cur, last)"
 
 
-def _run_chain(fe, orc, synth, cfg, sensor, lanes, n_frames, channels):
-    """lanes: list of dict(frames=callable t -> (im, im2), boxes=callable t -> (k,4) array or None, stamps=list)."""
+def _run_chain(fe, orc, synth, cfg, sensor, lanes, n_frames, channels, depth_f32=False, ini_features=0):
+    """lanes: list of dict(frames=callable t -> (im, im2), boxes=callable t -> (k,4) array or None, stamps=list) with the optional hooks of a
+    caller that owns SLAM state: pose = callable t -> Tcw (4x4 f32; the pose prior mVelocity * mLastFrame.mTcw), state = callable t -> int
+    (bit0 initialised, bit1 mState == OK && !mVelocity.empty()) -- all lanes or none --, mappoints = callable (t, FrameState) -> (xw, flags)
+    or None: the MapPoints the pose side commits for the frame just tracked."""
     import torch
     P = _pipe()
     S = len(lanes)
     W, H = cfg["width"], cfg["height"]
     ex = fe.ORBextractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
-    trk = fe.Tracker(ex, cfg, sensor, S, channels=channels, rgb_order=True, track_last=True)
-    oracles = [P.SequenceOracle(orc, cfg, sensor, rgb_order=True, track_last=True) for _ in lanes]
-    stats = dict(flag1=0, flag2=0, flag0=0, static=0, dynamic=0, status2=0, appended=0, refs=[])
+    trk = fe.Tracker(ex, cfg, sensor, S, channels=channels, rgb_order=True, track_last=True, depth_f32=depth_f32, ini_features=ini_features)
+    oracles = [P.SequenceOracle(orc, cfg, sensor, rgb_order=True, track_last=True, ini_features=ini_features) for _ in lanes]
+    stats = dict(flag1=0, flag2=0, flag0=0, static=0, dynamic=0, status2=0, appended=0, refs=[], n_track=[], n_last=[], N=[], flags={})
+    with_pose = "pose" in lanes[0]
+    with_state = "state" in lanes[0]
     try:
         for t in range(n_frames):
             ims = [ln["frames"](t) for ln in lanes]
@@ -112,14 +117,32 @@ def _run_chain(fe, orc, synth, cfg, sensor, lanes, n_frames, channels):
                 d_img = torch.from_numpy(np.stack([a for a, _ in ims])).cuda()
                 ipl = 1
                 if sensor == fe.SENSOR_RGBD:
-                    d_depth = torch.from_numpy(np.stack([c for _, c in ims]).view(np.int16)).cuda()
+                    dd = np.stack([c for _, c in ims])
+                    d_depth = torch.from_numpy(dd if depth_f32 else dd.view(np.int16)).cuda()
+            Tcw = Twc = None
+            if with_pose:
+                Tcw = np.stack([np.asarray(ln["pose"](t), np.float32).reshape(4, 4) for ln in lanes])
+                Twc = np.stack([P.pose_inverse(T) for T in Tcw])
+            states = [ln["state"](t) for ln in lanes] if with_state else [None] * S
+            trk.set_state(states if with_state else None)
             res = trk.track(d_img.data_ptr(), W * channels, W * H * channels, ts, boxes=bxs if sensor != fe.SENSOR_MONOCULAR else None,
-                            d_depth=d_depth.data_ptr() if d_depth is not None else 0, depth_stride=W, depth_pitch=W * H)
+                            d_depth=d_depth.data_ptr() if d_depth is not None else 0, depth_stride=W, depth_pitch=W * H, Tcw=Tcw, Twc=Twc)
+            commit_x, commit_f = [None] * S, [None] * S
             for l, ln in enumerate(lanes):
-                F = oracles[l].track(ims[l][0], ims[l][1], bxs[l], ts[l])
+                F = oracles[l].track(ims[l][0], ims[l][1], bxs[l], ts[l], Tcw=Tcw[l] if with_pose else None, Twc=Twc[l] if with_pose else None, state=states[l])
                 _check_frame(fe, trk, l, res[l], F, "frame %d lane %d" % (t, l))
+                stats["n_track"].append(F.n_track_matches); stats["n_last"].append(F.n_last_matches); stats["N"].append(F.N)
+                mp = ln["mappoints"](t, F) if "mappoints" in ln else None
+                if mp is not None:
+                    commit_x[l], commit_f[l] = mp
+                    oracles[l].set_mappoints(mp[0], mp[1])
+            if any(x is not None for x in commit_x):
+                trk.set_mappoints(commit_x, commit_f)
+            for l, ln in enumerate(lanes):
+                F = oracles[l].mLastFrame
                 stats["flag%d" % F.track_flag] += 1 if F.ref_id >= 0 else 0
                 if F.ref_id >= 0: stats["refs"].append((t, l, F.ref_id))
+                stats["flags"][(t, l)] = F.track_flag
                 if F.separate_ret == 1: stats["static"] += 1
                 if F.separate_ret == 0: stats["dynamic"] += 1
                 stats["status2"] += int((F.box_status == 2).sum())
@@ -147,6 +170,77 @@ def test_stereo_chain_kitti(gpu, fe, orc, synth):
     st = _run_chain(fe, orc, synth, cfg, fe.SENSOR_STEREO, lanes, T, channels=1)
     assert st["flag1"] + st["flag2"] >= 5, "TrackHomo must succeed on the static-background lanes: %r" % st
     assert st["static"] >= 3 and st["appended"] > 0, "Separate must re-admit static boxes somewhere: %r" % st
+
+
+def _yaw_pose(cfg, t, per_frame_px=3.0):
+    """The pose prior of a camera that yaws so that the image moves `per_frame_px` px per frame (the synthetic sequences shift 3 px per frame and
+    zoom by 1 %): Rcw = R_y(a t), a = per_frame_px / fx, no translation.  With it SearchByProjection's windows sit where the features went; with
+    the identity they are up to 9 px (stereo, three frames back) off."""
+    a = float(per_frame_px) * t / float(cfg["fx"])
+    T = np.eye(4, dtype=np.float32)
+    T[0, 0] = np.float32(np.cos(a)); T[0, 2] = np.float32(np.sin(a)); T[2, 0] = np.float32(-np.sin(a)); T[2, 2] = np.float32(np.cos(a))
+    return T
+
+
+def _commit_points(t, F, seed):
+    """What a pose side would leave in mCurrentFrame.mvpMapPoints: most stereo points kept (slightly moved by its optimisation), some culled as
+    outliers, some marked as observed by key frames, and a few key points WITHOUT depth given a map point (matched from the local map)."""
+    rng = np.random.default_rng(1000 * seed + t)
+    xw = F.xw.copy(); fl = F.mp_flags.copy()
+    n = len(fl)
+    xw += rng.normal(0, 0.01, xw.shape).astype(np.float32)
+    fl[rng.random(n) < 0.15] = 0
+    fl[(rng.random(n) < 0.4) & (fl != 0)] |= 2
+    extra = (F.mp_flags == 0) & (rng.random(n) < 0.2)
+    xw[extra] = rng.uniform(-20, 20, (int(extra.sum()), 3)).astype(np.float32) + np.array([0, 0, 30], np.float32)
+    fl[extra] = 1
+    return xw, fl
+
+
+def test_stereo_chain_moving_camera_pose_state_mappoints(gpu, fe, orc, synth):
+    """The SLAM state a live back end owns, through the Frame-level boundary (Tracking.cc:982 `SetPose(mVelocity*mLastFrame.mTcw)`, :998-1010 the
+    reference frame's MapPoints, :971 `mState==OK && !mVelocity.empty()`): a yawing camera's pose prior per frame on both lanes; lane 0 with an
+    explicit state that loses tracking on frame 5 (no TrackHomo there); lane 1 with the pose side's own MapPoints committed after every frame --
+    every frame of both lanes bit for bit against the frame-level oracle fed the same state."""
+    cfg = synth.KITTI_STEREO
+    T = 8
+    stamps = [0.1 * t for t in range(T)]
+    rect = lambda seq, t: synth.rows_to_rects(synth.boxes_for_frame(seq, t, cfg))
+    st0 = lambda t: 0 if t == 0 else (1 if t in (1, 5) else 3)
+    st1 = lambda t: 0 if t == 0 else (1 if t == 1 else 3)
+    lanes = [
+        dict(frames=lambda t: synth.stereo_frame_dyn(24, t, cfg)[:2], boxes=lambda t: rect(24, t), stamps=stamps, pose=lambda t: _yaw_pose(cfg, t), state=st0),
+        dict(frames=lambda t: synth.stereo_frame_dyn(25, t, cfg)[:2], boxes=lambda t: rect(25, t), stamps=stamps, pose=lambda t: _yaw_pose(cfg, t), state=st1,
+             mappoints=lambda t, F: _commit_points(t, F, 25)),
+    ]
+    st = _run_chain(fe, orc, synth, cfg, fe.SENSOR_STEREO, lanes, T, channels=1)
+    assert st["flags"][(5, 0)] == 0 and st["flags"][(5, 1)] != 0, "lane 0 is told tracking was lost on frame 5: no TrackHomo there: %r" % st["flags"]
+    assert st["flag1"] + st["flag2"] >= 6, "TrackHomo must succeed under the pose prior: %r" % st
+    assert max(v for v in st["n_track"] if v is not None) > 200, "the pose prior must put the windows on the features: %r" % st["n_track"]
+
+
+def test_rgbd_chain_rgba_input_f32_depth(gpu, fe, orc, synth):
+    """The inputs GrabImageRGBD accepts beside BGR + CV_16U (Tracking.cc:187-200 CV_RGBA2GRAY / CV_BGRA2GRAY, :271-272 a CV_32F depth map): 4-channel
+    colour images and float depth, once in metres with DepthMapFactor 1 (passed through) and once still to be scaled (factor 5000), with the pose
+    prior of a yawing camera -- bit for bit against the frame-level oracle."""
+    T = 6
+    for dmf in (1.0, 5000.0):
+        cfg = dict(synth.TUM3); cfg["depth_map_factor"] = dmf
+        stamps = [t / 30.0 for t in range(T)]
+
+        def frames(seq):
+            def f(t):
+                rgb, depth, _ = synth.rgbd_frame_dyn(seq, t, synth.TUM3)
+                rgba = np.concatenate([rgb, np.full(rgb.shape[:2] + (1,), 7 * t + 1, np.uint8)], -1)
+                d = depth.astype(np.float32) if dmf != 1.0 else (depth.astype(np.float32) / np.float32(5000.0)).astype(np.float32)
+                return np.ascontiguousarray(rgba), d
+            return f
+
+        rect = lambda seq, t: synth.rows_to_rects(synth.boxes_for_frame(seq, t, cfg))
+        lanes = [dict(frames=frames(41), boxes=lambda t: rect(41, t), stamps=stamps, pose=lambda t: _yaw_pose(cfg, t)),
+                 dict(frames=frames(42), boxes=lambda t: None if t == 1 else rect(42, t), stamps=stamps, pose=lambda t: _yaw_pose(cfg, t))]
+        st = _run_chain(fe, orc, synth, cfg, fe.SENSOR_RGBD, lanes, T, channels=4, depth_f32=True)
+        assert max(st["N"]) > 500 and max(v for v in st["n_last"] if v is not None) > 100, "%r" % st
 
 
 def _sparse_rgbd(synth, cfg, k):
@@ -215,6 +309,24 @@ def test_mono_chain_tum3(gpu, fe, orc, synth):
     T = 3
     lanes = [dict(frames=lambda t: (synth.rgbd_frame(33, t, cfg)[0], None), boxes=lambda t: None, stamps=[t / 30.0 for t in range(T)])]
     _run_chain(fe, orc, synth, cfg, fe.SENSOR_MONOCULAR, lanes, T, channels=3)
+
+
+def test_mono_chain_ini_extractor(gpu, fe, orc, synth):
+    """GrabImageMonocular (Tracking.cc:316-343): mpIniORBextractor (2 * nFeatures, Tracking.cc:127-128) while the lane is not initialised, the
+    regular extractor afterwards.  Lane 0 follows the automatic rule (frames 0, 1), lane 1 is told by its caller that initialisation took four
+    frames; the second tracker run mixes the two kinds of lanes in one call."""
+    cfg = dict(synth.TUM3)
+    T = 6
+    stamps = [t / 30.0 for t in range(T)]
+    fr = lambda seq: (lambda t: (synth.rgbd_frame(seq, t, cfg)[0], None))
+    st = _run_chain(fe, orc, synth, cfg, fe.SENSOR_MONOCULAR, [dict(frames=fr(35), boxes=lambda t: None, stamps=stamps)], 4, channels=3, ini_features=2 * cfg["n_features"])
+    nf = cfg["n_features"]             # (the quadtree may return a few more than its quota)
+    assert st["N"][0] > 1.5 * nf and st["N"][1] > 1.5 * nf and st["N"][2] < 1.2 * nf and st["N"][3] < 1.2 * nf, "frames 0, 1 come from the 2 * nFeatures extractor: %r" % st["N"]
+    lanes = [dict(frames=fr(36), boxes=lambda t: None, stamps=stamps, state=lambda t: 0 if t < 2 else 3),
+             dict(frames=fr(37), boxes=lambda t: None, stamps=stamps, state=lambda t: 0 if t < 4 else 3)]
+    st = _run_chain(fe, orc, synth, cfg, fe.SENSOR_MONOCULAR, lanes, T, channels=3, ini_features=2 * cfg["n_features"])
+    N = st["N"]          # [t0 l0, t0 l1, t1 l0, ...]
+    assert N[2 * 3] < 1.2 * nf and N[2 * 3 + 1] > 1.5 * nf, "frame 3: lane 0 is initialised, lane 1 is not: %r" % N
 
 
 @pytest.mark.parametrize("kind,seed", [("stereo", 11), ("rgbd", 12)])

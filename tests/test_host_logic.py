@@ -86,15 +86,17 @@ def test_result_record_layout_roundtrip(fe):
     """The per-frame record a rank gathers to rank 0 (N, keypoints, descriptors, uRight, depth, boxes / box_status, N_s)."""
     cap = 2064
     lay = bench.record_layout(cap, fe.FRAME_BOXES_BYTES)
-    assert lay["_stride"] % 16 == 0 and lay["kp"][1] == cap * 28 and lay["fb"][1] == 1560
+    M = fe.MAXB                                   # SD_MAX_BOXES
+    FB = 16 + M * 32 + 3 * M * 4 + (M + 1) * 4 + 4    # sizeof(sd_frame_boxes)
+    assert lay["_stride"] % 16 == 0 and lay["kp"][1] == cap * 28 and lay["fb"][1] == FB == 3096
     rec = np.zeros(lay["_stride"], np.uint8)
     N, Ns = 1800, 1750
     rec[lay["count"][0]:lay["count"][0] + 4] = np.array([N], np.int32).view(np.uint8)
-    fb = np.zeros(1560, np.uint8)
+    fb = np.zeros(FB, np.uint8)
     fb[:16] = np.array([2, 2000, Ns, 250], np.int32).view(np.uint8)
-    fb[16 + 1024:16 + 1024 + 8] = np.array([7, 9], np.int32).view(np.uint8)
-    fb[16 + 1024 + 128:16 + 1024 + 136] = np.array([2, -1], np.int32).view(np.uint8)
-    rec[lay["fb"][0]:lay["fb"][0] + 1560] = fb
+    fb[16 + 32 * M:16 + 32 * M + 8] = np.array([7, 9], np.int32).view(np.uint8)
+    fb[16 + 32 * M + 4 * M:16 + 32 * M + 4 * M + 8] = np.array([2, -1], np.int32).view(np.uint8)
+    rec[lay["fb"][0]:lay["fb"][0] + FB] = fb
     ur = np.arange(cap, dtype=np.float32)
     rec[lay["uright"][0]:lay["uright"][0] + cap * 4] = ur.view(np.uint8)
     d = bench.decode_record(rec, lay, cap)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 output merged under gpurun_out/ into the small files committed under profiles/.
 
-  python tools/summarize_prof.py <round-tag> <kernel-trace-dir> [<fetch-pmc-dir> <write-pmc-dir> <batch_images>]
+  python tools/summarize_prof.py <round-tag> <kernel-trace-dir> [<fetch-pmc-dir> <write-pmc-dir> <batch_images> [<workload> [<sq-pmc-dir>]]]
 
 Writes profiles/<tag>_kernel_stats.csv (our kernels + copies, torch template names shortened) and, when the two
 PMC passes are given, profiles/<tag>_pmc.csv plus profiles/pmc_traffic.json (read by bench.py):
@@ -50,5 +50,31 @@ if len(sys.argv) >= 6:
             hb = int((2 * fa + wa) * 1024)
             w.writerow([k, len(fe), "%.1f" % fa, "%.1f" % wa, hb])
             traffic[k] = {"hbm_bytes_per_launch": hb, "batch_images": int(sys.argv[5]), "profile": tag + "_pmc.csv"}
-    json.dump(traffic, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
-    print("wrote", tag + "_pmc.csv, pmc_traffic.json")
+    workload = sys.argv[6] if len(sys.argv) >= 7 else "stereo-yolo"
+    path = os.path.join(root, "profiles", "pmc_traffic.json")
+    try:
+        allw = json.load(open(path))
+        if allw and not all(isinstance(v, dict) and all(isinstance(x, dict) for x in v.values()) for v in allw.values()):
+            allw = {}
+        if any("hbm_bytes_per_launch" in v for v in allw.values()):          # the flat round-2 layout
+            allw = {}
+    except Exception:
+        allw = {}
+    allw[workload] = traffic                                               # bench.py reads the table of the workload it runs
+    json.dump(allw, open(path, "w"), indent=1, sort_keys=True)
+    print("wrote", tag + "_pmc.csv, pmc_traffic.json[%s]" % workload)
+    if len(sys.argv) >= 8:                                                 # SQ instruction counters (their own pass)
+        f = glob.glob(os.path.join(sys.argv[7], "**", "*_counter_collection.csv"), recursive=True)[0]
+        sq = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+            if k.startswith("k_"):
+                sq[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        with open(os.path.join(root, "profiles", tag + "_pmc_sq.csv"), "w", newline="") as fo:
+            w = csv.writer(fo)
+            names = sorted({c for v in sq.values() for c in v})
+            w.writerow(["Kernel", "Launches"] + [n + "_avg" for n in names])
+            for k in sorted(sq):
+                n = max(len(v) for v in sq[k].values())
+                w.writerow([k, n] + ["%.0f" % (sum(sq[k][c]) / max(1, len(sq[k][c]))) for c in names])
+        print("wrote", tag + "_pmc_sq.csv")
