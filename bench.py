@@ -19,8 +19,10 @@ quoted on:
                 rank 0 broadcasts over RCCL at start-up
   tum-mask      BASELINE configs[3]: TUM3 640x480 RGB-D, DepthMapFactor 5000, mask + boxes, cull + dense back-projection
                 of the unmasked pixels (pointcloudmapping.cc:59-103) -- the consumer of the semantic mask
-  kitti-batch   BASELINE configs[4]: 11 sequences x 256 stereo frames with boxes, WHOLE sequences assigned to ranks
-                (longest first); strong scaling
+  kitti-batch   BASELINE configs[4]: 11 sequences x 256 colour stereo frames, WHOLE sequences assigned to ranks (longest first), the
+                stereo-yolo chain on every frame; detector + extraction + stereo matching batched over consecutive frames of a
+                rank's sequences (a sequence cannot be cut: boxTrack's ids depend on its whole history), the recurrence frame by
+                frame; strong scaling
 The non-default single-GPU workloads are also run (short) by the default invocation and reported under "extra".
 
 Multi-GPU: one process per GPU.  `python bench.py --gpus N` without a torch.distributed environment starts the N ranks
@@ -413,24 +415,11 @@ class Workload:
         self.ipl = 2 if self.kind == "stereo" else 1
         cfg = self.cfg
         self.W, self.H = cfg["width"], cfg["height"]
-        self.strong = name == "kitti-batch"
-        if self.strong:                              # BASELINE configs[4]: 11 sequences x 256 frames, whole sequences per rank
-            n_seq, length = 11, args.kitti_frames
-            owner = shard_sequences(n_seq, [length] * n_seq, world)
-            self.my_sequences = [s for s in range(n_seq) if owner[s] == rank]
-            self.idle = len(self.my_sequences) == 0
-            # every rank runs the same number of lanes (the gathered records have one size): a rank with fewer sequences repeats one, uncounted
-            self.S = max(sum(1 for s in range(n_seq) if owner[s] == r) for r in range(world))
-            while len(self.my_sequences) < self.S:
-                self.my_sequences.append(self.my_sequences[-1] if self.my_sequences else 0)
-            self.total_frames_all_ranks = n_seq * length
-            self.T = length
-            self.distinct = self.S
-        else:
-            self.S = args.lanes
-            self.my_sequences = list(range(self.S))
-            self.idle = False
-            self.distinct = min(args.distinct, self.S)
+        self.strong = False                       # kitti-batch (configs[4]) is SequenceBatchWorkload
+        self.S = args.lanes
+        self.my_sequences = list(range(self.S))
+        self.idle = False
+        self.distinct = min(args.distinct, self.S)
         self.ex = fe.ORBextractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
         self.trk = fe.Tracker(self.ex, cfg, self.sensor, self.S, channels=3, rgb_order=True, track_last=True)
         self.batch = self.trk.batch
@@ -472,7 +461,7 @@ class Workload:
             self.depth_factor = float(np.float32(1.0) / np.float32(cfg["depth_map_factor"]))
         self.frames = []          # per timestep: dict(images, depth, boxes, n_boxes, stamps)
         self.n_total = 0          # time steps this workload will run (prepare() adds to it)
-        self.max_resident = self.T if self.strong else 48     # time steps generated and parked in HBM; longer runs walk them back and forth
+        self.max_resident = 48     # time steps generated and parked in HBM; longer runs walk them back and forth
         self.t = 0
         self.n_boxes_seen = []
         self.max_det_boxes = 0
@@ -485,7 +474,7 @@ class Workload:
         self.n_total += n_steps
         base = len(self.frames)
         for t in range(base, min(base + n_steps, self.max_resident)):
-            per = [synth_timestep(synth, self.kind, cfg, (10 + self.my_sequences[d]) if self.strong else (10 + 37 * self.rank + d), t) for d in range(D)]
+            per = [synth_timestep(synth, self.kind, cfg, 10 + 37 * self.rank + d, t) for d in range(D)]
             img = torch.from_numpy(np.stack([p["images"] for p in per])).to(self.dev)                  # [D, ipl, H, W, 3]
             img = img.repeat((reps, 1, 1, 1, 1))[:S].contiguous()
             dep = None
@@ -580,38 +569,220 @@ class Workload:
                 d_.close()
 
 
+def block_plan(T, S, block_frames, resident):
+    """kitti-batch: (D, [(t0, n, [resident frame index of t0 .. t0 + n - 1])]) -- D = frames per lane and block so that S * D >= block_frames, the T
+    frames of a sequence walked back and forth over `resident` generated ones."""
+    D = max(1, min(T, -(-block_frames // max(1, S))))
+    P = min(resident, T)
+    return D, [(t0, min(D, T - t0), [pingpong_index(t, P) for t in range(t0, min(t0 + D, T))]) for t0 in range(0, T, D)]
+
+
+class SequenceBatchWorkload:
+    """BASELINE configs[4] ("kitti-batch"): 11 KITTI stereo sequences x T frames, WHOLE sequences assigned to ranks (longest first), the f32
+    detector in the loop.  A rank owns S sequences (11 at N = 1, 1-2 at N = 8): too few lanes to fill the chip frame by frame, and a sequence
+    cannot be cut into independently processed chunks -- Frame::boxTrack's ids (`max + 1`, Frame.cc:545-550) depend on the whole history, so
+    no finite halo reproduces them.  Instead the frame is split: its history-free half (cvtColor, ORB extraction of both eyes, stereo
+    matching: sd_tracker_prefetch) and the detector run on D consecutive frames of every owned sequence in ONE batch (S * D >= 64 frames),
+    one block ahead on their own streams; the recurrence (boxTrack -> firstSeparate -> TrackHomo -> Separate -> UpdateFrame -> match vs
+    mLastFrame) then runs frame by frame on the prefetched results (sd_tracker_track with no image).  Every frame's result is the
+    sequential one (tests/test_gpu_pipeline.py::test_time_batched_prefetch_equals_sequential)."""
+
+    def __init__(self, args, rank, world, dev, pkg, dist, detector=True):
+        import torch
+        self.torch = torch
+        fe, synth = pkg.frontend, pkg.synth
+        self.fe, self.synth, self.pkg, self.dev, self.rank, self.world = fe, synth, pkg, dev, rank, world
+        self.name, self.kind, self.cfg, self.sensor, self.ipl = "kitti-batch", "stereo", synth.KITTI_STEREO, fe.SENSOR_STEREO, 2
+        self.detector, self.det_prec, self.with_boxes, self.strong, self.bow, self.cloud = detector, "f32", True, True, False, False
+        cfg = self.cfg
+        self.W, self.H = cfg["width"], cfg["height"]
+        n_seq, self.T = 11, args.kitti_frames
+        owner = shard_sequences(n_seq, [self.T] * n_seq, world)
+        self.my_sequences = [q for q in range(n_seq) if owner[q] == rank]
+        self.n_owned = len(self.my_sequences)
+        # every rank runs the same number of lanes (the gathered records have one size): a rank with fewer sequences repeats one, uncounted
+        self.S = max(sum(1 for q in range(n_seq) if owner[q] == r) for r in range(world))
+        while len(self.my_sequences) < self.S:
+            self.my_sequences.append(self.my_sequences[-1] if self.my_sequences else 0)
+        self.total_frames_all_ranks = n_seq * self.T
+        self.D, self.plan = block_plan(self.T, self.S, args.block_frames, 24)    # frames per lane and block: S * D >= --block-frames (64)
+        self.distinct = self.S
+        self.ex = fe.ORBextractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+        self.trk = fe.Tracker(self.ex, cfg, self.sensor, self.S, channels=3, rgb_order=True, track_last=True, lookahead=self.D)
+        self.batch = self.trk.batch
+        self.main = torch.cuda.current_stream()
+        self.pre_stream = torch.cuda.Stream(device=dev)
+        self.det = None
+        self.max_det_boxes = 0
+        if detector:
+            layers, anchors = pkg.yolo.v3_layers()
+            self.det = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=self.S * self.D, precision="f32")
+            self.det.load_weights(pkg.yolo.synth_weights(layers, seed=3)[0])
+            self.det_stream = torch.cuda.Stream(device=dev)
+            n, M = self.S * self.D, fe.MAXB
+            self.det_dev = [dict(b=torch.zeros((n, M, 4), dtype=torch.float64, device=dev), c=torch.zeros((n, M), dtype=torch.int32, device=dev),
+                                 f=torch.zeros((n, M), dtype=torch.float32, device=dev), n=torch.zeros((n,), dtype=torch.int32, device=dev)) for _ in range(2)]
+            self.det_host = [dict(b=torch.zeros((n, M, 4), dtype=torch.float64).pin_memory(), n=torch.zeros((n,), dtype=torch.int32).pin_memory()) for _ in range(2)]
+            self.det_ev = [torch.cuda.Event() for _ in range(2)]
+        self.blocks = []
+
+    def prepare(self):
+        resident = 24
+        """Generate `resident` time steps of every owned sequence on the host, walk them back and forth up to T frames (consecutive frames stay
+        consecutive views, time stamps keep increasing) and park the frames in HBM block by block in frame-major order [D, S, 2, H, W, 3]."""
+        torch, synth, cfg = self.torch, self.synth, self.cfg
+        P = min(resident, self.T)
+        per_seq = [[synth_timestep(synth, "stereo", cfg, 10 + q, t) for t in range(P)] for q in self.my_sequences[:max(1, self.n_owned)]]
+        while len(per_seq) < self.S:
+            per_seq.append(per_seq[-1])
+        dev_frames = [torch.from_numpy(np.stack([per_seq[l][p]["images"] for l in range(self.S)])).to(self.dev) for p in range(P)]      # [S, 2, H, W, 3] each
+        self.given_boxes = [[per_seq[l][p]["boxes"] for l in range(self.S)] for p in range(P)]
+        self.P = P
+        for t0, n, idx in self.plan:
+            self.blocks.append(dict(t0=t0, n=n, idx=idx, images=torch.stack([dev_frames[i] for i in idx]).contiguous()))
+        del dev_frames
+
+    def enqueue(self, bi):
+        """Detector (forward + NMS on the device + download) and the front half of block bi, each on its own stream; nothing waits."""
+        torch = self.torch
+        B = self.blocks[bi]
+        W, H, S = self.W, self.H, self.S
+        n = B["n"] * S
+        if self.det is not None:
+            k = bi & 1
+            ds = self.det_stream.cuda_stream
+            d = self.det_dev[k]
+            self.det.forward_device(B["images"].data_ptr(), W, H, W * 3, 2 * W * H * 3, n, 0.5, ds)
+            self.det.boxes_device(n, W, H, d["b"].data_ptr(), d["c"].data_ptr(), d["f"].data_ptr(), d["n"].data_ptr(), stream=ds)
+            with torch.cuda.stream(self.det_stream):
+                self.det_host[k]["b"][:n].copy_(d["b"][:n], non_blocking=True)
+                self.det_host[k]["n"][:n].copy_(d["n"][:n], non_blocking=True)
+                self.det_ev[k].record(self.det_stream)
+        self.trk.prefetch(B["images"].data_ptr(), W * 3, W * H * 3, B["n"], stream=self.pre_stream.cuda_stream)
+
+    def run(self, n_blocks=None, after_step=None):
+        """All (or the first n_blocks) blocks: block b + 1 is enqueued before block b's frames are tracked.  -> the last step's lane results."""
+        fe = self.fe
+        nb = len(self.blocks) if n_blocks is None else min(n_blocks, len(self.blocks))
+        W, H, S, M = self.W, self.H, self.S, self.fe.MAXB
+        res = None
+        self.enqueue(0)
+        for bi in range(nb):
+            if bi + 1 < nb:
+                self.enqueue(bi + 1)
+            B = self.blocks[bi]
+            if self.det is not None:
+                self.det_ev[bi & 1].synchronize()
+                nb_all = self.det_host[bi & 1]["n"].numpy()[:B["n"] * S]
+                if (nb_all < 0).any():
+                    raise RuntimeError("detector post-processing on the device exceeded its capacity")
+                self.max_det_boxes = max(self.max_det_boxes, int(nb_all.max()))
+                bx_all = self.det_host[bi & 1]["b"].numpy()
+            for k in range(B["n"]):
+                t = B["t0"] + k
+                if self.det is not None:
+                    boxes = bx_all[k * S:(k + 1) * S].copy(); n_boxes = nb_all[k * S:(k + 1) * S].astype(np.int32)
+                else:
+                    boxes = np.zeros((S, M, 4), np.float64); n_boxes = np.zeros(S, np.int32)
+                    for l in range(S):
+                        g = self.given_boxes[B["idx"][k]][l]; n_boxes[l] = len(g); boxes[l, :len(g)] = g
+                res = self.trk.track(0, W * 3, W * H * 3, np.full(S, t / float(self.cfg["fps"]), np.float64), boxes=boxes, n_boxes=n_boxes,
+                                     stream=self.main.cuda_stream)
+                if after_step is not None:
+                    after_step()
+        return res
+
+    def close(self):
+        self.trk.close()
+        if self.det is not None:
+            self.det.close()
+
+
+def run_sequence_batch(args, rank, world, dev, pkg, dist, detector=True):
+    """kitti-batch on this rank -> (result dict on rank 0, workload object)."""
+    import torch
+    fe = pkg.frontend
+    wl = SequenceBatchWorkload(args, rank, world, dev, pkg, dist, detector=detector)
+    wl.prepare()
+    batch, cap = wl.batch, wl.batch.cap
+    gatherer, rec_parts, layout = make_gatherer(wl, fe, dist, world, rank, dev)
+    after = (lambda: gatherer.submit(rec_parts)) if gatherer is not None else None
+    wl.run(n_blocks=1, after_step=after)               # warm-up: the first block, then every lane starts over
+    if gatherer is not None:
+        gatherer.finish()
+    wl.trk.reset()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = wl.run(after_step=after)
+    if gatherer is not None:
+        gatherer.finish()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = max_over_ranks(dist, time.perf_counter() - t0, dev)
+    out = None
+    if rank == 0:
+        frames = wl.total_frames_all_ranks
+        R = res[0]
+        out = {"workload": "kitti-batch", "value": round(frames / elapsed, 2), "ms_per_step": round(elapsed / wl.T * 1e3, 4), "steps": wl.T, "frames": frames,
+               "timed_s": round(elapsed, 3), "lanes_per_gpu": wl.S, "images_per_frame": 2, "frames_per_block_per_lane": wl.D, "blocks": len(wl.blocks),
+               "frames_in_one_extraction_batch": wl.S * wl.D, "distinct_frames_generated_per_sequence": wl.P,
+               "frames_truncated": 0, "max_detector_boxes_in_a_frame": wl.max_det_boxes if wl.det is not None else None,
+               "lane0_last_frame": {"N": R.N, "N_s": R.N_s, "N_d": R.N_d, "n_boxes": R.n_boxes, "track_flag": R.track_flag, "separate_ret": R.separate_ret,
+                                    "n_track_matches": R.n_track_matches, "n_last_matches": R.n_last_matches}}
+        if gatherer is not None:
+            rec = gatherer.recv[world - 1].view(wl.S, layout["_stride"])[0].cpu().numpy()
+            d = decode_record(rec, layout, cap)
+            out["gathered_record_check"] = {"from_rank": world - 1, "N": d["N"], "N_s": d["N_s"], "n_boxes": d["n_boxes"],
+                                            "bytes_per_frame": layout["_stride"], "finite_depths": int(np.isfinite(d["depth"]).sum())}
+    wl.close()
+    return out, wl
+
+
+def make_gatherer(wl, fe, dist, world, rank, dev):
+    """The per-step asynchronous gather of the lanes' result records to rank 0 (None without a process group)."""
+    if dist is None:
+        return None, None, None
+    import ctypes as C
+    batch = wl.batch
+    cap = batch.cap
+    kp_p, desc_p, cnt_p, _ = batch.results_device()
+    ur_p, dep_p = C.c_void_p(), C.c_void_p(); cc = C.c_int()
+    fe.check(fe.lib().sd_batch_stereo_device(batch.h, C.byref(ur_p), C.byref(dep_p), C.byref(cc)))
+    fb_bytes = fe.FRAME_BOXES_BYTES
+    fb_p = fe.batch_boxes_device(batch)
+    layout = record_layout(cap, fb_bytes)
+    stride = layout["_stride"]
+    S, ipl = wl.S, wl.ipl
+    gatherer = ResultGather(dist, world, rank, S * stride, dev)
+    stage2d = gatherer.stage.view(S, stride)
+    srcs = {"count": (cnt_p, 4), "fb": (fb_p, fb_bytes), "kp": (kp_p, cap * 28), "desc": (desc_p, cap * 32), "uright": (ur_p.value, cap * 4), "depth": (dep_p.value, cap * 4)}
+    rec_parts = []
+    for k in RECORD_FIELDS:
+        ptr, nbytes = srcs[k]
+        src = fe.as_torch_u8(ptr, S * ipl * nbytes).view(S * ipl, nbytes)[::ipl]        # the lanes' current (left) slots
+        o, n = layout[k]
+        rec_parts.append((stage2d[:, o:o + n], src))
+    return gatherer, rec_parts, layout
+
+
 def run_workload(name, args, rank, world, dev, pkg, dist, headline, vocab=None):
     """-> dict with the measured figures of one workload (rank 0 fills everything, other ranks only take part)."""
     import torch
     fe = pkg.frontend
+    if name == "kitti-batch":
+        return run_sequence_batch(args, rank, world, dev, pkg, dist, detector=not args.kitti_no_detector)
     wl = Workload(name, args, rank, world, dev, pkg, dist, vocab=vocab)
     steps, warm = (args.steps, args.warmup) if headline else (args.extra_steps, 1)
     prof_steps = 4 if (not args.no_profile and (headline or name in ("stereo", "rgbd-bow"))) else 0
-    if wl.strong:
-        steps, warm, prof_steps = wl.T - 1, 0, 0
     wl.prepare(1 + warm + steps + prof_steps + 1)
     batch = wl.batch
     cap = batch.cap
-    gatherer, rec_parts, layout = None, None, None
-    if dist is not None:
-        import ctypes as C
-        kp_p, desc_p, cnt_p, _ = batch.results_device()
-        ur_p, dep_p = C.c_void_p(), C.c_void_p(); cc = C.c_int()
-        fe.check(fe.lib().sd_batch_stereo_device(batch.h, C.byref(ur_p), C.byref(dep_p), C.byref(cc)))
-        fb_bytes = fe.FRAME_BOXES_BYTES
-        fb_p = fe.batch_boxes_device(batch)
-        layout = record_layout(cap, fb_bytes)
-        stride = layout["_stride"]
-        S, ipl = wl.S, wl.ipl
-        gatherer = ResultGather(dist, world, rank, S * stride, dev)
-        stage2d = gatherer.stage.view(S, stride)
-        srcs = {"count": (cnt_p, 4), "fb": (fb_p, fb_bytes), "kp": (kp_p, cap * 28), "desc": (desc_p, cap * 32), "uright": (ur_p.value, cap * 4), "depth": (dep_p.value, cap * 4)}
-        rec_parts = []
-        for k in RECORD_FIELDS:
-            ptr, nbytes = srcs[k]
-            src = fe.as_torch_u8(ptr, S * ipl * nbytes).view(S * ipl, nbytes)[::ipl]        # the lanes' current (left) slots
-            o, n = layout[k]
-            rec_parts.append((stage2d[:, o:o + n], src))
+    gatherer, rec_parts, layout = make_gatherer(wl, fe, dist, world, rank, dev)
 
     def one_step():
         r = wl.step()
@@ -639,7 +810,7 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline, vocab=None):
 
     out = None
     if rank == 0:
-        frames = wl.total_frames_all_ranks - 11 if wl.strong else world * wl.S * steps       # strong: frame 0 of every sequence is the priming step
+        frames = world * wl.S * steps
         value = frames / elapsed
         R = res[0]
         out = {"workload": name, "value": round(value, 2), "ms_per_step": round(elapsed / steps * 1e3, 4), "steps": steps, "frames": frames,
@@ -756,7 +927,9 @@ WORKLOAD_TEXT = {
     "rgbd-cull": "KITTI-03 RGB-D 1241x376, 2000 feat/frame, 3 given boxes per frame: extract + match + boxTrack + firstSeparate + TrackHomo + Separate + UpdateFrame",
     "tum-mask": "TUM3 RGB-D 640x480, 1000 feat/frame, DepthMapFactor 5000, 30 fps, mask + 3 boxes per frame: extract + match + cull + dense back-projection of the "
                 "pixels outside (dynamic box AND mask) (BASELINE configs[3])",
-    "kitti-batch": "11 synthetic KITTI stereo sequences x %d frames with 3 boxes per frame, whole sequences per rank (BASELINE configs[4]); cull on, detector off",
+    "kitti-batch": "11 synthetic KITTI stereo colour sequences x %d frames, whole sequences per rank (BASELINE configs[4]), the configs[2] chain on every frame "
+                   "(YOLOv3 f32 -> boxes -> TrackStereo with the cull): detector + extraction + stereo matching batched over consecutive frames of the owned "
+                   "sequences (sd_tracker_prefetch), the per-stream recurrence frame by frame; results identical to the sequential run",
 }
 
 
@@ -771,6 +944,8 @@ def main():
     ap.add_argument("--extra", default="auto", help="comma-separated workloads also run (short) and reported under 'extra'; 'auto' = stereo,rgbd,rgbd-cull at N=1, none otherwise; 'none'")
     ap.add_argument("--extra-steps", type=int, default=12)
     ap.add_argument("--kitti-frames", type=int, default=256)
+    ap.add_argument("--block-frames", type=int, default=64, help="kitti-batch: frames (over all owned sequences) whose detector pass / extraction / stereo matching form one batch")
+    ap.add_argument("--kitti-no-detector", action="store_true", help="kitti-batch with the 3 given boxes per frame instead of the detector")
     ap.add_argument("--det-split", type=int, default=1, help="sub-batches the detector processes a step's images in, each on its own stream "
                     "(measured on MI355X: 1 -> 995.5, 2 -> 995.1, 4 -> 989.7 frames/s: the convolutions' drain phases are not worth filling)")
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of host time for the CPU-baseline sample (0 = skip)")
@@ -847,17 +1022,15 @@ def main():
     for w in names:
         if w not in WORKLOADS:
             raise SystemExit("unknown workload " + w)
-        kf = args.kitti_frames
-        if w == "kitti-batch" and args.extra == "auto":
-            args.kitti_frames = min(kf, 64)          # a bounded sample of configs[4] (the host generates every frame of every sequence): the text says how many
         o, _ = run_workload(w, args, rank, world, dev, pkg, dist, headline=False, vocab=vocab)
         if rank == 0:
             extras[w] = {"value": o["value"], "unit": "frames/s", "ms_per_step": o["ms_per_step"], "steps": o["steps"], "lanes_per_gpu": o["lanes_per_gpu"],
                          "scaling": "strong" if w == "kitti-batch" else "weak",
                          "workload": WORKLOAD_TEXT[w] % args.kitti_frames if w == "kitti-batch" else WORKLOAD_TEXT[w], "lane0_last_frame": o["lane0_last_frame"]}
-            if "roofline" in o:
-                extras[w]["roofline"] = o["roofline"]
-        args.kitti_frames = kf
+            for k in ("roofline", "frames", "frames_per_block_per_lane", "frames_in_one_extraction_batch", "blocks", "distinct_frames_generated_per_sequence",
+                      "max_detector_boxes_in_a_frame", "frames_truncated"):
+                if k in o:
+                    extras[w][k] = o[k]
 
     if rank == 0:
         cpu = None
@@ -867,6 +1040,9 @@ def main():
             nthr = max(1, min(usable_cpus(), 64))
             cpu["all_cores"] = cpu_all_cores(wl.cfg, wl.kind, P_SENSOR, wl.with_boxes or wl.detector, pkg, nthr)
         text = WORKLOAD_TEXT[args.workload] % args.kitti_frames if args.workload == "kitti-batch" else WORKLOAD_TEXT[args.workload]
+        if wl.with_boxes:            # the two choices of this build that the reference leaves undefined / outside the boundary
+            text += "; spec Q9: the stereo constructor's box split is the RGB-D constructor's (the reference's call is commented out, Frame.cc:166); spec Q14: no SLAM back end -- " \
+                    "identity pose prior, map points = the frame's own stereo points, mState == OK from a stream's third frame"
         cull = wl.with_boxes
         out = {
             "metric": "tracking frames/sec (extract+match%s), %s %dx%d" % ("+dynamic-cull" if cull else "", "KITTI" if wl.cfg is not synth.TUM3 else "TUM3", wl.W, wl.H),
@@ -881,6 +1057,10 @@ def main():
                                     if world > 1 else "single GPU")},
             "roofline": head.get("roofline"), "cpu_baseline": cpu, "extra": extras,
         }
+        for k in ("frames_truncated", "max_detector_boxes_in_a_frame", "frames_per_block_per_lane", "frames_in_one_extraction_batch", "blocks",
+                  "distinct_frames_generated_per_sequence"):
+            if k in head:
+                out["config"][k] = head[k]
         if "gathered_record_check" in head:
             out["gathered_record_check"] = head["gathered_record_check"]
         out["vocabulary"] = {"nodes": vocab.info()["n_nodes"], "words": vocab.info()["n_words"], "packed_bytes": int(voc_bytes)}

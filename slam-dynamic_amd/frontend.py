@@ -60,6 +60,7 @@ def lib():
         L.sd_batch_rgbd_from_f32_scaled.argtypes = [vp, vp, sz, sz, i, f, f, vp]
         L.sd_tracker_set_mappoints.argtypes = [vp, vp, vp, vp]
         L.sd_tracker_set_state.argtypes = [vp, vp]
+        L.sd_tracker_prefetch.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, vp]
         L.sd_batch_extract_host.argtypes = [vp, vp, sz, sz, i]
         L.sd_batch_results_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i)]
         L.sd_batch_counts.argtypes = [vp, vp, i]
@@ -496,7 +497,7 @@ class TrackerParams(C.Structure):
     """sd_tracker_params (include/sd_frontend.h)."""
     _fields_ = [("sensor", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32), ("rgb_order", C.c_int32),
                 ("n_lanes", C.c_int32), ("track_last", C.c_int32), ("depth_type", C.c_int32), ("cam", _Camera), ("dist", C.c_float * 5),
-                ("fps", C.c_float), ("depth_map_factor", C.c_float), ("th_depth", C.c_float), ("ini_features", C.c_int32), ("reserved2", C.c_int32)]
+                ("fps", C.c_float), ("depth_map_factor", C.c_float), ("th_depth", C.c_float), ("ini_features", C.c_int32), ("lookahead", C.c_int32)]
 
 
 class LaneResult(C.Structure):
@@ -512,11 +513,11 @@ class Tracker:
     """sd_tracker: System::TrackStereo / TrackRGBD / TrackMonocular for n_lanes independent camera streams, one frame per lane per call
     (Tracking::GrabImage* -> Frame::Frame -> Track_new's dynamic block -> match vs mLastFrame -> q_frame)."""
 
-    def __init__(self, extractor, cfg, sensor, n_lanes, channels=1, rgb_order=True, track_last=True, depth_f32=False, ini_features=0):
+    def __init__(self, extractor, cfg, sensor, n_lanes, channels=1, rgb_order=True, track_last=True, depth_f32=False, ini_features=0, lookahead=0):
         """depth_f32: the depth images are CV_32F (Tracking.cc:271-272); ini_features: nFeatures of mpIniORBextractor for monocular lanes
         that are not initialised (Tracking.cc:127-128, 335-338), 0 = none."""
         p = TrackerParams()
-        p.depth_type, p.ini_features = int(bool(depth_f32)), int(ini_features)
+        p.depth_type, p.ini_features, p.lookahead = int(bool(depth_f32)), int(ini_features), int(lookahead)
         p.sensor, p.width, p.height, p.channels, p.rgb_order = sensor, cfg["width"], cfg["height"], channels, int(bool(rgb_order))
         p.n_lanes, p.track_last = n_lanes, int(bool(track_last))
         cam = make_camera(cfg)
@@ -548,6 +549,12 @@ class Tracker:
 
     def reset(self):
         check(lib().sd_tracker_reset(self.h))
+
+    def prefetch(self, d_images, stride, image_pitch, n_frames, d_depth=0, depth_stride=0, depth_pitch=0, stream=None):
+        """The history-free half (cvtColor, extraction, undistortion, stereo / RGB-D association) of the next n_frames frames of every lane in one
+        batch: images in frame-major order (frame k, lane s, eye e).  The following n_frames track() calls pass d_images = 0."""
+        check(lib().sd_tracker_prefetch(self.h, C.c_void_p(d_images), stride, image_pitch, C.c_void_p(d_depth or 0), depth_stride, depth_pitch, n_frames,
+                                        C.c_void_p(stream or 0)))
 
     def set_state(self, state):
         """state: per lane, bit0 = initialised, bit1 = mState == OK && !mVelocity.empty(); None = the automatic rule."""
@@ -586,7 +593,7 @@ class Tracker:
         np_ = _p(np.ascontiguousarray(n_boxes, np.int32)) if n_boxes is not None else None
         tc = np.ascontiguousarray(Tcw, np.float32).reshape(S, 16) if Tcw is not None else None
         tw = np.ascontiguousarray(Twc, np.float32).reshape(S, 16) if Twc is not None else None
-        check(lib().sd_tracker_track(self.h, C.c_void_p(d_images), stride, image_pitch, C.c_void_p(d_depth or 0), depth_stride, depth_pitch,
+        check(lib().sd_tracker_track(self.h, C.c_void_p(d_images or 0), stride, image_pitch, C.c_void_p(d_depth or 0), depth_stride, depth_pitch,
                                      bp, np_, _p(ts), _p(tc) if tc is not None else None, _p(tw) if tw is not None else None,
                                      C.cast(self.results, C.c_void_p), C.c_void_p(stream or 0)))
         return self.results

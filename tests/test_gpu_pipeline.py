@@ -339,3 +339,65 @@ def test_randomised_sequences(gpu, kind, seed):
     spec = importlib.util.spec_from_file_location("fuzz_tracker", os.path.join(graft.ROOT, "tools", "fuzz_tracker.py"))
     m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
     assert m.run(3, seed, kind) == 0
+
+
+@pytest.mark.parametrize("kind", ["stereo", "rgbd-tum1"])
+def test_time_batched_prefetch_equals_sequential(gpu, fe, orc, synth, kind):
+    """BASELINE configs[4]'s mode (whole sequences, few lanes per GPU): sd_tracker_prefetch runs the history-free half of D consecutive frames of
+    every lane in ONE batch, the following D sd_tracker_track calls run only the recurrence (boxTrack -> firstSeparate -> TrackHomo -> Separate ->
+    UpdateFrame -> match vs mLastFrame).  A stream cannot be cut into chunks with a halo -- boxTrack's ids (`max + 1`, Frame.cc:545-550) depend on
+    its whole history -- so this is how a rank that owns one or two sequences fills the chip.  Two lanes, blocks of 4, 3 and 5 frames with two
+    blocks outstanding: EVERY frame equals the sequential frame-level oracle bit for bit (no relabelling of box ids)."""
+    import torch
+    P = _pipe()
+    stereo = kind == "stereo"
+    cfg = synth.KITTI_STEREO if stereo else synth.TUM1
+    sensor = fe.SENSOR_STEREO if stereo else fe.SENSOR_RGBD
+    ch = 1 if stereo else 3
+    W, H = cfg["width"], cfg["height"]
+    S, blocks = 2, [4, 3, 5]
+    T = sum(blocks)
+    seqs = [91, 92]
+    ex = fe.ORBextractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+    trk = fe.Tracker(ex, cfg, sensor, S, channels=ch, rgb_order=True, track_last=True, lookahead=5)
+    oracles = [P.SequenceOracle(orc, cfg, sensor, rgb_order=True, track_last=True) for _ in range(S)]
+    frames = [[(synth.stereo_frame_dyn(q, t, cfg)[:2] if stereo else synth.rgbd_frame_dyn(q, t, cfg)[:2]) for q in seqs] for t in range(T)]
+    boxes = [[synth.rows_to_rects(synth.boxes_for_frame(q, t, cfg)) if not (l == 1 and t == 2) else None for l, q in enumerate(seqs)] for t in range(T)]
+    stamp = lambda t: t / float(cfg["fps"])
+
+    def upload(t0, n):
+        if stereo:
+            img = torch.from_numpy(np.stack([np.stack([np.stack(frames[t][l]) for l in range(S)]) for t in range(t0, t0 + n)])).cuda()      # [n, S, 2, H, W]
+            return img, None
+        img = torch.from_numpy(np.stack([np.stack([frames[t][l][0] for l in range(S)]) for t in range(t0, t0 + n)])).cuda()
+        dep = torch.from_numpy(np.stack([np.stack([frames[t][l][1] for l in range(S)]) for t in range(t0, t0 + n)]).view(np.int16)).cuda()
+        return img, dep
+
+    flags = 0
+    try:
+        starts = np.cumsum([0] + blocks)
+        keep = []
+        pending = []
+        # block 0 and block 1 are both in flight before the first frame is tracked
+        for bi in (0, 1):
+            img, dep = upload(starts[bi], blocks[bi]); keep.append((img, dep))
+            trk.prefetch(img.data_ptr(), W * ch, W * H * ch, blocks[bi], d_depth=dep.data_ptr() if dep is not None else 0, depth_stride=W, depth_pitch=W * H)
+            pending.append(bi)
+        nxt = 2
+        for t in range(T):
+            res = trk.track(0, W * ch, W * H * ch, [stamp(t)] * S, boxes=boxes[t])
+            for l in range(S):
+                F = oracles[l].track(frames[t][l][0], frames[t][l][1], boxes[t][l], stamp(t))
+                _check_frame(fe, trk, l, res[l], F, "%s frame %d lane %d" % (kind, t, l))
+                flags += F.track_flag != 0
+            if t + 1 == starts[pending[0] + 1]:          # a block is used up: the next one goes out while the other outstanding block is tracked
+                pending.pop(0)
+                if nxt < len(blocks):
+                    img, dep = upload(starts[nxt], blocks[nxt]); keep.append((img, dep))
+                    trk.prefetch(img.data_ptr(), W * ch, W * H * ch, blocks[nxt], d_depth=dep.data_ptr() if dep is not None else 0, depth_stride=W, depth_pitch=W * H)
+                    pending.append(nxt); nxt += 1
+        with pytest.raises(fe.SdError):
+            trk.track(0, W * ch, W * H * ch, [stamp(T)] * S, boxes=boxes[0])           # nothing prefetched and no image
+    finally:
+        trk.close()
+    assert flags >= 4, "TrackHomo must have run on the later frames"

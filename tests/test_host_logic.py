@@ -195,3 +195,20 @@ def test_bench_pingpong_index_keeps_neighbours():
         assert all(0 <= i < P for i in seq)
         assert all(abs(a - b) == 1 for a, b in zip(seq, seq[1:]))
     assert [bench.pingpong_index(t, 1) for t in range(4)] == [0, 0, 0, 0]
+
+
+def test_sequence_batch_block_plan():
+    """configs[4]: whole sequences per rank (11 over 8 ranks: at most 2 per rank), and blocks of D consecutive frames per owned sequence so that one
+    detector / extraction batch holds >= 64 frames whatever the rank count."""
+    for world in (1, 2, 4, 8):
+        owner = bench.shard_sequences(11, [256] * 11, world)
+        per_rank = [sum(1 for o in owner if o == r) for r in range(world)]
+        assert sum(per_rank) == 11 and max(per_rank) - min(per_rank) <= 1
+        S = max(per_rank)
+        D, plan = bench.block_plan(256, S, 64, 24)
+        assert S * D >= 64 and S * (D - 1) < 64
+        assert sum(n for _, n, _ in plan) == 256 and plan[0][0] == 0 and all(len(idx) == n for _, n, idx in plan)
+        flat = [i for _, _, idx in plan for i in idx]
+        assert all(abs(a - b) == 1 for a, b in zip(flat, flat[1:])) and max(flat) == 23 and min(flat) == 0      # consecutive frames stay neighbouring views
+    D, plan = bench.block_plan(5, 2, 64, 24)
+    assert D == 5 and plan == [(0, 5, [0, 1, 2, 3, 4])]
