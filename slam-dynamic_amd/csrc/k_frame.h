@@ -14,9 +14,9 @@ __device__ __forceinline__ int sd_hamming256(const uint4 a0, const uint4 a1, con
            __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
-// Right-image keypoints bucketed by integer row (counting sort in LDS): rowStart[y] .. rowStart[y+1] are the
-// right keypoints with (int)y == y.  The order inside a bucket is irrelevant: the matcher takes the
-// lexicographic minimum of (distance, iR).
+// Keypoints of BOTH eyes bucketed by integer row (counting sort in LDS, grid = (frames, 2 eyes)): rowStart[y] .. rowStart[y+1] are
+// the keypoints of that image with (int)y == y.  The order inside a bucket is irrelevant: the matcher takes the lexicographic minimum of
+// (distance, iR).  Tables are indexed by IMAGE (2f = left, 2f + 1 = right).
 __global__ void __launch_bounds__(256) k_row_sort(const sd_keypoint* __restrict__ kp, const int* __restrict__ count,
                                                   unsigned short* __restrict__ rowIdx, int* __restrict__ rowStart,
                                                   int cap, int H)
@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256) k_row_sort(const sd_keypoint* __restrict_
     int* start = (int*)smem;                 // [H + 1]
     int* fill = start + H + 8;               // [H]
     __shared__ int s_carry;
-    const int f = blockIdx.x, img = 2 * f + 1, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int img = 2 * blockIdx.x + blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     __shared__ int s_wsum[4];
     const int N = count[img];
     const sd_keypoint* k = kp + (size_t)img * cap;
@@ -53,175 +53,258 @@ __global__ void __launch_bounds__(256) k_row_sort(const sd_keypoint* __restrict_
     __syncthreads();
     for (int i = tid; i < N; i += 256) {
         int y = (int)k[i].y; y = min(max(y, 0), H - 1);
-        rowIdx[(size_t)f * cap + start[y] + atomicAdd(&fill[y], 1)] = (unsigned short)i;
+        rowIdx[(size_t)img * cap + start[y] + atomicAdd(&fill[y], 1)] = (unsigned short)i;
     }
-    for (int y = tid; y <= H; y += 256) rowStart[(size_t)f * (H + 8) + y] = start[y];
+    for (int y = tid; y <= H; y += 256) rowStart[(size_t)img * (H + 8) + y] = start[y];
 }
 
-// Half a wave (32 lanes) per left keypoint, eight keypoints per workgroup.  Row-band membership (the reference's vRowIndices
-// table, Frame.cc:884-900) is evaluated directly per (left, right) pair: right keypoint iR is a candidate of row yi iff
-// floor(kpY - r) <= yi <= ceil(kpY + r), r = 2*scale[octave]; candidates are visited in increasing iR there, so "first best
-// wins" == lexicographic min of (distance, iR) here.  The kernel is bound by memory round trips per keypoint, not by lanes: two
-// keypoints per wave keep twice as many requests in flight; all cross-lane steps stay inside a half (xor < 32), loop bounds
-// are made wave-uniform with __any().
-__global__ void __launch_bounds__(256) k_stereo_match(const sd_keypoint* __restrict__ kp,
+// Frame::ComputeStereoMatches (Frame.cc:874-1031) with the descriptor search staged through LDS.  A workgroup owns SD_SR_ROWS image rows
+// of ONE frame: the left keypoints of those rows (from the left eye's row table) and every right keypoint that can lie in the band of any of
+// them (rows Y0 - bandR .. Y1 + bandR of the right eye's table: position, octave, index and the 256-bit descriptor) are staged ONCE, and the
+// half-waves then walk left keypoints against LDS-resident candidates -- instead of every left keypoint fetching its ~70 candidates'
+// keypoint records and descriptors through L2 again (round 2: 5.3x the algorithmic bytes, one dependent global round trip per step of the
+// search).  Row-band membership (the reference's vRowIndices table, Frame.cc:884-900) is evaluated per (left, right) pair: right keypoint iR is
+// a candidate of row yi iff floor(kpY - r) <= yi <= ceil(kpY + r), r = 2*scale[octave]; the reference visits candidates in increasing iR, so
+// "first best wins" == lexicographic min of (distance, iR) here, whatever the staging order.  More keypoints than a pass holds (SD_SR_LEFT /
+// SD_SR_CAND) are taken in further passes.  The 11 x 11 SAD refinement is per matched keypoint as before (its windows are the algorithmic
+// bulk of this kernel's bytes).  1-D grid in XCD-aware order: the chunks of a frame meet in one L2.
+#define SD_SR_ROWS 16
+#define SD_SR_LEFT 128
+#define SD_SR_CAND 256
+#define SD_SR_RS 96               // staged slice of the right row table: SD_SR_ROWS + 2 * bandR + 2 entries
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) k_stereo_match(const sd_keypoint* __restrict__ kp,
                                                       const uint8_t* __restrict__ desc, const int* __restrict__ count,
                                                       const uint8_t* __restrict__ pyr, float* __restrict__ uRight,
                                                       float* __restrict__ depthOut, int* __restrict__ sadOut,
                                                       const unsigned short* __restrict__ rowIdx,
                                                       const int* __restrict__ rowStart, int bandR,
-                                                      const SdDevPlan* __restrict__ PP, float mbf, float fx)
+                                                      const SdDevPlan* __restrict__ PP, float mbf, float fx, int nFrames, int chunksPerFrame)
 {
     const SdDevPlan& P = *PP;
-    __shared__ __align__(16) uint8_t s_win[8][11 * 12 + 11 * 24 + 4];       // per keypoint: left window + right strip
-    const int f = blockIdx.y;
-    const int lane = threadIdx.x & 63, hl = lane & 31, grp = threadIdx.x >> 5;
+    __shared__ __align__(16) uint8_t s_win[8][2 * (2 * 11 * 12 + 11 * 24) + 16];       // per half-wave: the SAD step's left window (twice) + right strip as u16
+    __shared__ uint4 s_ld0[SD_SR_LEFT], s_ld1[SD_SR_LEFT], s_rd0[SD_SR_CAND], s_rd1[SD_SR_CAND];
+    __shared__ float s_lx[SD_SR_LEFT], s_ly[SD_SR_LEFT], s_rx[SD_SR_CAND], s_ry[SD_SR_CAND];
+    __shared__ unsigned s_lmeta[SD_SR_LEFT], s_rmeta[SD_SR_CAND], s_best[SD_SR_LEFT];      // meta = index | octave << 16
+    __shared__ float s_bx[SD_SR_LEFT];                                                      // x of the best candidate so far (kpR.pt.x of Frame.cc:957)
+    __shared__ int s_rs[SD_SR_RS];
+    // the level geometry the refinement step needs, by LEVEL (a per-lane level would otherwise cost a dependent global load of the plan per key point)
+    __shared__ float s_lvInv[SD_MAX_LEVELS], s_lvScale[SD_MAX_LEVELS];
+    __shared__ int s_lvW[SD_MAX_LEVELS], s_lvStride[SD_MAX_LEVELS], s_lvOff[SD_MAX_LEVELS];
+    int f, chunk;
+    if (!sd_xcd_image_item(blockIdx.x, chunksPerFrame, nFrames, f, chunk)) return;
+    const int tid = threadIdx.x, lane = tid & 63, hl = lane & 31, grp = tid >> 5;
     const int imgL = 2 * f, imgR = 2 * f + 1;
-    const int N = count[imgL];
-    const int iLraw = blockIdx.x * 8 + grp;
-    if (blockIdx.x * 8 >= N) return;                      // whole workgroup past the last keypoint
-    const bool live = iLraw < N;
-    const int iL = live ? iLraw : 0;
-    const size_t o = (size_t)imgL * P.kpCap + iL;         // outputs are indexed by the LEFT image
-    const sd_keypoint kL = kp[o];
-    const uint4* dl = (const uint4*)(desc + o * 32);
-    const uint4 l0 = dl[0], l1 = dl[1];
+    const int H0 = P.lv[0].H;
+    const int Y0 = chunk * SD_SR_ROWS, Y1 = min(Y0 + SD_SR_ROWS, H0);
+    if (Y0 >= H0) return;
+    const int* rsL = rowStart + (size_t)imgL * (H0 + 8);
+    const int* rsR = rowStart + (size_t)imgR * (H0 + 8);
+    const unsigned short* ridxL = rowIdx + (size_t)imgL * P.kpCap;
+    const unsigned short* ridxR = rowIdx + (size_t)imgR * P.kpCap;
+    const int l0 = rsL[Y0], l1 = rsL[Y1];
+    if (l0 == l1) return;                                     // no left keypoint in these rows
+    const int ya = max(Y0 - bandR, 0), yb = min(Y1 - 1 + bandR, H0 - 1);
+    if (tid <= yb + 1 - ya && tid < SD_SR_RS) s_rs[tid] = rsR[ya + tid];
+    if (tid >= 128 && tid < 128 + P.nlevels) {
+        const SdLevel& gl = P.lv[tid - 128];
+        s_lvInv[tid - 128] = gl.invScale; s_lvScale[tid - 128] = gl.scale; s_lvW[tid - 128] = gl.W; s_lvStride[tid - 128] = gl.stride;
+        s_lvOff[tid - 128] = gl.pyrOffset + SD_EDGE * gl.stride + SD_XOFF;
+    }
+    const int r0 = rsR[ya], r1 = rsR[yb + 1];
+    const sd_keypoint* kL_ = kp + (size_t)imgL * P.kpCap;
+    const sd_keypoint* kR = kp + (size_t)imgR * P.kpCap;
+    const uint8_t* dL = desc + (size_t)imgL * P.kpCap * 32;
+    const uint8_t* dR = desc + (size_t)imgR * P.kpCap * 32;
     const float mb = mbf / fx;
     const float minZ = mb, minD = 0.f;
     const float maxD = mbf / minZ;
-    const float uL = kL.x, vL = kL.y;
-    const int yi = (int)vL;
-    const float minU = uL - maxD, maxU = uL - minD;
-    const int levelL = kL.octave;
-    unsigned bestKey = ((unsigned)SD_TH_HIGH << 16) | 0xFFFFu;
-    const sd_keypoint* kR = kp + (size_t)imgR * P.kpCap;
-    const uint8_t* dR = desc + (size_t)imgR * P.kpCap * 32;
-    // lane l of each half holds scale[l]: the band radius of a right keypoint comes from a cross-lane read, not from a load
-    // chained behind its octave
+    // lane l of each half holds scale[l]: the band radius of a right keypoint comes from a cross-lane read
     const float scaleOfLane = hl < P.nlevels ? P.lv[hl].scale : 0.f;
-    {
-        // only right keypoints whose integer row lies within bandR (>= 2*scale_max + 1) rows can contain yi
-        const int H0 = P.lv[0].H;
-        const int* rs = rowStart + (size_t)f * (H0 + 8);
-        const unsigned short* ridx = rowIdx + (size_t)f * P.kpCap;
-        const bool scan = live && !(maxU < 0);
-        // a candidate must sit on level levelL - 1 .. levelL + 1, so its band radius is at most 2 * scale[levelL + 1]: rows further
-        // than that (+1 for the floor / ceil of the band test) hold no candidate of THIS keypoint; bandR is the all-level bound
-        const float rmax = 2.0f * __shfl(scaleOfLane, (lane & 32) + min(levelL + 1, P.nlevels - 1), 64);
-        const int band = min(bandR, (int)ceilf(rmax) + 1);
-        const int p0 = rs[min(max(yi - band, 0), H0 - 1)], p1 = scan ? rs[min(max(yi + band, 0), H0 - 1) + 1] : p0;
-        for (int pb = 0; __any(p0 + pb < p1); pb += 32) {
-            const int p = p0 + pb + hl;
-            const bool in = p < p1;
-            // position, octave and descriptor of the candidate are requested together (one round trip after its index)
-            const int iR = in ? ridx[p] : 0;
-            const sd_keypoint* kq = kR + iR;
-            const float kx = kq->x, ky = kq->y;
-            const int koct = kq->octave;
-            const uint4* dr = (const uint4*)(dR + (size_t)iR * 32);
-            const uint4 d0 = dr[0], d1 = dr[1];
-            const float r = 2.0f * __shfl(scaleOfLane, (lane & 32) + koct, 64);
-            const int maxr = (int)ceilf(ky + r), minr = (int)floorf(ky - r);
-            const bool cand = in && !(yi < minr || yi > maxr) && !(koct < levelL - 1 || koct > levelL + 1) && kx >= minU && kx <= maxU;
-            const unsigned dist = (unsigned)sd_hamming256(l0, l1, d0, d1);
-            const unsigned key = (dist << 16) | (unsigned)iR;
-            if (cand) bestKey = min(bestKey, key);
+    for (int lb = l0; lb < l1; lb += SD_SR_LEFT) {
+        const int nL = min(SD_SR_LEFT, l1 - lb);
+        __syncthreads();                                       // the previous pass is done with the left arrays (and s_rs is written)
+        if (tid < nL) {
+            const int iL = ridxL[lb + tid];
+            const sd_keypoint* q = kL_ + iL;
+            s_lx[tid] = q->x; s_ly[tid] = q->y; s_lmeta[tid] = (unsigned)iL | ((unsigned)q->octave << 16);
+            const uint4* d = (const uint4*)(dL + (size_t)iL * 32);
+            s_ld0[tid] = d[0]; s_ld1[tid] = d[1];
+            s_best[tid] = ((unsigned)SD_TH_HIGH << 16) | 0xFFFFu; s_bx[tid] = 0.f;
         }
-    }
+        for (int cb = r0; cb < r1; cb += SD_SR_CAND) {
+            const int nC = min(SD_SR_CAND, r1 - cb);
+            __syncthreads();                                   // left arrays visible / the previous candidate chunk is consumed
+            if (tid < nC) {
+                const int iR = ridxR[cb + tid];
+                const sd_keypoint* q = kR + iR;
+                s_rx[tid] = q->x; s_ry[tid] = q->y; s_rmeta[tid] = (unsigned)iR | ((unsigned)q->octave << 16);
+                const uint4* d = (const uint4*)(dR + (size_t)iR * 32);
+                s_rd0[tid] = d[0]; s_rd1[tid] = d[1];
+            }
+            __syncthreads();
+            for (int j = grp; j < nL; j += 8) {
+                const float uL = s_lx[j], vL = s_ly[j];
+                const int levelL = (int)(s_lmeta[j] >> 16);
+                const uint4 a0 = s_ld0[j], a1 = s_ld1[j];
+                const int yi = (int)vL;
+                const float minU = uL - maxD, maxU = uL - minD;
+                // a candidate must sit on level levelL - 1 .. levelL + 1, so its band radius is at most 2 * scale[levelL + 1]: rows further
+                // than that (+1 for the floor / ceil of the band test) hold no candidate of THIS keypoint; bandR is the all-level bound
+                const float rmax = 2.0f * __shfl(scaleOfLane, (lane & 32) + min(levelL + 1, P.nlevels - 1), 64);
+                const int band = min(bandR, (int)ceilf(rmax) + 1);
+                const bool scan = !(maxU < 0);
+                int p0 = s_rs[min(max(yi - band, 0), H0 - 1) - ya];
+                int p1 = scan ? s_rs[min(max(yi + band, 0), H0 - 1) + 1 - ya] : p0;
+                p0 = max(p0, cb) - cb; p1 = min(p1, cb + nC) - cb;
+                unsigned bestKey = 0xFFFFFFFFu;
+                float bestX = 0.f;
+                for (int pb = p0; pb < p1; pb += 32) {          // uniform inside a half
+                    const int p = pb + hl;
+                    const bool in = p < p1;
+                    const int pp = in ? p : p0;
+                    const float kx = s_rx[pp], ky = s_ry[pp];
+                    const unsigned meta = s_rmeta[pp];
+                    const int koct = (int)(meta >> 16);
+                    const float r = 2.0f * __shfl(scaleOfLane, (lane & 32) + koct, 64);
+                    const int maxr = (int)ceilf(ky + r), minr = (int)floorf(ky - r);
+                    const bool cand = in && !(yi < minr || yi > maxr) && !(koct < levelL - 1 || koct > levelL + 1) && kx >= minU && kx <= maxU;
+                    const unsigned dist = (unsigned)sd_hamming256(a0, a1, s_rd0[pp], s_rd1[pp]);
+                    const unsigned key = (dist << 16) | (meta & 0xFFFFu);
+                    if (cand && key < bestKey) { bestKey = key; bestX = kx; }
+                }
+                unsigned wkey = bestKey;
 #pragma unroll
-    for (int s = 16; s > 0; s >>= 1) bestKey = min(bestKey, (unsigned)__shfl_xor((int)bestKey, s, 64));
-    const int bestDist = (int)(bestKey >> 16);
-    const int thOrbDist = (SD_TH_HIGH + SD_TH_LOW) / 2;
-    float outU = -1.f, outD = -1.f;
-    int outS = -1;
-    if (live && bestDist < thOrbDist) {                   // uniform inside a half
-        const int bestIdxR = (int)(bestKey & 0xFFFFu);
-        const float uR0 = kR[bestIdxR].x;
-        const SdLevel& g = P.lv[levelL];
-        const float sf = g.invScale;
-        const float scaleduL = roundf(kL.x * sf), scaledvL = roundf(kL.y * sf), scaleduR0 = roundf(uR0 * sf);
-        const int w = 5, L = 5;
-        const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
-        if (!(iniu < 0 || endu >= (float)g.W)) {
-            const uint8_t* baseL = pyr + (size_t)imgL * P.pyrImageBytes + g.pyrOffset + (size_t)SD_EDGE * g.stride + SD_XOFF;
-            const uint8_t* baseR = pyr + (size_t)imgR * P.pyrImageBytes + g.pyrOffset + (size_t)SD_EDGE * g.stride + SD_XOFF;
+                for (int s = 16; s > 0; s >>= 1) wkey = min(wkey, (unsigned)__shfl_xor((int)wkey, s, 64));
+                // keys are unique (they carry iR): exactly one lane holds the winner; only this half-wave owns entry j
+                if (bestKey == wkey && wkey < s_best[j]) { s_best[j] = wkey; s_bx[j] = bestX; }
+            }
+        }
+        __syncthreads();
+        // ---- sub-pixel refinement of every left keypoint of this pass (Frame.cc:963-1031), one half-wave per keypoint.  Everything the
+        // window addresses need is in LDS (the winning candidate's x was kept beside its key), so the 99 dword requests of keypoint j + 8 are
+        // issued BEFORE the 1331 absolute differences of keypoint j are formed: one exposed round trip per half-wave instead of one per keypoint.
+        struct Win { uint32_t ld[4]; float scaleduR0; int ok; };
+        const uint8_t* pyrF = pyr + (size_t)imgL * P.pyrImageBytes;         // imgR = imgL + 1 follows it
+        auto issue = [&](int j) -> Win {
+            Win wq; wq.ok = 0; wq.scaleduR0 = 0.f;
+#pragma unroll
+            for (int it = 0; it < 4; it++) wq.ld[it] = 0;
+            if (j >= nL) return wq;
+            const unsigned bestKey = s_best[j];
+            if ((int)(bestKey >> 16) >= (SD_TH_HIGH + SD_TH_LOW) / 2) return wq;
+            const int levelL = (int)(s_lmeta[j] >> 16);
+            const float sf = s_lvInv[levelL];
+            const int gW = s_lvW[levelL], gStride = s_lvStride[levelL];
+            const float scaleduL = roundf(s_lx[j] * sf), scaledvL = roundf(s_ly[j] * sf), scaleduR0 = roundf(s_bx[j] * sf);
+            const int w = 5, L = 5;
+            const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+            if (iniu < 0 || endu >= (float)gW) return wq;
             const int rowT = (int)(scaledvL - w);
-            const uint8_t* IL = baseL + (ptrdiff_t)rowT * g.stride + (int)(scaleduL - w);
-            const uint8_t* IR = baseR + (ptrdiff_t)rowT * g.stride + (int)(scaleduR0 - w);   // incR = 0 window
-            // The 11x11 left window and the 11x21 strip the right window slides over are staged in this keypoint's LDS with
-            // 99 unaligned dword requests (four per lane, one round trip); the 1331 absolute differences then read LDS bytes.
-            uint8_t* sIL = s_win[grp];                           // [11][12]
-            uint8_t* sIR = sIL + 11 * 12;                        // [11][24]: columns -5 .. +18 of the incR = 0 window
-            uint32_t ld[4];
+            // 32-bit offsets inside the frame's two pyramid blocks (left image first): one wave-uniform base, per-lane offsets
+            const int offL = s_lvOff[levelL] + rowT * gStride + (int)(scaleduL - w);
+            const int offR = (int)P.pyrImageBytes + s_lvOff[levelL] + rowT * gStride + (int)(scaleduR0 - w) - L;   // incR = 0 window, columns -5 ..
 #pragma unroll
             for (int it = 0; it < 4; it++) {
                 const int id = hl + 32 * it;
-                ld[it] = 0;
-                if (id < 33) { const int yy = id / 3, q = id - yy * 3; ld[it] = *(const sd_u32_una*)(IL + yy * g.stride + 4 * q); }
-                else if (id < 99) { const int j = id - 33, yy = j / 6, q = j - yy * 6; ld[it] = *(const sd_u32_una*)(IR + yy * g.stride - L + 4 * q); }
+                if (id < 33) { const int yy = id / 3, q = id - yy * 3; wq.ld[it] = *(const sd_u32_una*)(pyrF + (unsigned)(offL + yy * gStride + 4 * q)); }
+                else if (id < 99) { const int jj = id - 33, yy = jj / 6, q = jj - yy * 6; wq.ld[it] = *(const sd_u32_una*)(pyrF + (unsigned)(offR + yy * gStride + 4 * q)); }
             }
+            wq.scaleduR0 = scaleduR0; wq.ok = 1;
+            return wq;
+        };
+        Win cur = issue(grp);
+        for (int j = grp; j < nL; j += 8) {
+            const Win nxt = issue(j + 8);
+            const int iL = (int)(s_lmeta[j] & 0xFFFFu), levelL = (int)(s_lmeta[j] >> 16);
+            const float uL = s_lx[j];
+            const size_t o = (size_t)imgL * P.kpCap + iL;         // outputs are indexed by the LEFT image
+            float outU = -1.f, outD = -1.f;
+            int outS = -1;
+            if (cur.ok) {                                         // uniform inside a half
+                const float gScale = s_lvScale[levelL];
+                const int L = 5;
+                // The SAD of Frame.cc:981-1003 for the 11 shifts incR = -5 .. 5:  dist(k) = sum over the 11 x 11 window of
+                // |(IL - cL) - (IR(x + k) - cR(k))| = |(IL + cR(k)) - (IR(x + k) + cL)|, all exact integers.  Lane (k, rg) of the half-wave
+                // (22 of 32 lanes) owns shift k for the rows of group rg (0: rows 0-5, 1: rows 6-10) and forms TWO differences per
+                // v_sad_u16: the windows lie in LDS as u16 (left: plain and shifted by one pixel, so that an odd shift still reads
+                // ALIGNED pixel pairs on both sides; right: + cL already added), one v_pk-style add puts cR(k) on the left pair.
+                uint16_t* wLA = (uint16_t*)s_win[grp];                // [11][12]  L[y][x]
+                uint16_t* wLB = wLA + 11 * 12;                       // [11][12]  L[y][x + 1]
+                uint16_t* wR = wLB + 11 * 12;                        // [11][24]  R[y][c] + cL, c = 0 .. 20 (column c = pixel -5 + c of the incR = 0 window)
+                const unsigned cL = (unsigned)(__shfl((int)cur.ld[0], (lane & 32) + 16, 64) >> 8) & 255u;   // L[5][5]: dword id 16 = row 5, bytes 4..7
+                const unsigned cL2 = cL * 0x10001u;
+                __builtin_amdgcn_wave_barrier();                     // the previous keypoint's window reads are done
 #pragma unroll
-            for (int it = 0; it < 4; it++) {
-                const int id = hl + 32 * it;
-                if (id < 33) { const int yy = id / 3, q = id - yy * 3; *(uint32_t*)(sIL + yy * 12 + 4 * q) = ld[it]; }
-                else if (id < 99) { const int j = id - 33, yy = j / 6, q = j - yy * 6; *(uint32_t*)(sIR + yy * 24 + 4 * q) = ld[it]; }
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): this wave's LDS writes are done
-            const int cL = sIL[w * 12 + w];
-            int cR[11];
-#pragma unroll
-            for (int k = 0; k < 11; k++) cR[k] = sIR[w * 24 + w + k];           // column (w + inc) + L, inc = k - L
-            int sums[11];
-#pragma unroll
-            for (int k = 0; k < 11; k++) sums[k] = 0;
-#pragma unroll
-            for (int it = 0; it < 4; it++) {
-                const int p = hl + 32 * it;
-                if (p < 121) {
-                    const int yy = p / 11, xx = p - yy * 11;
-                    const int a = (int)sIL[yy * 12 + xx] - cL;
-                    const uint8_t* rowR = sIR + yy * 24 + xx;
-#pragma unroll
-                    for (int k = 0; k < 11; k++) {
-                        const int b = (int)rowR[k] - cR[k];
-                        const int d = a - b;
-                        sums[k] += d < 0 ? -d : d;
+                for (int it = 0; it < 4; it++) {
+                    const int id = hl + 32 * it;
+                    const uint32_t v = cur.ld[it];
+                    const uint32_t lo = __builtin_amdgcn_perm(0u, v, 0x0C010C00u), hi = __builtin_amdgcn_perm(0u, v, 0x0C030C02u);   // bytes -> u16 pairs
+                    if (id < 33) {
+                        const int yy = id / 3, q = id - yy * 3;
+                        uint32_t* pa = (uint32_t*)(wLA + yy * 12 + 4 * q);
+                        pa[0] = lo; pa[1] = hi;
+                        uint16_t* pb = wLB + yy * 12 + 4 * q;                                   // LB[c - 1 .. c + 2] = bytes 0 .. 3
+                        if (q > 0) pb[-1] = (uint16_t)(v & 255u);
+                        *(uint32_t*)pb = __builtin_amdgcn_perm(0u, v, 0x0C020C01u);
+                        pb[2] = (uint16_t)(v >> 24);
+                    } else if (id < 99) {
+                        const int jj = id - 33, yy = jj / 6, q = jj - yy * 6;
+                        uint32_t* pr = (uint32_t*)(wR + yy * 24 + 4 * q);
+                        pr[0] = lo + cL2; pr[1] = hi + cL2;
                     }
                 }
-            }
-            __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): this wave's LDS writes are done
+                const int k = hl < 11 ? hl : (hl < 22 ? hl - 11 : 0), rg = hl >= 11 ? 1 : 0;
+                const int e = k & 1;
+                const unsigned cRk = (unsigned)wR[L * 24 + L + k] - cL;            // R[5][5 + k]
+                const unsigned cR2 = cRk * 0x10001u;
+                const uint16_t* lsel = e ? wLB : wLA;
+                const int xs = e ? 0 : 10;                                         // the pixel left over beside the five aligned pairs
+                unsigned acc = 0;
+                const int yBeg = rg ? 6 : 0, yEnd = rg ? 11 : 6;
+                for (int yy = yBeg; yy < yEnd; yy++) {
+                    const uint32_t* lp = (const uint32_t*)(lsel + yy * 12);
+                    const uint32_t* rp = (const uint32_t*)(wR + yy * 24 + k + e);   // k + e is even: aligned pairs R[xx + k], R[xx + 1 + k], xx = e + 2 i
 #pragma unroll
-            for (int k = 0; k < 11; k++)
+                    for (int i = 0; i < 5; i++) acc = __builtin_amdgcn_sad_u16(lp[i] + cR2, rp[i], acc);
+                    acc = __builtin_amdgcn_sad_u16((unsigned)wLA[yy * 12 + xs] + cRk, (unsigned)wR[yy * 24 + xs + k], acc);
+                }
+                if (hl >= 22) acc = 0;
+                __builtin_amdgcn_wave_barrier();
+                // lanes 0 .. 10 of the half: dist(k) = both row groups
+                const int hb = lane & 32;
+                unsigned dk = acc + (unsigned)__shfl((int)acc, hb + (hl < 11 ? hl + 11 : hl), 64);
+                // `if(dist<bestDist)` over incR ascending: the FIRST minimum = min of (dist << 4 | k)
+                unsigned key = hl < 11 ? (dk << 4) | (unsigned)hl : 0xFFFFFFFFu;
 #pragma unroll
-                for (int s = 16; s > 0; s >>= 1) sums[k] += __shfl_xor(sums[k], s, 64);
-            int bestS = 0x7FFFFFFF, bestinc = 0;
-#pragma unroll
-            for (int k = 0; k < 11; k++)
-                if (sums[k] < bestS) { bestS = sums[k]; bestinc = k - L; }
-            if (!(bestinc == -L || bestinc == L)) {
-                float dist1 = 0.f, dist2 = 0.f, dist3 = 0.f;
-#pragma unroll
-                for (int k = 1; k < 10; k++)
-                    if (k - L == bestinc) { dist1 = (float)sums[k - 1]; dist2 = (float)sums[k]; dist3 = (float)sums[k + 1]; }
-                const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
-                if (!(deltaR < -1 || deltaR > 1)) {
-                    float bestuR = g.scale * ((float)scaleduR0 + (float)bestinc + deltaR);
-                    float disparity = (uL - bestuR);
-                    if (disparity >= minD && disparity < maxD) {
-                        if (disparity <= 0) {
-                            disparity = (float)0.01;
-                            bestuR = (float)((double)uL - 0.01);
+                for (int s = 8; s > 0; s >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, s, 64));
+                key = (unsigned)__shfl((int)key, hb, 64);                          // (lanes 16 .. 31 reduced among themselves)
+                const int bestS = (int)(key >> 4), bestinc = (int)(key & 15u) - L;
+                if (!(bestinc == -L || bestinc == L)) {
+                    const int kb = bestinc + L;
+                    const float dist1 = (float)(unsigned)__shfl((int)dk, hb + kb - 1, 64), dist2 = (float)bestS,
+                                dist3 = (float)(unsigned)__shfl((int)dk, hb + kb + 1, 64);
+                    const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+                    if (!(deltaR < -1 || deltaR > 1)) {
+                        float bestuR = gScale * ((float)cur.scaleduR0 + (float)bestinc + deltaR);
+                        float disparity = (uL - bestuR);
+                        if (disparity >= minD && disparity < maxD) {
+                            if (disparity <= 0) {
+                                disparity = (float)0.01;
+                                bestuR = (float)((double)uL - 0.01);
+                            }
+                            outD = mbf / disparity;
+                            outU = bestuR;
+                            outS = bestS;
                         }
-                        outD = mbf / disparity;
-                        outU = bestuR;
-                        outS = bestS;
                     }
                 }
             }
+            if (hl == 0) { uRight[o] = outU; depthOut[o] = outD; sadOut[o] = outS; }
+            cur = nxt;
         }
     }
-    if (hl == 0 && live) { uRight[o] = outU; depthOut[o] = outD; sadOut[o] = outS; }
 }
 
 // Median-of-SAD outlier rejection (Frame.cc:1033-1047): median = element [size/2] of the sorted SAD

@@ -748,15 +748,16 @@ int sd_batch_stereo_match(sd_batch* b, int n_frames, float mbf, float fx, void* 
     {
         ProfScope ps(b, s, K_STEREO);
         const size_t lds = (size_t)(2 * H0 + 16) * 4;
-        hipLaunchKernelGGL(k_row_sort, dim3(n_frames), dim3(256), lds, s, b->d_kp, b->d_count, b->d_rowIdx, b->d_rowStart,
+        hipLaunchKernelGGL(k_row_sort, dim3(n_frames, 2), dim3(256), lds, s, b->d_kp, b->d_count, b->d_rowIdx, b->d_rowStart,
                            b->plan.kpCap, H0);
     }
     LAUNCH_CHECK("k_row_sort");
     {
         ProfScope ps(b, s, K_STEREO);
-        dim3 grd((b->plan.kpCap + 7) / 8, n_frames);               // eight left keypoints per workgroup (half a wave each)
-        hipLaunchKernelGGL(k_stereo_match, grd, dim3(256), 0, s, b->d_kp, b->d_desc, b->d_count, b->d_pyr, b->d_uright,
-                           b->d_depth, b->d_sad, b->d_rowIdx, b->d_rowStart, bandR, b->d_plan, mbf, fx);
+        if (SD_SR_ROWS + 2 * bandR + 2 > SD_SR_RS) return set_err(SD_ERR_UNSUPPORTED, "stereo row band larger than the staged row table (too many pyramid levels)");
+        const int chunks = (H0 + SD_SR_ROWS - 1) / SD_SR_ROWS;      // SD_SR_ROWS image rows of one frame per workgroup, XCD-aware 1-D order
+        hipLaunchKernelGGL(k_stereo_match, dim3((unsigned)chunks * (unsigned)((n_frames + 7) / 8 * 8)), dim3(256), 0, s, b->d_kp, b->d_desc, b->d_count, b->d_pyr, b->d_uright,
+                           b->d_depth, b->d_sad, b->d_rowIdx, b->d_rowStart, bandR, b->d_plan, mbf, fx, n_frames, chunks);
     }
     LAUNCH_CHECK("k_stereo_match");
     {
