@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (WM == 2 && BK == 16 ? 
     if (ksteps > 1) fetch(NSET - 1);
     if (DEEP && ksteps > 2) fetch(0);
     __syncthreads();
-    // Measured around this loop at batch 128 (ms per detector batch; the ablation switches below give wrong results and exist for timing):
+    // Measured around this loop at batch 128 (ms per detector batch; the ablation builds -- no barrier / no staging / no fragment reads -- gave wrong results, existed for timing only and are no longer in this source):
     // as is 121.0-122.5; without the barrier -1 % (122.9 against 124.1, measured before the two-step prefetch); without any staging (no
     // loads, no LDS writes, no address updates) 109.3; staging without the
     // global loads 120.1 -- i.e. what the staging costs is not the memory latency.  Requests issued unconditionally (so that the
@@ -185,30 +185,20 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (WM == 2 && BK == 16 ? 
     // 83 % in the 3 x 3 body layers.
     auto step = [&](const int ks, const int par) {     // par = ks & 1, a literal at both call sites
         const int cur = par;
-#ifndef SD_F32_EXPERIMENT_NOFRAGS
         frags(cur, 0, 0);
-#else
-        if (ks == 0) { frags(cur, 0, 0); frags(cur, 1, 1); }
-#endif
 #pragma unroll
         for (int kc = 0; kc < NCH; kc++) {
-#ifndef SD_F32_EXPERIMENT_NOFRAGS
             if (kc + 1 < NCH) frags(cur, kc + 1, (kc + 1) & 1);
-#endif
             mfmas(kc & 1);
-#ifndef SD_F32_EXPERIMENT_NOSTAGE
             if (kc == myslot) {                         // stage ks + 1 into the other buffer, stage ks + 3 requested into the set that frees
                 if (ks + 1 < ksteps) store(cur ^ 1, DEEP ? par ^ 1 : 0);
                 if (ks + 1 + NSET < ksteps) fetch(DEEP ? par ^ 1 : 0);
             }
-#endif
         }
         // The barrier stays BEHIND the step's last MFMA: hoisted above them (legal, they touch no memory) the two waves of a SIMD
         // would reach it a staging block apart and the earlier one would sit there with its remaining MFMAs unissued.
         __builtin_amdgcn_sched_barrier(0);
-#ifndef SD_F32_EXPERIMENT_NOBARRIER
         __syncthreads();
-#endif
         __builtin_amdgcn_sched_barrier(0);
     };
     int ks = 0;
