@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "ORBextractor.h"
+#include "Trajectory.h"
 
 #define FRAME_GRID_ROWS 48      // include/Frame.h:39-40
 #define FRAME_GRID_COLS 64
@@ -219,6 +220,14 @@ public:
         const int32_t nn = n;
         sdfe::check(sd_tracker_set_mappoints(trk_, x.data(), f.data(), &nn), "Tracking::CommitMapPoints");
     }
+    // The pose side's estimate of the frame just tracked (after TrackWithMotionModel / TrackLocalMap): replaces the prediction everywhere the
+    // mirror keeps it -- mCurrentFrame.mTcw (the next prediction starts from it) and the trajectory record.
+    void SetCurrentPose(const sdfe::Pose& Tcw)
+    {
+        mCurrentFrame.mTcw = Tcw;
+        if (!mlFramePoses.empty()) std::memcpy(mlFramePoses.back().Tcw, Tcw.m, 64);
+    }
+    std::vector<sdfe::TrajectoryPose> mlFramePoses;
     sd_batch* batch() { return batch_; }
     int current_slot() const { return res_.cur_slot; }
 
@@ -255,6 +264,11 @@ private:
         fill(mCurrentFrame, timestamp);
         mCurrentFrame.mTcw = Tcw;
         frames_++;
+        // mlRelativeFramePoses / mlFrameTimes / mlbLost (src/Tracking.cc:568-582), with the frame pose itself in place of the pose relative to
+        // a reference key frame: what System::SaveTrajectoryTUM / KITTI write
+        sdfe::TrajectoryPose tp;
+        std::memcpy(tp.Tcw, Tcw.m, 64); tp.timestamp = timestamp; tp.lost = mState == LOST;
+        mlFramePoses.push_back(tp);
         if (boxes) {                                    // boxTrack / firstSeparate rewrite the caller's vector (they take it by reference)
             boxes->resize(mCurrentFrame.objects.size());
             for (size_t j = 0; j < boxes->size(); j++) {
@@ -355,6 +369,11 @@ public:
     template <class MatT> sdfe::Pose TrackMonocular(const MatT& im, const double& timestamp)
     { require(MONOCULAR, "TrackMonocular"); return mpTracker->GrabImageMonocular(im, timestamp); }
     Tracking* GetTracker() { return mpTracker; }
+    // void SaveTrajectoryTUM(const string& filename) / SaveTrajectoryKITTI (src/System.cc:434-490, 524-565): refused for the monocular sensor
+    bool SaveTrajectoryTUM(const std::string& filename) const
+    { return mSensor != MONOCULAR && sdfe::SaveTrajectoryTUM(filename, mpTracker->mlFramePoses); }
+    bool SaveTrajectoryKITTI(const std::string& filename) const
+    { return mSensor != MONOCULAR && sdfe::SaveTrajectoryKITTI(filename, mpTracker->mlFramePoses); }
 
 private:
     void require(eSensor s, const char* what) const
