@@ -50,7 +50,8 @@ __device__ __forceinline__ int sd_block_scan256(int v, int* wsum, int& total)
 }
 
 // Input: fb[slot].nb / boxes / box_idx filled by the host (boxTrack output).  One workgroup per frame.
-__global__ void __launch_bounds__(256) k_box_separate(SdCullPtrs A, const int* __restrict__ slots)
+// `stage` (nullable): the host's records of this launch, one per workgroup, uploaded in ONE copy; the workgroup moves its record into its slot first.
+__global__ void __launch_bounds__(256) k_box_separate(SdCullPtrs A, const int* __restrict__ slots, const SdFrameBoxes* __restrict__ stage)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     typedef unsigned long long bmask;               // bit j = the key point lies in box j (SD_MAXB <= 64)
@@ -62,6 +63,13 @@ __global__ void __launch_bounds__(256) k_box_separate(SdCullPtrs A, const int* _
     __shared__ double s_box[SD_MAXB][4];
     const int slot = slots[blockIdx.x], tid = threadIdx.x;
     SdFrameBoxes& F = A.fb[slot];
+    if (stage) {
+        const uint32_t* src = (const uint32_t*)(stage + blockIdx.x);
+        uint32_t* dst = (uint32_t*)&F;
+        for (int i = tid; i < (int)(sizeof(SdFrameBoxes) / 4); i += 256) dst[i] = src[i];
+        __threadfence_block();
+        __syncthreads();
+    }
     const int N = A.count[slot], nb = F.nb;
     const size_t base = (size_t)slot * A.cap;
     if (N == 0) {                                   // `if(mvKeys.empty()) return;` (Frame.cc:160-161, 320-321): the constructor ends BEFORE boxTrack, objects stays empty

@@ -99,6 +99,7 @@ struct sd_batch {
     int dlPairs = 0;          // pairs sd_batch_download_matches may read (the tracker also keeps pairs at [n_lanes, 2 * n_lanes))
     // dynamic-object cull
     SdFrameBoxes* d_fb = nullptr;
+    SdFrameBoxes* d_fbStage = nullptr;     // one upload per sd_batch_first_separate call
     int* d_boxItems = nullptr;
     sd_keypoint* d_kpT = nullptr; uint8_t* d_descT = nullptr; float* d_urT = nullptr; float* d_depT = nullptr;
     sd_keypoint* d_kpD = nullptr; uint8_t* d_descD = nullptr; float* d_urD = nullptr; float* d_depD = nullptr;
@@ -225,7 +226,7 @@ static void batch_free(sd_batch* b)
                     b->d_nodeOf, b->d_lvlCount, b->d_candCount, b->d_lvlKp, b->d_rot, b->d_kp, b->d_desc, b->d_count,
                     b->d_err, b->d_uright, b->d_depth, b->d_sad, b->d_stage, b->d_cellOf, b->d_xw, b->d_flags,
                     b->d_pcand, b->d_pncand, b->d_match, b->d_pairs, b->d_npairs, b->d_nmatch, b->d_pose, b->d_pairIdx, b->d_sortedIdx, b->d_cellStart,
-                    b->d_fb, b->d_boxItems, b->d_kpT, b->d_descT, b->d_urT, b->d_depT, b->d_slots, b->d_HorF, b->d_sepFlag,
+                    b->d_fb, b->d_fbStage, b->d_boxItems, b->d_kpT, b->d_descT, b->d_urT, b->d_depT, b->d_slots, b->d_HorF, b->d_sepFlag,
                     b->d_lastIdx, b->d_lastStatus, b->d_nLast, b->d_dynStart, b->d_dynStatus, b->d_sepMatches, b->d_sepRet,
                     b->d_sepPairs, b->d_kpD, b->d_descD, b->d_urD, b->d_depD, b->d_rowIdx, b->d_rowStart,
                     b->d_lmCand, b->d_lmN, b->d_lmOvf, b->d_lmIdx, b->d_bowWordF, b->d_bowWF, b->d_bowNidF, b->d_fvNode, b->d_fvFeat,
@@ -330,6 +331,7 @@ static int batch_create_impl(sd_batch** out, sd_extractor* ex, int width, int he
     ALLOC(b->d_pose, nI * 2 * 16 * 4);
     b->itemsCap = 2 * P.kpCap;
     ALLOC(b->d_fb, nI * sizeof(SdFrameBoxes));
+    ALLOC(b->d_fbStage, nI * sizeof(SdFrameBoxes));
     ALLOC(b->d_boxItems, nI * b->itemsCap * 4);
     ALLOC(b->d_kpT, nI * P.kpCap * sizeof(sd_keypoint));
     ALLOC(b->d_descT, nI * P.kpCap * 32);
@@ -1755,13 +1757,12 @@ int sd_batch_first_separate(sd_batch* b, int n_frames, const int32_t* slots, con
             h[f].box_status[j] = -1;
         }
     }
-    for (int f = 0; f < n_frames; f++)
-        HIPCHK(hipMemcpyAsync(b->d_fb + slots[f], &h[f], sizeof(SdFrameBoxes), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->d_fbStage, h.data(), (size_t)n_frames * sizeof(SdFrameBoxes), hipMemcpyHostToDevice, s));      // one copy; the workgroups scatter
     HIPCHK(hipMemcpyAsync(b->d_slots, slots, (size_t)n_frames * 4, hipMemcpyHostToDevice, s));
     {
         ProfScope ps(b, s, K_BOXSEP);
         const size_t lds = (size_t)b->plan.kpCap * 16 + 64;      // two 64-bit box masks per key point
-        hipLaunchKernelGGL(k_box_separate, dim3(n_frames), dim3(256), lds, s, cull_ptrs(b), b->d_slots);
+        hipLaunchKernelGGL(k_box_separate, dim3(n_frames), dim3(256), lds, s, cull_ptrs(b), b->d_slots, b->d_fbStage);
     }
     LAUNCH_CHECK("k_box_separate");
     return SD_OK;
