@@ -944,7 +944,7 @@ def main():
     ap.add_argument("--extra", default="auto", help="comma-separated workloads also run (short) and reported under 'extra'; 'auto' = stereo,rgbd,rgbd-cull at N=1, none otherwise; 'none'")
     ap.add_argument("--extra-steps", type=int, default=12)
     ap.add_argument("--kitti-frames", type=int, default=256)
-    ap.add_argument("--block-frames", type=int, default=64, help="kitti-batch: frames (over all owned sequences) whose detector pass / extraction / stereo matching form one batch")
+    ap.add_argument("--block-frames", type=int, default=128, help="kitti-batch: frames (over all owned sequences) whose detector pass / extraction / stereo matching form one batch")
     ap.add_argument("--kitti-no-detector", action="store_true", help="kitti-batch with the 3 given boxes per frame instead of the detector")
     ap.add_argument("--det-split", type=int, default=1, help="sub-batches the detector processes a step's images in, each on its own stream "
                     "(measured on MI355X: 1 -> 995.5, 2 -> 995.1, 4 -> 989.7 frames/s: the convolutions' drain phases are not worth filling)")

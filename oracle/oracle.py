@@ -234,12 +234,12 @@ def search_local_map(kpF, descF, uRightF, mps, mp_desc, Tcw, cam10, scale_factor
     return track, mpm, kpm, nm
 
 
-MAXB = 32
-
-
-def box_track(boxes, last_objects, last_box_idx, last_omit, last_velocity, img_cols, img_rows, cap=MAXB):
-    """Frame::boxTrack.  boxes (n,4) f64 -> (boxes', box_idx, omit, velocity) with re-injected boxes appended."""
+def box_track(boxes, last_objects, last_box_idx, last_omit, last_velocity, img_cols, img_rows, cap=None):
+    """Frame::boxTrack.  boxes (n,4) f64 -> (boxes', box_idx, omit, velocity) with re-injected boxes appended.  The reference's vectors are
+    unbounded: the buffers hold the current boxes plus every last-frame box that could be re-injected."""
     n = len(boxes)
+    if cap is None:
+        cap = n + len(np.asarray(last_box_idx).reshape(-1)) + 1
     bx = np.zeros((cap, 4), np.float64); bx[:n] = boxes
     lo = np.ascontiguousarray(last_objects, np.float64).reshape(-1, 4)
     li = np.ascontiguousarray(last_box_idx, np.int32); lm = np.ascontiguousarray(last_omit, np.uint8)

@@ -329,8 +329,8 @@ def test_mono_chain_ini_extractor(gpu, fe, orc, synth):
     assert N[2 * 3] < 1.2 * nf and N[2 * 3 + 1] > 1.5 * nf, "frame 3: lane 0 is initialised, lane 1 is not: %r" % N
 
 
-@pytest.mark.parametrize("kind,seed", [("stereo", 11), ("rgbd", 12)])
-def test_randomised_sequences(gpu, kind, seed):
+@pytest.mark.parametrize("kind,seed,state", [("stereo", 11, False), ("rgbd", 12, False), ("stereo", 13, True), ("rgbd", 14, True)])
+def test_randomised_sequences(gpu, kind, seed, state):
     """3 fixed draws per sensor of tools/fuzz_tracker.py: random box sets (none / empty / overlapping / partly outside / erased), jittered and
     jumping time stamps, blank frames (the constructor's `mvKeys.empty()` return), scene cuts -- every frame of every lane identical to the
     frame-level oracle.  (When written: 16 + 80 draws of 3 lanes x 8 frames were run; the sweep found the blank-frame case, where the
@@ -338,7 +338,7 @@ def test_randomised_sequences(gpu, kind, seed):
     import importlib.util, os
     spec = importlib.util.spec_from_file_location("fuzz_tracker", os.path.join(graft.ROOT, "tools", "fuzz_tracker.py"))
     m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
-    assert m.run(3, seed, kind) == 0
+    assert m.run(3, seed, kind, state=state) == 0        # state: + a caller's pose prior / mState / committed MapPoints and crowded (> 32 boxes) frames
 
 
 @pytest.mark.parametrize("kind", ["stereo", "rgbd-tum1"])
