@@ -925,7 +925,7 @@ __global__ void __launch_bounds__(256) k_describe(const uint8_t* __restrict__ bl
         int r = lane / 10, c = lane - r * 10;
 #pragma unroll
         for (int k = 0; k < 6; k++) {
-            offs[k] = r * step + 4 * c;
+            offs[k] = __mul24(r, step) + 4 * c;
             r += 6; c += 4;                                   // + 64 = 6 rows of 10 dwords + 4
             if (c >= 10) { c -= 10; r += 1; }
         }
@@ -966,8 +966,8 @@ __global__ void __launch_bounds__(256) k_describe(const uint8_t* __restrict__ bl
             const float x1 = (float)(signed char)((pq >> 16) & 255u), y1 = (float)(signed char)(pq >> 24);
             const int iy0 = __float2int_rn(x0 * b + y0 * a), ix0 = __float2int_rn(x0 * a - y0 * b);
             const int iy1 = __float2int_rn(x1 * b + y1 * a), ix1 = __float2int_rn(x1 * a - y1 * b);
-            const int t0 = center[iy0 * SD_DP_W + ix0];
-            const int t1 = center[iy1 * SD_DP_W + ix1];
+            const int t0 = center[__mul24(iy0, SD_DP_W) + ix0];      // v_mad_i32_i24: a plain `iy * W` is a quarter-rate v_mul_lo_u32 here
+            const int t1 = center[__mul24(iy1, SD_DP_W) + ix1];
             words[r] = __ballot(t0 < t1);
         }
         if (lane < 4) {

@@ -17,7 +17,7 @@
 #include "k_extract.h"
 
 #define SD_FS_MAXWIN 52            // largest window side handled here
-#define SD_FS_TW 56                // tile row stride (bytes) = 14 words
+#define SD_FS_TW 64                // tile row stride (bytes) = four 16-byte chunks (window width + 1 <= 53)
 #define SD_FS_SW 48                // score tile row stride (bytes), 1-px zero frame included
 #define SD_FS_MAXSCAN (46 * 46)
 
@@ -87,15 +87,17 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     {
         // ---- phase 0: window -> LDS.  All row requests of a thread are issued before the first one is consumed (one memory
         // round trip per cell instead of one per 8 rows); the LDS clears run underneath.
+        // 16-byte requests (the window rows are not aligned; the hardware takes unaligned dwordx4): four chunks per row, two requests per
+        // thread cover the 52-row maximum -- a quarter of the address arithmetic and LDS writes of the dword form (the kernel is VALU-bound)
         const uint8_t* src = pyr + (size_t)img * A.pyrImageBytes + c.srcOff;
-        const int wd = tid & 15, y0 = tid >> 4;
-        constexpr int NR = (SD_FS_MAXWIN + NT / 16 - 1) / (NT / 16);
-        uint32_t px[NR];
+        const int wd = tid & 3, y0 = tid >> 2;
+        constexpr int NR = (SD_FS_MAXWIN + NT / 4 - 1) / (NT / 4);
+        sd_u4v px[NR];
+        const int nq = (ww + 1 + 15) >> 4;                  // chunks that hold window bytes (tile column 0 = window x - 1)
 #pragma unroll
         for (int k = 0; k < NR; k++) {
-            const int y = y0 + k * (NT / 16);
-            px[k] = 0;
-            if (wd < 14 && y < wh) px[k] = *(const sd_u32_unaligned*)(src + (unsigned)__mul24(y, c.stride) + 4 * wd);
+            const int y = y0 + k * (NT / 4);
+            if (wd < nq && y < wh) px[k] = *(const sd_u128_unaligned*)(src + (unsigned)__mul24(y, c.stride) + 16 * wd);
         }
         // only the frame and the scanned rows of the score tile are ever read: rows 0 .. sh+1
         for (int i = tid; i < (sh + 2) * (SD_FS_SW / 4); i += NT) scoreW[i] = 0;
@@ -103,8 +105,8 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         if (tid == 0) { s_cnt1 = 0; s_cnt2 = 0; s_cnt3 = 0; }
 #pragma unroll
         for (int k = 0; k < NR; k++) {
-            const int y = y0 + k * (NT / 16);
-            if (wd < 14 && y < wh) tileW[y * 14 + wd] = px[k];
+            const int y = y0 + k * (NT / 4);
+            if (wd < nq && y < wh) *(sd_u4v*)(tile + y * SD_FS_TW + 16 * wd) = px[k];
         }
         __syncthreads();
         // ---- phase 1: compass quick test, 4 px per thread, four pixels per 32-bit operation on HALVED pixel values (7 bits per
@@ -129,10 +131,10 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
             const bool live = it < nitems && gq < ng;
             unsigned pmask = 0;
             if (live) {
-                const uint32_t* row = tileW + (sy + 3) * 14 + gq;
+                const uint32_t* row = tileW + (sy + 3) * (SD_FS_TW / 4) + gq;
                 const uint32_t w0 = row[0], w1 = row[1], w2 = row[2];
-                const uint32_t N = tileW[sy * 14 + gq + 1];
-                const uint32_t S = tileW[(sy + 6) * 14 + gq + 1];
+                const uint32_t N = tileW[sy * (SD_FS_TW / 4) + gq + 1];
+                const uint32_t S = tileW[(sy + 6) * (SD_FS_TW / 4) + gq + 1];
                 // halved pixels, 7 bits per byte (the alignbit forms shift the E / W neighbours into place on the way)
                 const uint32_t C7 = (w1 >> 1) & M7, N7 = (N >> 1) & M7, S7 = (S >> 1) & M7;
                 const uint32_t E7 = __builtin_amdgcn_alignbit(w2, w1, 25) & M7;
@@ -241,6 +243,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         // ---- phase 4: row-major emission.  rank of a survivor = survivors in the rows above (wave prefix sum over the row
         //      masks, one row per lane) + survivors to its left in its own row (popcount of the masked row word)
         const unsigned long long* rows = rowAll;
+        if (tid >= 64 && tid - lane >= n3) return;     // a wave without a survivor of its own has nothing to emit (wave 0 writes the count; n3 <= 64 almost always)
         const int rowPop = lane < SD_FS_ROWS ? __popcll(rows[lane]) : 0;
         int incl = rowPop;
 #pragma unroll

@@ -1,14 +1,13 @@
 """The callers of the hot path, restated for this library: the dataset layouts and file grammars
 of the reference's example drivers, their per-frame timing statistics, and the per-frame call sequence of
 System::TrackRGBD -> Tracking::GrabImageRGBD -> Frame(gray, rgb, depth, mask, boxes, last_frame, ...) ->
-Tracking::Track_new's dynamic block, issued against the C ABI.  Host code only; everything heavy runs in the library.
+Tracking::Track_new's dynamic block, which is ONE call of the Frame-level boundary (sd_tracker_track).  Host code only.
 
   Examples/RGB-D/rgbd_my.cc:86-131    main loop: imread rgb / depth / mask, mask.convertTo(CV_32F), steady-clock around TrackRGBD
   Examples/RGB-D/rgbd_my.cc:133-146   sort(vTimesTrack); median = vTimesTrack[nImages/2]; mean = sum / nImages
   Examples/RGB-D/rgbd_my.cc:196-253   LoadKITTIImages: times.txt, image_2/%06d.png, depth/%06d.png, mask/mask_%06d.png,
                                       yolov5_2Dbbox/%06d.txt with lines `id cx cy w h`
   Examples/Stereo/stereo_kitti.cc:173-208  LoadImages: times.txt, image_2/, image_3/
-  src/Tracking.cc:620-666, 952-959    reference-frame queue, TrackHomo, Separate, UpdateFrame
 """
 import os
 import time
@@ -109,95 +108,34 @@ def timing_summary(times):
 
 # ------------------------------------------------------------------------------------------------ the per-frame caller
 class DynamicFrontEnd:
-    """One frame at a time through the library, in the order the reference's Tracking thread does it for an RGB-D frame with
-    detector boxes.  There is no SLAM back end here: the predicted pose of TrackHomo is the identity and the reference frame's
-    map points are its own stereo points (SURVEY §8e's "sharded batch mode").  Slot 0 = mCurrentFrame, slot 1 = mLastFrame,
-    slots 2.. = the copies held by q_frame."""
+    """`System::TrackRGBD(im, depthmap, mask, boxes, timestamp)` for one camera stream, one frame at a time, as rgbd_my.cc's main loop
+    calls it: a host image goes up, the Frame-level boundary (sd_tracker: one lane) does the rest -- GrabImageRGBD, the Frame constructor,
+    Track_new's dynamic block, q_frame / mLastFrame.  There is no SLAM back end here: the tracker runs its sharded batch mode."""
 
     def __init__(self, fe, cfg, rgb_order=True):
         import torch
         self.fe, self.cfg, self.torch = fe, cfg, torch
         self.ex = fe.ORBextractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
-        self.max_q = int(np.ceil(0.3 * cfg["fps"])) + 1
-        self.ring = self.max_q + 2
-        self.batch = fe.Batch(self.ex, cfg["width"], cfg["height"], 2 + self.ring)
-        self.cam = fe.make_camera(cfg)
-        self.queue = fe.RefQueue()
-        self.rgb_order = rgb_order
-        self.frame_no = 0
-        self.last = None
+        self.trk = fe.Tracker(self.ex, cfg, fe.SENSOR_RGBD, 1, channels=3, rgb_order=rgb_order, track_last=True)
         W, H = cfg["width"], cfg["height"]
         self.d_rgb = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
         self.d_depth = torch.empty((H, W), dtype=torch.int16, device="cuda")
-        self.depth_factor = float(np.float32(1.0) / np.float32(cfg.get("depth_map_factor", 1.0)))
-        self.I = np.eye(4, dtype=np.float32)[None]
 
     def close(self):
-        self.batch.close()
+        self.trk.close()
 
     def track_rgbd(self, im_rgb, im_depth_u16, mask_f32, boxes, timestamp):
-        """System::TrackRGBD(im, depthmap, mask, boxes, timestamp).  The mask is accepted and never read, exactly as
-        Frame::firstSeparate does (Frame.cc:555-604: only a commented-out print touches it)."""
-        fe, b, cfg, torch = self.fe, self.batch, self.cfg, self.torch
+        """The mask is accepted and never read, exactly as Frame::firstSeparate does (Frame.cc:555-604: only a commented-out print touches it)."""
+        torch, cfg = self.torch, self.cfg
         W, H = cfg["width"], cfg["height"]
-        st = torch.cuda.current_stream().cuda_stream
-        # Tracking::GrabImageRGBD (Tracking.cc:256-272): cvtColor + depth scaling; Frame ctor (Frame.cc:297-323): extract + RGB-D stereo
-        self.d_rgb.copy_(torch.from_numpy(np.ascontiguousarray(im_rgb)), non_blocking=False)
+        self.d_rgb.copy_(torch.from_numpy(np.ascontiguousarray(im_rgb)))
         self.d_depth.copy_(torch.from_numpy(np.ascontiguousarray(im_depth_u16).view(np.int16)))
-        b.extract_color_device(self.d_rgb.data_ptr(), W * 3, W * H * 3, 1, bool(self.rgb_order), st)
-        b.rgbd_from_u16(self.d_depth.data_ptr(), W, W * H, 1, self.depth_factor, cfg["bf"], st)
-        # Frame::boxTrack (Frame.cc:324) on the host, then firstSeparate + the static/dynamic split (:329-367)
-        boxes = np.asarray(boxes, np.float64).reshape(-1, 4)
-        if self.last is not None:
-            lo, li, lm, lv = self.last["objects"], self.last["box_idx"], self.last["omit"], self.last["velocity"]
-        else:
-            lo, li, lm, lv = np.zeros((0, 4)), np.zeros(0, np.int32), np.zeros(0, np.uint8), np.zeros((0, 2))
-        bx, idx, omit, vel = fe.box_track(boxes, lo, li, lm, lv, W, H)
-        b.first_separate([0], [bx], [idx], stream=st)
-        b.assign_grid(1, self.cam, st)
-        b.unproject(1, 1, self.cam, self.I, st)
-        kept = b.download_boxes(0)
-        has_boxes = kept["nb"] > 0
-        out = dict(flag=0, separate_ret=None, ref_slot=-1, n_boxes=kept["nb"], n_static=int(b.counts(1)[0]))
-        # Tracking::Track_new dynamic block (Tracking.cc:620-666)
-        if self.frame_no > 0 and has_boxes and len(self.queue) > 0:
-            while True:
-                ref = self.queue.candidate(timestamp, True)
-                if ref < 0:
-                    break
-                th = 15.0                                            # TrackHomo: 15 unless stereo (7); doubled when < 20 matches
-                b.search_by_projection([0], [ref], self.I, self.I, self.cam, th, False, True, stream=st)
-                _, _, nm = b.download_matches(0)
-                if nm < 20:
-                    b.search_by_projection([0], [ref], self.I, self.I, self.cam, 2 * th, False, True, stream=st)
-                    _, _, nm = b.download_matches(0)
-                flag = 0
-                if nm >= 20:
-                    b.estimate_motion(st)
-                    mo = b.download_motion(0)
-                    flag = mo["flag"]
-                if flag != 0:
-                    lastb = b.download_boxes(1)
-                    b.separate([0], [ref], None, None, [lastb["box_idx"]], [lastb["box_status"]], stream=st)     # HorF / flag stay on the device
-                    b.update_frame(True, st)                         # if(Separate(...) == 1) mCurrentFrame.UpdateFrame(dynStatus)
-                    b.assign_grid(1, self.cam, st)
-                    ret, ds, dyn, mt = b.download_separate(0)
-                    out.update(flag=flag, separate_ret=ret, ref_slot=ref, n_h=mo["n_h"], n_f=mo["n_f"], matches=int(nm))
-                    break
-                if not self.queue.reject():
-                    break
-        after = b.download_boxes(0)
-        out.update(box_idx=after["box_idx"].copy(), box_status=after["box_status"].copy(), n_keypoints=int(b.counts(1)[0]))
-        # the frame becomes mLastFrame and joins q_frame (Tracking.cc:952-959; both are copies in the reference too)
-        b.copy_frame(0, 1, st)
-        slot = 2 + self.frame_no % self.ring
-        b.copy_frame(0, slot, st)
-        self.queue.push(timestamp, slot, has_boxes, int(cfg["fps"]))
-        ko = kept["kept_orig"]
-        self.last = dict(objects=kept["boxes"].copy(), box_idx=kept["box_idx"].copy(), omit=omit[ko].copy(), velocity=vel[ko].copy())
-        self.frame_no += 1
-        b.sync()
-        return out
+        R = self.trk.track(self.d_rgb.data_ptr(), W * 3, W * H * 3, [timestamp], boxes=[np.asarray(boxes, np.float64).reshape(-1, 4)],
+                           d_depth=self.d_depth.data_ptr(), depth_stride=W, depth_pitch=W * H)[0]
+        nb = R.n_boxes
+        return dict(flag=R.track_flag, separate_ret=R.separate_ret if R.track_flag else None, ref_frame=R.ref_frame_id, n_boxes=nb, n_static=R.N_s,
+                    n_keypoints=R.N, matches=R.n_track_matches, n_h=R.n_h, n_f=R.n_f, box_idx=np.array(R.box_idx[:nb], np.int32),
+                    box_status=np.array(R.box_status[:nb], np.int32))
 
 
 def run_rgbd_sequence(front, root, n_frames):
