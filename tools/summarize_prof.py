@@ -18,7 +18,8 @@ import sys
 tag, kt = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
-stats = glob.glob(os.path.join(kt, "**", "*_kernel_stats.csv"), recursive=True)[0]
+newest = lambda pattern_dir, pat: max(glob.glob(os.path.join(pattern_dir, "**", pat), recursive=True), key=os.path.getmtime)   # gpurun merges runs: take the last one
+stats = newest(kt, "*_kernel_stats.csv")
 rows = list(csv.DictReader(open(stats)))
 with open(os.path.join(root, "profiles", tag + "_kernel_stats.csv"), "w", newline="") as f:
     w = csv.writer(f)
@@ -33,7 +34,7 @@ print("wrote", tag + "_kernel_stats.csv")
 if len(sys.argv) >= 6:
     agg = collections.defaultdict(list)
     for d in (sys.argv[3], sys.argv[4]):
-        f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+        f = newest(d, "*_counter_collection.csv")
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
             if k.startswith("k_") or k.startswith("void k_"):
@@ -64,7 +65,7 @@ if len(sys.argv) >= 6:
     json.dump(allw, open(path, "w"), indent=1, sort_keys=True)
     print("wrote", tag + "_pmc.csv, pmc_traffic.json[%s]" % workload)
     if len(sys.argv) >= 8:                                                 # SQ instruction counters (their own pass)
-        f = glob.glob(os.path.join(sys.argv[7], "**", "*_counter_collection.csv"), recursive=True)[0]
+        f = newest(sys.argv[7], "*_counter_collection.csv")
         sq = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
