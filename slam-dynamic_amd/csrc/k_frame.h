@@ -532,6 +532,39 @@ __global__ void __launch_bounds__(256) k_unproject(const sd_keypoint* __restrict
     flags[o] = f;
 }
 
+// wave-wide ascending bitonic sort of one 64-bit key per lane
+// (keys occupy lanes 0 .. n-1, the other lanes hold the maximum: a network over the first 2^ceil(log2 n) lanes suffices)
+__device__ __forceinline__ unsigned long long sd_wave_sort64(unsigned long long key, int lane, int n = 64)
+{
+    int m = 2;
+    while (m < n) m <<= 1;
+    for (int k = 2; k <= m && n > 1; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)key, j, 64);
+            const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(key >> 32), j, 64);
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            const bool takeMin = (((lane & k) == 0) == ((lane & j) == 0));
+            key = takeMin ? (key < other ? key : other) : (key > other ? key : other);
+        }
+    return key;
+}
+// merge two ascending 64-key sequences held one per lane, keep the 64 smallest (ascending)
+__device__ __forceinline__ unsigned long long sd_wave_merge_low64(unsigned long long a, unsigned long long b, int lane)
+{
+    const unsigned lo = (unsigned)__shfl((int)(unsigned)b, 63 - lane, 64);
+    const unsigned hi = (unsigned)__shfl((int)(unsigned)(b >> 32), 63 - lane, 64);
+    const unsigned long long br = ((unsigned long long)hi << 32) | lo;
+    unsigned long long key = a < br ? a : br;                 // bitonic: the 64 smallest of both
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+        const unsigned l2 = (unsigned)__shfl_xor((int)(unsigned)key, j, 64);
+        const unsigned h2 = (unsigned)__shfl_xor((int)(unsigned)(key >> 32), j, 64);
+        const unsigned long long other = ((unsigned long long)h2 << 32) | l2;
+        key = ((lane & j) == 0) ? (key < other ? key : other) : (key > other ? key : other);
+    }
+    return key;
+}
+
 // Phase A.  Projects every Last-frame map point, scans the Current frame's keypoints for the members of
 // GetFeaturesInArea(u, v, radius, level range) and keeps the (<= 64) candidates with Hamming distance <= TH_HIGH sorted by
 // (distance, visiting order).  No assignment state is touched here.
@@ -631,6 +664,10 @@ __device__ __forceinline__ int sd_proj_point(const SdProjArgs& A, int pair, int 
 #pragma unroll
     for (int o = GW; o < 64; o <<= 1) colsU = max(colsU, __shfl_xor(colsU, o, 64));
     colsU = __builtin_amdgcn_readfirstlane(colsU);
+    // GW == 64 (the whole wave on one point): more than 64 hits are possible (wide windows over dense key points); the 64 SMALLEST keys are
+    // kept by a running merge, so that a truncated list is the true head of the full one (k_proj_resolve says so if it ever runs out)
+    unsigned long long best = ~0ull;
+    int nbuf = 0;
     for (int base = 0; __any(base < total); base += GW) {
         const int t = base + gl;
         bool hit = false;
@@ -668,11 +705,34 @@ __device__ __forceinline__ int sd_proj_point(const SdProjArgs& A, int pair, int 
         }
         const unsigned long long mAll = __ballot(hit);
         const unsigned long long m = GW == 64 ? mAll : (mAll >> gshift) & ((1ull << (GW & 63)) - 1ull);
-        if (hit) {
-            const int pos = n + __popcll(m & ((1ull << gl) - 1ull));
-            if (pos < GW) keys[pos] = key;
+        if (GW == 64) {
+            const int h = __popcll(m);
+            if (nbuf + h > 64) {                       // flush the waiting keys into the running best-64
+                __builtin_amdgcn_wave_barrier();
+                unsigned long long kb = gl < nbuf ? keys[gl] : ~0ull;
+                kb = sd_wave_sort64(kb, gl, nbuf);
+                best = sd_wave_merge_low64(best, kb, gl);
+                nbuf = 0;
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (hit) keys[nbuf + __popcll(m & ((1ull << gl) - 1ull))] = key;
+            nbuf += h;
+            n += h;
+        } else {
+            if (hit) {
+                const int pos = n + __popcll(m & ((1ull << gl) - 1ull));
+                if (pos < GW) keys[pos] = key;
+            }
+            n += __popcll(m);
         }
-        n += __popcll(m);
+    }
+    if (GW == 64) {
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        unsigned long long kb = gl < nbuf ? keys[gl] : ~0ull;
+        kb = sd_wave_sort64(kb, gl, nbuf);
+        keyOut = sd_wave_merge_low64(best, kb, gl);
+        return n;
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave's LDS writes are done
@@ -732,7 +792,7 @@ __global__ void __launch_bounds__(256) k_proj_candidates(const SdProjArgs A)
         unsigned long long key64;
         bool wide64;
         int n64 = sd_proj_point<64>(A, pair, iw + s, true, lane, 0, s_keys[wv], key64, wide64);
-        if (n64 > SD_PROJ_K) { if (lane == 0) atomicOr(A.errFlag, 4); n64 = SD_PROJ_K; }
+        if (n64 > SD_PROJ_K) n64 = SD_PROJ_K;                         // the 64 nearest of more: a list of exactly 64 may be truncated (k_proj_resolve)
         const size_t o64 = (size_t)pair * cap + iw + s;
         if (lane < n64) A.cand[o64 * SD_PROJ_K + lane] = (unsigned short)(key64 & 0xFFFFu);
         if (lane == 0) A.ncand[o64] = (uint8_t)n64;
@@ -748,7 +808,7 @@ __global__ void __launch_bounds__(64) k_proj_resolve(
     const unsigned short* __restrict__ cand, const uint8_t* __restrict__ ncand, const uint8_t* __restrict__ occupied,
     int* __restrict__ matchOut, int* __restrict__ pairsOut, int* __restrict__ npairsOut, int* __restrict__ nmatchOut,
     const SdDevPlan* __restrict__ PP, int checkOrientation, const int2* __restrict__ pairIdx,
-    const int* __restrict__ active, int redoBelow)
+    const int* __restrict__ active, int redoBelow, int* __restrict__ errFlag)
 {
     if (active && !active[blockIdx.x]) return;                       // tracker mode: see SdProjArgs
     if (redoBelow > 0 && nmatchOut[blockIdx.x] >= redoBelow) return;
@@ -811,6 +871,9 @@ __global__ void __launch_bounds__(64) k_proj_resolve(
                     const int c2 = cd[(size_t)i * SD_PROJ_K + j];
                     if (!s_taken[c2]) { pick = c2; break; }
                 }
+            // a full list may be the head of a longer one (k_proj_candidates keeps the 64 nearest): if every entry is taken the 65th
+            // nearest would decide -- say so instead of answering "no match"
+            if (pick < 0 && n == SD_PROJ_K) atomicOr(errFlag, 4);
         }
         // conflict: an earlier lane with observations wants the same keypoint
         bool conflict = false;
@@ -834,6 +897,7 @@ __global__ void __launch_bounds__(64) k_proj_resolve(
                     const int c = cd[(size_t)il * SD_PROJ_K + j];
                     if (!s_taken[c]) { p = c; break; }
                 }
+                if (p < 0 && nl == SD_PROJ_K && lane == 0) atomicOr(errFlag, 4);
                 if (lane == l) pick = p;
                 if (p >= 0 && (fl[il] & 2) && lane == 0) s_taken[p] = 1;
                 __syncthreads();
@@ -901,38 +965,6 @@ struct SdTrack { float projX, projY, projXR, viewCos; int level; int inView; }; 
 // std::log(float), taken correctly rounded (the oracle's logf_cr)
 __device__ __forceinline__ float sd_logf_cr(float x) { return (float)log((double)x); }
 
-// wave-wide ascending bitonic sort of one 64-bit key per lane
-// (keys occupy lanes 0 .. n-1, the other lanes hold the maximum: a network over the first 2^ceil(log2 n) lanes suffices)
-__device__ __forceinline__ unsigned long long sd_wave_sort64(unsigned long long key, int lane, int n = 64)
-{
-    int m = 2;
-    while (m < n) m <<= 1;
-    for (int k = 2; k <= m && n > 1; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)key, j, 64);
-            const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(key >> 32), j, 64);
-            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
-            const bool takeMin = (((lane & k) == 0) == ((lane & j) == 0));
-            key = takeMin ? (key < other ? key : other) : (key > other ? key : other);
-        }
-    return key;
-}
-// merge two ascending 64-key sequences held one per lane, keep the 64 smallest (ascending)
-__device__ __forceinline__ unsigned long long sd_wave_merge_low64(unsigned long long a, unsigned long long b, int lane)
-{
-    const unsigned lo = (unsigned)__shfl((int)(unsigned)b, 63 - lane, 64);
-    const unsigned hi = (unsigned)__shfl((int)(unsigned)(b >> 32), 63 - lane, 64);
-    const unsigned long long br = ((unsigned long long)hi << 32) | lo;
-    unsigned long long key = a < br ? a : br;                 // bitonic: the 64 smallest of both
-#pragma unroll
-    for (int j = 32; j > 0; j >>= 1) {
-        const unsigned l2 = (unsigned)__shfl_xor((int)(unsigned)key, j, 64);
-        const unsigned h2 = (unsigned)__shfl_xor((int)(unsigned)(key >> 32), j, 64);
-        const unsigned long long other = ((unsigned long long)h2 << 32) | l2;
-        key = ((lane & j) == 0) ? (key < other ? key : other) : (key > other ? key : other);
-    }
-    return key;
-}
 
 // One wave per local map point.  cand[m][k] = (dist << 16 | keypoint index) of the SD_PROJ_K nearest members of
 // GetFeaturesInArea (all distances: the second best may exceed TH_HIGH) ordered by (distance, visiting order);

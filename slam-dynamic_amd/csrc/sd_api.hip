@@ -1090,7 +1090,7 @@ static int search_by_projection_impl(sd_batch* b, int pairBase, int n_pairs, con
         if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_proj_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_proj_resolve, dim3(n_pairs), dim3(64), lds, s, KPUN(b), b->d_count, b->d_flags, b->d_pcand + pOff * SD_PROJ_K, b->d_pncand + pOff,
                            d_occupied, b->d_match + pOff, b->d_pairs + pOff * 2, b->d_npairs + pairBase, b->d_nmatch + pairBase, b->d_plan, checkOrientation,
-                           dIdx, d_active, redoBelow);
+                           dIdx, d_active, redoBelow, b->d_err);
     }
     LAUNCH_CHECK("k_proj_resolve");
     if (pairBase == 0) b->nPairs = n_pairs;

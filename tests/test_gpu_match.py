@@ -151,9 +151,12 @@ def test_reprojection_residuals_match_to_1e5(seq, fe, orc):
     assert np.array_equal(rg, ro)            # in fact identical: the inputs are bit-identical
 
 
-def test_search_by_projection_crowded_windows(gpu, fe, orc, synth):
+@pytest.mark.parametrize("th", [25.0, 100.0])
+def test_search_by_projection_crowded_windows(gpu, fe, orc, synth, th):
     """Every descriptor zeroed: each window member is a hit at distance 0, so points collect more than 16 candidates (the
-    whole-wave path of k_proj_candidates) and every choice is decided by the visiting order of GetFeaturesInArea alone."""
+    whole-wave path of k_proj_candidates) and every choice is decided by the visiting order of GetFeaturesInArea alone.
+    th = 100: windows of 200 px and more hold MORE THAN 64 hits -- the kernel keeps the 64 nearest (here: the first 64 in visiting
+    order) by a running merge instead of refusing the frame (round 2: SD_ERR_UNSUPPORTED, found by tools/fuzz_frame.py seed 62)."""
     cfg = synth.KITTI_STEREO
     T = 2
     frames = [synth.stereo_frame(seq=6, t=t) for t in range(T)]
@@ -177,7 +180,6 @@ def test_search_by_projection_crowded_windows(gpu, fe, orc, synth):
         _, d_desc, _, cap = b.results_device()
         fe.as_torch_u8(d_desc, 2 * T * cap * 32).zero_()
         b.sync()
-        th = 25.0
         b.search_by_projection([2], [0], I[None], I[None], cam, th, False, True)
         cur, last = ref[1], ref[0]
         scale = orc.Extractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"]).scale.copy()
