@@ -47,8 +47,8 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming)
-MFMA_PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3}   # dense peaks, MI355X_MICROARCH.md
-WORKLOADS = ["stereo-yolo", "stereo-yolo-f16", "stereo", "rgbd", "rgbd-cull", "rgbd-bow", "tum-mask", "kitti-batch"]
+MFMA_PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "f32w": 157.3}   # dense peaks, MI355X_MICROARCH.md
+WORKLOADS = ["stereo-yolo", "stereo-yolo-f32w", "stereo-yolo-f16", "stereo", "rgbd", "rgbd-cull", "rgbd-bow", "tum-mask", "kitti-batch"]
 
 
 # --------------------------------------------------------------------------- host logic (also used by CPU tests)
@@ -401,10 +401,11 @@ class Workload:
         self.torch = torch
         fe, synth = pkg.frontend, pkg.synth
         self.fe, self.synth, self.pkg, self.name, self.dev, self.dist, self.rank, self.world = fe, synth, pkg, name, dev, dist, rank, world
-        self.detector = name in ("stereo-yolo", "stereo-yolo-f16")
-        self.det_prec = "f16" if name == "stereo-yolo-f16" else "f32"      # f32 = the reference's arithmetic (cv::dnn on the CPU computes in f32)
-        self.with_boxes = name in ("stereo-yolo", "stereo-yolo-f16", "rgbd-cull", "tum-mask", "kitti-batch")
-        self.kind = "stereo" if name in ("stereo-yolo", "stereo-yolo-f16", "stereo", "kitti-batch") else "rgbd"
+        self.detector = name in ("stereo-yolo", "stereo-yolo-f32w", "stereo-yolo-f16")
+        # f32 = the reference's arithmetic (cv::dnn on the CPU computes in f32); f32w = f32 with the 3 x 3 stride-1 layers as Winograd F(2x2, 3x3)
+        self.det_prec = {"stereo-yolo-f16": "f16", "stereo-yolo-f32w": "f32w"}.get(name, "f32")
+        self.with_boxes = name in ("stereo-yolo", "stereo-yolo-f32w", "stereo-yolo-f16", "rgbd-cull", "tum-mask", "kitti-batch")
+        self.kind = "stereo" if name in ("stereo-yolo", "stereo-yolo-f32w", "stereo-yolo-f16", "stereo", "kitti-batch") else "rgbd"
         self.bow = name == "rgbd-bow"
         self.vocab = vocab
         self.bow_history = []             # per step: the lanes' ring slots (the copies q_frame holds)
@@ -779,7 +780,7 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline, vocab=None):
         return run_sequence_batch(args, rank, world, dev, pkg, dist, detector=not args.kitti_no_detector)
     wl = Workload(name, args, rank, world, dev, pkg, dist, vocab=vocab)
     steps, warm = (args.steps, args.warmup) if headline else (args.extra_steps, 1)
-    prof_steps = 4 if (not args.no_profile and (headline or name in ("stereo", "rgbd-bow"))) else 0
+    prof_steps = 4 if (not args.no_profile and (headline or name in ("stereo", "rgbd-bow", "stereo-yolo-f32w"))) else 0
     wl.prepare(1 + warm + steps + prof_steps + 1)
     batch = wl.batch
     cap = batch.cap
@@ -888,7 +889,10 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline, vocab=None):
                             "their times here are CONTENDED (CU slots held by convolution workgroups) -- the uncontended per-kernel figures are under extra.stereo.roofline"
                             if wl.det is not None else None}
             if det_ms is not None:
-                fl = wl.det.flops()
+                # the roofline counts the MFMA FLOPs the mode EXECUTES: in f32w the Winograd layers run 16 multiplies per 2 x 2 block and
+                # (filter, channel) pair instead of 36, and the direct-convolution count is reported beside it as "nominal"
+                nominal = wl.det.flops()
+                fl = wl.det.mfma_flops()
                 prec = wl.det_prec
                 tf = fl * wl.S / (det_ms * 1e-3) / 1e12
                 # The kernel that decides this workload is the detector's convolution (k_conv_f32 / the f16 conv kernels: > 90 % of the GPU
@@ -901,11 +905,13 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline, vocab=None):
                     det_traffic = int(e["hbm_bytes_per_launch"]) * n_conv * wl.n_det       # the profile's launches are sub-batch launches
                     det_prof = e.get("profile")
                 top = {"bound": "mfma", "kernel": "k_conv_f32 x %d launches = the convolutions of one %d-image detector batch" % (n_conv * wl.n_det, wl.S) if prec == "f32"
-                                                  else "the f16 convolution kernels of one %d-image detector batch" % wl.S,
+                                                  else ("k_conv_f32 / k_wino_input + k_wino_gemm_f32: the %d convolutions of one %d-image detector batch" % (n_conv * wl.n_det, wl.S) if prec == "f32w"
+                                                        else "the f16 convolution kernels of one %d-image detector batch" % wl.S),
                        "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS[prec], "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS[prec], 4),
                        "traffic": det_traffic, "traffic_profile": det_prof, "algorithmic_flops_per_launch": int(fl * wl.S), "avg_launch_ms": round(det_ms, 3),
-                       "algorithmic_bytes_per_launch": detector_algorithmic_bytes(wl.det.layers, wl.det.net_w, wl.det.net_h, wl.S, 4 if prec == "f32" else 2),
+                       "algorithmic_bytes_per_launch": detector_algorithmic_bytes(wl.det.layers, wl.det.net_w, wl.det.net_h, wl.S, 2 if prec == "f16" else 4),
                        "operands": prec, "images_per_s": round(wl.S / (det_ms * 1e-3), 1), "gflop_per_image": round(fl / 1e9, 2), "batch": wl.S,
+                       "nominal_direct_convolution": {"gflop_per_image": round(nominal / 1e9, 2), "tflops": round(nominal * wl.S / (det_ms * 1e-3) / 1e12, 1)},
                        "measured": "3 detector passes alone (%d sub-batch(es) of %d images on their own streams, as in the timed steps) between events on those streams (untimed pass)" % (wl.n_det, wl.S_det),
                        "weights": "synthetic (yolov3.weights is a download that never was in the reference)",
                        "front_end": roof}
@@ -919,6 +925,9 @@ WORKLOAD_TEXT = {
     "stereo-yolo": "KITTI stereo 1241x376 colour pairs, 2000 feat/image: YOLOv3 (640x480, f32 as the reference's cv::dnn, synthetic weights) on the left image -> "
                    "boxes -> TrackStereo = cvtColor + 2x ORB extract + stereo match + boxTrack + firstSeparate + TrackHomo (SearchByProjection vs the queued frame "
                    "> 0.2 s back, H/F fit) + Separate + UpdateFrame + SearchByProjection vs the last frame (BASELINE configs[2])",
+    "stereo-yolo-f32w": "the same chain with the detector's 3 x 3 stride-1 layers (>= 64 input channels) computed as Winograd F(2x2, 3x3), still f32 operands and f32 "
+                        "accumulation: 2.25 x fewer MFMA FLOPs on those layers, same layer tolerance (2e-5 relative L2) and same 32 / 32 box-set equality against the "
+                        "torch-fp32 oracle as the f32 mode (tests/test_gpu_yolo.py); kept beside the headline, whose detector computes the direct sums",
     "stereo-yolo-f16": "the same chain with the detector in its throughput mode (f16 operands, f32 accumulation): its box sets differ from the f32 reference's "
                        "(tests/test_gpu_yolo.py counts them), so this is NOT the parity configuration",
     "stereo": "KITTI stereo 1241x376 colour pairs, 2000 feat/image: cvtColor + 2x ORB extract + stereo match + projection match vs the last frame, no detector / boxes",
@@ -1017,7 +1026,7 @@ def main():
     extras = {}
     names = []
     if args.extra == "auto":
-        names = [w for w in ("stereo-yolo-f16", "stereo", "rgbd", "rgbd-cull", "rgbd-bow", "tum-mask", "kitti-batch") if w != args.workload] if world == 1 else []
+        names = [w for w in ("stereo-yolo-f32w", "stereo-yolo-f16", "stereo", "rgbd", "rgbd-cull", "rgbd-bow", "tum-mask", "kitti-batch") if w != args.workload] if world == 1 else []
     elif args.extra != "none":
         names = [w for w in args.extra.split(",") if w]
     for w in names:
@@ -1052,7 +1061,8 @@ def main():
             "vs_baseline": None, "dtype": "u8" + ("+" + wl.det_prec if wl.detector else ""), "data": "synthetic",
             "config": {"workload": text, "lanes_per_gpu": head["lanes_per_gpu"], "frames_per_step_per_gpu": head["lanes_per_gpu"], "images_per_frame": wl.ipl,
                        "distinct_sequences_per_gpu": wl.distinct, "timed_seconds": head["timed_s"], "frames_timed": head["frames"],
-                       "detector_arithmetic": ("%s operands, f32 accumulation (v_mfma_f32_32x32x%s)" % (wl.det_prec, "2_f32" if wl.det_prec == "f32" else "16_f16")) if wl.detector else None,
+                       "detector_arithmetic": ("%s operands, f32 accumulation (v_mfma_f32_32x32x%s)" % (wl.det_prec[:3], "16_f16" if wl.det_prec == "f16" else "2_f32")
+                                               + ("; 3 x 3 stride-1 layers as Winograd F(2x2, 3x3)" if wl.det_prec == "f32w" else "")) if wl.detector else None,
                        "lane0_last_frame": head["lane0_last_frame"],
                        "sharding": ("independent lanes per rank, no data-path collective; per-step async gather of the result records to rank 0"
                                     if world > 1 else "single GPU")},

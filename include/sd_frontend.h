@@ -484,9 +484,13 @@ int sd_yolo_create(sd_yolo** out, const sd_yolo_layer* layers, int n_layers, con
                    int net_h, int max_batch);
 /* The same with the arithmetic chosen: SD_YOLO_F16 = f16 operands, f32 accumulation on v_mfma_f32_32x32x16_f16 (default, the
  * throughput mode); SD_YOLO_F32 = f32 operands and accumulation on v_mfma_f32_32x32x2_f32, i.e. the reference's own arithmetic
- * (cv::dnn computes in f32, src/yolo.cc:29), at 1/16 of the MFMA rate.  In F32 mode sd_yolo_download_layer returns floats. */
+ * (cv::dnn computes in f32, src/yolo.cc:29), at 1/16 of the MFMA rate.  In F32 mode sd_yolo_download_layer returns floats.
+ * SD_YOLO_F32W = SD_YOLO_F32 with the 3 x 3 stride-1 layers of >= 64 input channels and >= 128 filters computed as Winograd
+ * F(2 x 2, 3 x 3) in f32 (2.25 x fewer multiplies on those layers; sums of inputs and of weights are multiplied, so the last bits
+ * differ from the direct f32 convolution -- held to the same layer tolerance and box-set test as SD_YOLO_F32). */
 #define SD_YOLO_F16 0
 #define SD_YOLO_F32 1
+#define SD_YOLO_F32W 2
 int sd_yolo_create_prec(sd_yolo** out, const sd_yolo_layer* layers, int n_layers, const float anchors[18], int classes, int net_w,
                         int net_h, int max_batch, int precision);
 int sd_yolo_precision(const sd_yolo* y, int* precision);
@@ -495,6 +499,8 @@ int sd_yolo_weight_count(const sd_yolo* y, size_t* n_floats);
 int sd_yolo_load_darknet_weights(sd_yolo* y, const float* payload, size_t n_floats);
 int sd_yolo_layer_shape(const sd_yolo* y, int layer, int* h, int* w, int* c);
 int sd_yolo_flops(const sd_yolo* y, double* flops_per_image);
+/* The MFMA FLOPs the chosen mode actually executes per image (== sd_yolo_flops except in SD_YOLO_F32W). */
+int sd_yolo_mfma_flops(const sd_yolo* y, double* flops_per_image);
 /* blobFromImage + net.forward + the confidence filter (yolo.cc:63-68,163-183) for n 8-bit 3-channel images in HBM
  * (channel order as cv::imread delivers it, i.e. BGR; swapRB is applied as in the reference). */
 int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int height, size_t stride, size_t image_pitch, int n,

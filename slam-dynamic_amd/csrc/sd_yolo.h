@@ -9,14 +9,19 @@
 #include <vector>
 #include "k_yolo.h"
 #include "k_yolo32.h"
+#include "k_yolo32w.h"
 
 struct sd_yolo {
     std::vector<sd_yolo_layer> L;
-    struct Rt { int H = 0, W = 0, C = 0; int cinPad = 0, coutPad = 0; size_t wOff = 0, bOff = 0; _Float16* out = nullptr; int outC = 0; bool alias = false; };
+    struct Rt { int H = 0, W = 0, C = 0; int cinPad = 0, coutPad = 0; size_t wOff = 0, bOff = 0; _Float16* out = nullptr; int outC = 0; bool alias = false;
+                bool wino = false; size_t wOffW = 0; };        // SD_YOLO_F32W: this layer runs as Winograd F(2x2, 3x3), its transformed weights at d_wgtW + wOffW
     std::vector<Rt> R;
     int netW = 0, netH = 0, classes = 80, maxBatch = 0, nconv = 0;
     int f32 = 0;                   // SD_YOLO_F32: activations / weights / arithmetic in f32 (k_yolo32.h); the `out` pointers then hold floats
     float* d_blob8 = nullptr; float* d_wgt32 = nullptr; bool attrF32 = false, attrNms = false;
+    int wino = 0;                  // SD_YOLO_F32W (k_yolo32w.h): f32 mode with the eligible 3 x 3 stride-1 layers as Winograd F(2x2, 3x3)
+    float* d_wgtW = nullptr; float* d_V = nullptr; size_t wTotalW = 0; bool attrWino = false;
+    double mfmaFlops = 0;          // per image, as executed (Winograd layers: 16 multiplies per 2 x 2 block instead of 36)
     float anchors[18];
     _Float16* d_blob4 = nullptr;   // network input, NHWC f16 x 4 channels
     _Float16* d_wgt = nullptr; float* d_bias = nullptr; _Float16* d_zero = nullptr;

@@ -154,13 +154,14 @@ class Detector:
         L.sd_yolo_load_darknet_weights.argtypes = [vp, vp, sz]
         L.sd_yolo_layer_shape.argtypes = [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
         L.sd_yolo_flops.argtypes = [vp, C.POINTER(C.c_double)]
+        L.sd_yolo_mfma_flops.argtypes = [vp, C.POINTER(C.c_double)]
         L.sd_yolo_forward_device.argtypes = [vp, vp, i, i, sz, sz, i, f, vp]
         L.sd_yolo_download_layer.argtypes = [vp, i, i, vp]
         L.sd_yolo_download_region.argtypes = [vp, vp, C.POINTER(i)]
         L.sd_yolo_boxes.argtypes = [vp, i, i, i, f, f, vp, vp, vp, i, C.POINTER(i)]
         L.sd_yolo_mask_device.argtypes = [vp, i, i, i, f, f, vp, sz, C.POINTER(i), vp]
         fe.check(L.sd_yolo_create_prec(C.byref(self.h), fe._p(self.layers), len(self.layers), fe._p(self.anchors), 80, net_w, net_h, max_batch,
-                                       {"f16": 0, "f32": 1}[precision]))
+                                       {"f16": 0, "f32": 1, "f32w": 2}[precision]))
 
     def close(self):
         if self.h:
@@ -188,12 +189,16 @@ class Detector:
     def flops(self):
         d = C.c_double(); fe.check(fe.lib().sd_yolo_flops(self.h, C.byref(d))); return d.value
 
+    def mfma_flops(self):
+        """MFMA FLOPs per image as the mode executes them (== flops() except for "f32w", whose Winograd layers run 16 / 36 of the multiplies)."""
+        d = C.c_double(); fe.check(fe.lib().sd_yolo_mfma_flops(self.h, C.byref(d))); return d.value
+
     def forward_device(self, d_bgr_ptr, width, height, stride, pitch, n, conf=0.5, stream=None):
         fe.check(fe.lib().sd_yolo_forward_device(self.h, C.c_void_p(d_bgr_ptr), width, height, stride, pitch, n, conf, C.c_void_p(stream or 0)))
 
     def layer_output(self, layer, image=0):
         h, w, c = self.layer_shape(layer)
-        out = np.zeros((h, w, c), np.float32 if self.precision == "f32" else np.float16)
+        out = np.zeros((h, w, c), np.float32 if self.precision in ("f32", "f32w") else np.float16)
         fe.check(fe.lib().sd_yolo_download_layer(self.h, layer, image, fe._p(out)))
         return out
 

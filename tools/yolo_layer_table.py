@@ -28,13 +28,20 @@ for _ in range(3): conv(128, 1, 1); conv(256, 3, 1)
 conv(255, 1, 1); skip()
 ci = 0
 tot = 0
+pre = 0.0       # the Winograd input transform that precedes its GEMM (mode f32w): counted into the layer
 for r in rows[last:]:
     name = r[0]; us = (r[2] - r[1]) / 1e3
-    if 'conv' in name and ci < len(convs):
+    if 'k_wino_input' in name:
+        pre = us
+    elif ('conv' in name or 'k_wino_gemm' in name) and ci < len(convs):
         i, k, s, cin, f, ho, wo = convs[ci]; ci += 1
         fl = 2.0 * k * k * cin * f * ho * wo * B
-        tot += us
-        print("L%3d %dx%d/%d %4d->%4d %3dx%3d  %-22s grid %5d x %2d  %8.1f us  %6.1f TFLOP/s" % (i, k, k, s, cin, f, wo, ho, name[:22], r[3] // r[5], r[4], us, fl / us / 1e6))
+        wino = 'k_wino_gemm' in name
+        ex = 2.0 * 16 * cin * f * ((ho + 1) // 2) * ((wo + 1) // 2) * B if wino else fl
+        tot += us + pre
+        print("L%3d %dx%d/%d %4d->%4d %3dx%3d  %-22s grid %5d x %2d  %8.1f us  %6.1f TFLOP/s nominal%s" % (i, k, k, s, cin, f, wo, ho, name[:22], r[3] // r[5], r[4], us + pre, fl / (us + pre) / 1e6,
+              "  (input transform %.1f us; GEMM alone %.1f TFLOP/s executed)" % (pre, ex / us / 1e6) if wino else ""))
+        pre = 0.0
     else:
         print("     %-40s %8.1f us" % (name[:40], us))
 print("conv total %.2f ms" % (tot / 1e3))
