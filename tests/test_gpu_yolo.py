@@ -204,3 +204,43 @@ def test_box_sets_of_32_images_f32_exact_f16_counted(det, pkg, orc, synth):
     assert same32 == n_img, "f32 mode differs from the torch-fp32 oracle on images %r" % bad32
     assert same32w == n_img, "f32w mode differs from the torch-fp32 oracle on images %r" % bad32w
     assert boxes16_match >= 0.5 * boxes_ref, "f16 mode: fewer than half of the reference boxes reproduced exactly"
+
+
+@pytest.mark.parametrize("prec", ["f32", "f32w"])
+def test_f32_modes_odd_feature_maps_and_batch(gpu, pkg, orc, synth, prec):
+    """A 352 x 224 network input: feature maps of 11 x 7 (odd both ways: the Winograd blocks of the last row / column hang over the edge),
+    22 x 14 and 44 x 28; three different images in one batch, every image compared with its own torch-fp32 forward."""
+    import torch
+    import __graft_entry__ as graft
+    yo = graft.load_yolo_oracle()
+    layers, anchors = pkg.yolo.v3_layers()
+    payload, per = pkg.yolo.synth_weights(layers, seed=3)
+    cfg = synth.KITTI03_RGBD
+    NW, NH = 352, 224
+    imgs = [np.ascontiguousarray(synth.rgbd_frame(6, k, cfg)[0][:, :, ::-1]) for k in range(3)]
+    imgs[1] = np.ascontiguousarray(imgs[1][::-1]); imgs[2] = np.ascontiguousarray(imgs[2][:, ::-1])
+    H, W = imgs[0].shape[:2]
+    dev = torch.from_numpy(np.stack(imgs)).cuda()
+    d = pkg.yolo.Detector(layers, anchors, NW, NH, max_batch=3, precision=prec)
+    try:
+        d.load_weights(payload)
+        CONF = 0.3                    # the smaller network yields no box above 0.5 with these weights
+        d.forward_device(dev.data_ptr(), W, H, W * 3, W * H * 3, 3, CONF)
+        got_boxes = [d.boxes(k, W, H, CONF, 0.4) for k in range(3)]      # the host form: no SD_MAX_BOXES cap on the kept boxes
+        total = 0
+        for k in range(3):
+            ref = yo.torch_forward(layers, per, yo.blob_from_image(imgs[k], NW, NH, orc.resize_linear))
+            for layer in (4, 11, 36, 61, 74, 76, 80, 81, 88, 93, 100, 105):
+                got = d.layer_output(layer, image=k).transpose(2, 0, 1)
+                exp = ref[layer][0].numpy()
+                assert got.shape == exp.shape, layer
+                e = _rel(got, exp)
+                assert e < 2e-5, "%s mode, image %d, layer %d: relative L2 error %.3g" % (prec, k, layer, e)
+            rows_ref = np.concatenate([yo.region_decode(ref[li - 1][0].numpy().transpose(1, 2, 0), list(layers[li]["mask"]), anchors, NW, NH)
+                                       for li in (82, 94, 106)])
+            eb, ec, ef = yo.postprocess(rows_ref, W, H, CONF, 0.4)
+            total += len(eb)
+            assert np.array_equal(got_boxes[k][0], eb) and np.array_equal(got_boxes[k][1], ec), "%s mode, image %d: box set differs from the torch-fp32 oracle's" % (prec, k)
+        assert total > 0, "the synthetic weights must yield boxes at this size too"
+    finally:
+        d.close()
