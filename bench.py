@@ -900,9 +900,14 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline, vocab=None):
                 # detector's stream.  The dominant HBM-bound kernel of the front end stays beside it under "front_end".
                 n_conv = int((wl.det.layers["type"] == 0).sum())                  # yolo.CONV
                 det_traffic, det_prof = None, None
-                e = pmc.get("k_conv_f32" if prec == "f32" else "")
-                if e and e.get("batch_images") == n_img:
+                e = pmc.get("k_conv_f32" if prec in ("f32", "f32w") else "")
+                if e and e.get("batch_images") == n_img and prec == "f32":
                     det_traffic = int(e["hbm_bytes_per_launch"]) * n_conv * wl.n_det       # the profile's launches are sub-batch launches
+                    det_prof = e.get("profile")
+                if e and e.get("batch_images") == n_img and prec == "f32w" and "k_wino_input" in pmc and "k_wino_gemm_f32" in pmc:
+                    n_w = wl.det.winograd_layers()
+                    det_traffic = (int(e["hbm_bytes_per_launch"]) * (n_conv - n_w) + (int(pmc["k_wino_input"]["hbm_bytes_per_launch"])
+                                   + int(pmc["k_wino_gemm_f32"]["hbm_bytes_per_launch"])) * n_w) * wl.n_det
                     det_prof = e.get("profile")
                 top = {"bound": "mfma", "kernel": "k_conv_f32 x %d launches = the convolutions of one %d-image detector batch" % (n_conv * wl.n_det, wl.S) if prec == "f32"
                                                   else ("k_conv_f32 / k_wino_input + k_wino_gemm_f32: the %d convolutions of one %d-image detector batch" % (n_conv * wl.n_det, wl.S) if prec == "f32w"

@@ -501,6 +501,8 @@ int sd_yolo_layer_shape(const sd_yolo* y, int layer, int* h, int* w, int* c);
 int sd_yolo_flops(const sd_yolo* y, double* flops_per_image);
 /* The MFMA FLOPs the chosen mode actually executes per image (== sd_yolo_flops except in SD_YOLO_F32W). */
 int sd_yolo_mfma_flops(const sd_yolo* y, double* flops_per_image);
+/* How many convolutions the mode computes as Winograd F(2 x 2, 3 x 3) (0 except in SD_YOLO_F32W). */
+int sd_yolo_winograd_layers(const sd_yolo* y, int* n_layers);
 /* blobFromImage + net.forward + the confidence filter (yolo.cc:63-68,163-183) for n 8-bit 3-channel images in HBM
  * (channel order as cv::imread delivers it, i.e. BGR; swapRB is applied as in the reference). */
 int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int height, size_t stride, size_t image_pitch, int n,

@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) k_wino_input(const float* __restrict__ in
 // ~100 VALU instructions against 2 cin / 8 * 4 MFMAs (8192 MFMA cycles at cin = 128) and runs under the MFMAs of the other
 // workgroup's wave on the same SIMD.  Two workgroups per CU (<= 256 VGPRs + AGPRs per lane).
 template <int BK, int MT>
-__global__ void __launch_bounds__(256, MT == 1 ? 3 : 2) k_wino_gemm_f32(SdWinoArgs A)
+__global__ void __launch_bounds__(256, MT == 1 ? 3 : 2) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 3 : 2, MT == 1 ? 3 : 2))) k_wino_gemm_f32(SdWinoArgs A)
 {
     constexpr int NT = 256, BM = 64 * MT, BN = 64;
     constexpr int LD = BK + 4, CPR = BK / 4;

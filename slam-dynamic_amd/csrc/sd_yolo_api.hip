@@ -306,6 +306,15 @@ int sd_yolo_flops(const sd_yolo* y, double* flops_per_image)
     return SD_OK;
 }
 
+int sd_yolo_winograd_layers(const sd_yolo* y, int* n_layers)
+{
+    if (!y || !n_layers) return SD_ERR_INVALID;
+    int n = 0;
+    for (const sd_yolo::Rt& r : y->R) n += r.wino ? 1 : 0;
+    *n_layers = n;
+    return SD_OK;
+}
+
 int sd_yolo_mfma_flops(const sd_yolo* y, double* flops_per_image)
 {
     if (!y || !flops_per_image) return SD_ERR_INVALID;
@@ -372,7 +381,10 @@ static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int hei
             LAUNCH_CHECK("k_wino_input");
             // 128 filters x 64 blocks per workgroup.  Measured on one box against the direct f32 mode's 126.4 ms per 128-image batch: this tile
             // 90.9 ms; 64 x 64 tiles (a wave owns 32 x 32, 126 VGPRs, three workgroups per CU) 93.8 ms with 16-channel steps, 92.4 ms with 32.
-            A.tilesX = (int)((nblk + 63) / 64); A.tilesY = r.coutPad / 128; A.groupY = f32_group_y(A.tilesY, 128, 16 * A.cin);
+            // All filter tiles back to back on a block tile: V is the big operand here (4 x the layer's input; a block tile's 16 cin x 64 floats stay in L2
+            // while the filter tiles pass, the weights come from the Infinity Cache) -- with k_conv_f32's rule (a group's weights <= 2.5 MB) the 512-channel
+            // layers re-read V eight times: 89.1 / 88.1 ms per 128-image batch against 86.1 on the same box.
+            A.tilesX = (int)((nblk + 63) / 64); A.tilesY = r.coutPad / 128; A.groupY = A.tilesY;
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wino_gemm_f32<16, 2>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(256), SD_WINO_LDS(16, 2), s, A);
             LAUNCH_CHECK("k_wino_gemm_f32");
         } else if (l.type == SD_YOLO_CONV) {

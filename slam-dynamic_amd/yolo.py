@@ -193,6 +193,10 @@ class Detector:
         """MFMA FLOPs per image as the mode executes them (== flops() except for "f32w", whose Winograd layers run 16 / 36 of the multiplies)."""
         d = C.c_double(); fe.check(fe.lib().sd_yolo_mfma_flops(self.h, C.byref(d))); return d.value
 
+    def winograd_layers(self):
+        n = C.c_int(); fe.lib().sd_yolo_winograd_layers.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        fe.check(fe.lib().sd_yolo_winograd_layers(self.h, C.byref(n))); return n.value
+
     def forward_device(self, d_bgr_ptr, width, height, stride, pitch, n, conf=0.5, stream=None):
         fe.check(fe.lib().sd_yolo_forward_device(self.h, C.c_void_p(d_bgr_ptr), width, height, stride, pitch, n, conf, C.c_void_p(stream or 0)))
 
