@@ -100,20 +100,23 @@ private:
     int inpHeight = 480;          // Height of network's input image
     sd_yolo* net = nullptr;
 
-    void load(const std::string& modelConfiguration, const std::string& modelWeights)
+    // precision: SD_YOLO_F32 (default) computes like cv::dnn on DNN_TARGET_CPU does (yolo.cc:29), in f32; SD_YOLO_F32W the same with the
+    // 3 x 3 stride-1 layers as Winograd F(2x2, 3x3) (1.4 x faster, same tolerance and box-set tests); SD_YOLO_F16 is the throughput mode
+    // (f16 operands: 4.5 x faster, boxes can move by a pixel).
+    void load(const std::string& modelConfiguration, const std::string& modelWeights, int precision)
     {
         std::vector<sd_yolo_layer> layers;
         float anchors[18] = {0};
         int classes = 80;
         parse_darknet_cfg(modelConfiguration, layers, anchors, classes);
         const std::vector<float> w = read_darknet_weights(modelWeights);
-        sdfe::check(sd_yolo_create(&net, layers.data(), (int)layers.size(), anchors, classes, inpWidth, inpHeight, 1), "readNetFromDarknet");
+        sdfe::check(sd_yolo_create_prec(&net, layers.data(), (int)layers.size(), anchors, classes, inpWidth, inpHeight, 1, precision), "readNetFromDarknet");
         sdfe::check(sd_yolo_load_darknet_weights(net, w.data(), w.size()), "readNetFromDarknet");
     }
 
 public:
-    yolov3Segment() { load("/home/hai/projects/slam-dynamic/src/yolo/yolov3.cfg", "/home/hai/projects/slam-dynamic/src/yolo/yolov3.weights"); }   // yolo.cc:22-27
-    yolov3Segment(const std::string& modelConfiguration, const std::string& modelWeights) { load(modelConfiguration, modelWeights); }
+    yolov3Segment() { load("/home/hai/projects/slam-dynamic/src/yolo/yolov3.cfg", "/home/hai/projects/slam-dynamic/src/yolo/yolov3.weights", SD_YOLO_F32); }   // yolo.cc:22-27
+    yolov3Segment(const std::string& modelConfiguration, const std::string& modelWeights, int precision = SD_YOLO_F32) { load(modelConfiguration, modelWeights, precision); }
     ~yolov3Segment() { if (net) sd_yolo_destroy(net); }
     yolov3Segment(const yolov3Segment&) = delete;
     yolov3Segment& operator=(const yolov3Segment&) = delete;

@@ -1,8 +1,9 @@
 // Exercises slam-dynamic_amd/host/yolo.h (the mirror of yolov3::yolov3Segment):
-//   yolo_mirror_main <cfg> <weights> <w> <h> <bgr.raw> <out.bin>
+//   yolo_mirror_main <cfg> <weights> <w> <h> <bgr.raw> <out.bin> [precision: absent = the class default (f32), else SD_YOLO_*]
 // writes: int32 n, n x 4 doubles (Segmentation_), int32 noTarget, w*h mask bytes (Segmentation).
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <vector>
 #include "yolo.h"
 #include "cv_like.h"
@@ -20,7 +21,8 @@ int main(int argc, char** argv)
     try { yolov3::yolov3Segment missing; } catch (const std::exception&) { threw = true; }      // the reference's hard-coded paths do not exist here
     if (!threw) return 4;
     try {
-        yolov3::yolov3Segment yolo(argv[1], argv[2]);
+        std::unique_ptr<yolov3::yolov3Segment> py(argc > 7 ? new yolov3::yolov3Segment(argv[1], argv[2], atoi(argv[7])) : new yolov3::yolov3Segment(argv[1], argv[2]));
+        yolov3::yolov3Segment& yolo = *py;
         sdfe::ImageView v; v.data = img.data(); v.cols = w; v.rows = h; v.step = (size_t)w * 3;
         const std::vector<yolov3::Rect2d> boxes = yolo.Segmentation_(v);
         const std::vector<uint8_t> mask = yolo.Segmentation(v);

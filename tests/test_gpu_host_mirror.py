@@ -32,8 +32,10 @@ def test_cpp_orbextractor_matches_oracle(gpu, fe, orc, synth, tmp_path):
     assert np.array_equal(plane, o.pyramid(1))
 
 
-def test_cpp_yolov3segment_matches_python_detector(gpu, pkg, fe, synth, tmp_path):
-    """host/yolo.h: Darknet cfg + weights files -> Segmentation_ boxes and Segmentation mask, equal to the ctypes Detector's."""
+@pytest.mark.parametrize("prec", ["default", "f16", "f32w"])
+def test_cpp_yolov3segment_matches_python_detector(gpu, pkg, fe, synth, tmp_path, prec):
+    """host/yolo.h: Darknet cfg + weights files -> Segmentation_ boxes and Segmentation mask, equal to the ctypes Detector's.  The class
+    computes in f32 unless told otherwise (cv::dnn's arithmetic, yolo.cc:29); the other two modes are constructor arguments."""
     import torch
     yolo = pkg.yolo
     exe = str(tmp_path / "yolo_mirror")
@@ -53,13 +55,13 @@ def test_cpp_yolov3segment_matches_python_detector(gpu, pkg, fe, synth, tmp_path
     H, W = img.shape[:2]
     raw = tmp_path / "img.raw"; out = tmp_path / "out.bin"
     raw.write_bytes(img.tobytes())
-    subprocess.check_call([exe, str(cfg), str(wts), str(W), str(H), str(raw), str(out)])
+    subprocess.check_call([exe, str(cfg), str(wts), str(W), str(H), str(raw), str(out)] + ([] if prec == "default" else [str({"f16": 0, "f32w": 2}[prec])]))
     blob = out.read_bytes()
     n = int(np.frombuffer(blob, np.int32, 1)[0])
     boxes = np.frombuffer(blob, np.float64, 4 * n, 4).reshape(n, 4)
     nt = int(np.frombuffer(blob, np.int32, 1, 4 + 32 * n)[0])
     mask = np.frombuffer(blob, np.uint8, W * H, 8 + 32 * n).reshape(H, W)
-    d = yolo.Detector(layers, anchors, 640, 480, max_batch=1)
+    d = yolo.Detector(layers, anchors, 640, 480, max_batch=1, precision="f32" if prec == "default" else prec)
     d.load_weights(payload)
     dev = torch.from_numpy(img[None]).cuda()
     d.forward_device(dev.data_ptr(), W, H, W * 3, W * H * 3, 1, 0.5)
