@@ -47,8 +47,8 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming)
-MFMA_PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "f32w": 157.3}   # dense peaks, MI355X_MICROARCH.md
-WORKLOADS = ["stereo-yolo", "stereo-yolo-f32w", "stereo-yolo-f16", "stereo", "rgbd", "rgbd-cull", "rgbd-bow", "tum-mask", "kitti-batch"]
+MFMA_PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "f32w": 157.3, "f32x3": 2500.0}   # dense peaks, MI355X_MICROARCH.md
+WORKLOADS = ["stereo-yolo", "stereo-yolo-f32w", "stereo-yolo-f32x3", "stereo-yolo-f16", "stereo", "rgbd", "rgbd-cull", "rgbd-bow", "tum-mask", "kitti-batch"]
 
 
 # --------------------------------------------------------------------------- host logic (also used by CPU tests)
@@ -401,11 +401,11 @@ class Workload:
         self.torch = torch
         fe, synth = pkg.frontend, pkg.synth
         self.fe, self.synth, self.pkg, self.name, self.dev, self.dist, self.rank, self.world = fe, synth, pkg, name, dev, dist, rank, world
-        self.detector = name in ("stereo-yolo", "stereo-yolo-f32w", "stereo-yolo-f16")
+        self.detector = name in ("stereo-yolo", "stereo-yolo-f32w", "stereo-yolo-f32x3", "stereo-yolo-f16")
         # f32 = the reference's arithmetic (cv::dnn on the CPU computes in f32); f32w = f32 with the 3 x 3 stride-1 layers as Winograd F(2x2, 3x3)
-        self.det_prec = {"stereo-yolo-f16": "f16", "stereo-yolo-f32w": "f32w"}.get(name, "f32")
-        self.with_boxes = name in ("stereo-yolo", "stereo-yolo-f32w", "stereo-yolo-f16", "rgbd-cull", "tum-mask", "kitti-batch")
-        self.kind = "stereo" if name in ("stereo-yolo", "stereo-yolo-f32w", "stereo-yolo-f16", "stereo", "kitti-batch") else "rgbd"
+        self.det_prec = {"stereo-yolo-f16": "f16", "stereo-yolo-f32w": "f32w", "stereo-yolo-f32x3": "f32x3"}.get(name, "f32")      # f32x3: f32 operands as three bf16 limbs
+        self.with_boxes = name in ("stereo-yolo", "stereo-yolo-f32w", "stereo-yolo-f32x3", "stereo-yolo-f16", "rgbd-cull", "tum-mask", "kitti-batch")
+        self.kind = "stereo" if name in ("stereo-yolo", "stereo-yolo-f32w", "stereo-yolo-f32x3", "stereo-yolo-f16", "stereo", "kitti-batch") else "rgbd"
         self.bow = name == "rgbd-bow"
         self.vocab = vocab
         self.bow_history = []             # per step: the lanes' ring slots (the copies q_frame holds)
@@ -780,7 +780,7 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline, vocab=None):
         return run_sequence_batch(args, rank, world, dev, pkg, dist, detector=not args.kitti_no_detector)
     wl = Workload(name, args, rank, world, dev, pkg, dist, vocab=vocab)
     steps, warm = (args.steps, args.warmup) if headline else (args.extra_steps, 1)
-    prof_steps = 4 if (not args.no_profile and (headline or name in ("stereo", "rgbd-bow", "stereo-yolo-f32w"))) else 0
+    prof_steps = 4 if (not args.no_profile and (headline or name in ("stereo", "rgbd-bow", "stereo-yolo-f32w", "stereo-yolo-f32x3"))) else 0
     wl.prepare(1 + warm + steps + prof_steps + 1)
     batch = wl.batch
     cap = batch.cap
@@ -895,6 +895,17 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline, vocab=None):
                 fl = wl.det.mfma_flops()
                 prec = wl.det_prec
                 tf = fl * wl.S / (det_ms * 1e-3) / 1e12
+                frac = tf / MFMA_PEAK_TFLOPS[prec]
+                limb = None
+                if prec == "f32x3":
+                    # two matrix-pipe rates in one pass: the limb layers execute bf16 MFMAs (six per f32 product block), the first four layers f32 MFMAs.
+                    # `achieved` is the bf16 rate over the WHOLE pass time, `frac` the share of that time the matrix pipe must be busy at its peaks
+                    fb = wl.det.mfma_flops_bf16()
+                    limb = {"bf16_gflop_per_image": round(fb / 1e9, 2), "f32_gflop_per_image": round(fl / 1e9, 2),
+                            "f32_mfma_tflops": round(tf, 2)}
+                    frac = (fb / (MFMA_PEAK_TFLOPS["f32x3"] * 1e12) + fl / (MFMA_PEAK_TFLOPS["f32"] * 1e12)) * wl.S / (det_ms * 1e-3)
+                    tf = fb * wl.S / (det_ms * 1e-3) / 1e12
+                    fl = fb
                 # The kernel that decides this workload is the detector's convolution (k_conv_f32 / the f16 conv kernels: > 90 % of the GPU
                 # time), so IT is the roofline object; one "launch" = the convolution launches of one detector batch, timed alone on the
                 # detector's stream.  The dominant HBM-bound kernel of the front end stays beside it under "front_end".
@@ -910,9 +921,10 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline, vocab=None):
                                    + int(pmc["k_wino_gemm_f32"]["hbm_bytes_per_launch"])) * n_w) * wl.n_det
                     det_prof = e.get("profile")
                 top = {"bound": "mfma", "kernel": "k_conv_f32 x %d launches = the convolutions of one %d-image detector batch" % (n_conv * wl.n_det, wl.S) if prec == "f32"
-                                                  else ("k_conv_f32 / k_wino_input + k_wino_gemm_f32: the %d convolutions of one %d-image detector batch" % (n_conv * wl.n_det, wl.S) if prec == "f32w"
+                                                  else ("k_conv3x3_b3 / k_conv_b3 (bf16 limbs) + k_conv_f32 (first layers): the %d convolutions of one %d-image detector batch" % (n_conv * wl.n_det, wl.S) if prec == "f32x3"
+                                                        else "k_conv_f32 / k_wino_input + k_wino_gemm_f32: the %d convolutions of one %d-image detector batch" % (n_conv * wl.n_det, wl.S) if prec == "f32w"
                                                         else "the f16 convolution kernels of one %d-image detector batch" % wl.S),
-                       "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS[prec], "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS[prec], 4),
+                       "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS[prec], "unit": "TFLOP/s", "frac": round(frac, 4), "limb_mode": limb,
                        "traffic": det_traffic, "traffic_profile": det_prof, "algorithmic_flops_per_launch": int(fl * wl.S), "avg_launch_ms": round(det_ms, 3),
                        "algorithmic_bytes_per_launch": detector_algorithmic_bytes(wl.det.layers, wl.det.net_w, wl.det.net_h, wl.S, 2 if prec == "f16" else 4),
                        "operands": prec, "images_per_s": round(wl.S / (det_ms * 1e-3), 1), "gflop_per_image": round(fl / 1e9, 2), "batch": wl.S,
@@ -933,6 +945,9 @@ WORKLOAD_TEXT = {
     "stereo-yolo-f32w": "the same chain with the detector's 3 x 3 stride-1 layers (>= 64 input channels) computed as Winograd F(2x2, 3x3), still f32 operands and f32 "
                         "accumulation: 2.25 x fewer MFMA FLOPs on those layers, same layer tolerance (2e-5 relative L2) and same 32 / 32 box-set equality against the "
                         "torch-fp32 oracle as the f32 mode (tests/test_gpu_yolo.py); kept beside the headline, whose detector computes the direct sums",
+    "stereo-yolo-f32x3": "the same chain with the detector's >= 128-filter layers computed on three bf16 limbs per f32 operand (x = hi + mid + lo exactly, six exact limb "
+                         "products per product, f32 accumulation on v_mfma_f32_32x32x16_bf16): what is dropped is <= 2^-23 of a product; same layer tolerance and same 32 / 32 "
+                         "box-set equality as the f32 mode (tests/test_gpu_yolo.py); kept beside the headline",
     "stereo-yolo-f16": "the same chain with the detector in its throughput mode (f16 operands, f32 accumulation): its box sets differ from the f32 reference's "
                        "(tests/test_gpu_yolo.py counts them), so this is NOT the parity configuration",
     "stereo": "KITTI stereo 1241x376 colour pairs, 2000 feat/image: cvtColor + 2x ORB extract + stereo match + projection match vs the last frame, no detector / boxes",
@@ -1031,7 +1046,7 @@ def main():
     extras = {}
     names = []
     if args.extra == "auto":
-        names = [w for w in ("stereo-yolo-f32w", "stereo-yolo-f16", "stereo", "rgbd", "rgbd-cull", "rgbd-bow", "tum-mask", "kitti-batch") if w != args.workload] if world == 1 else []
+        names = [w for w in ("stereo-yolo-f32w", "stereo-yolo-f32x3", "stereo-yolo-f16", "stereo", "rgbd", "rgbd-cull", "rgbd-bow", "tum-mask", "kitti-batch") if w != args.workload] if world == 1 else []
     elif args.extra != "none":
         names = [w for w in args.extra.split(",") if w]
     for w in names:
@@ -1066,7 +1081,7 @@ def main():
             "vs_baseline": None, "dtype": "u8" + ("+" + wl.det_prec if wl.detector else ""), "data": "synthetic",
             "config": {"workload": text, "lanes_per_gpu": head["lanes_per_gpu"], "frames_per_step_per_gpu": head["lanes_per_gpu"], "images_per_frame": wl.ipl,
                        "distinct_sequences_per_gpu": wl.distinct, "timed_seconds": head["timed_s"], "frames_timed": head["frames"],
-                       "detector_arithmetic": ("%s operands, f32 accumulation (v_mfma_f32_32x32x%s)" % (wl.det_prec[:3], "16_f16" if wl.det_prec == "f16" else "2_f32")
+                       "detector_arithmetic": ("%s operands, f32 accumulation (v_mfma_f32_32x32x%s)" % (wl.det_prec[:3], "16_f16" if wl.det_prec == "f16" else ("16_bf16 on three bf16 limbs per operand" if wl.det_prec == "f32x3" else "2_f32"))
                                                + ("; 3 x 3 stride-1 layers as Winograd F(2x2, 3x3)" if wl.det_prec == "f32w" else "")) if wl.detector else None,
                        "lane0_last_frame": head["lane0_last_frame"],
                        "sharding": ("independent lanes per rank, no data-path collective; per-step async gather of the result records to rank 0"

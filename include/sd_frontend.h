@@ -491,6 +491,10 @@ int sd_yolo_create(sd_yolo** out, const sd_yolo_layer* layers, int n_layers, con
 #define SD_YOLO_F16 0
 #define SD_YOLO_F32 1
 #define SD_YOLO_F32W 2
+/* SD_YOLO_F32X3 = SD_YOLO_F32 with the >= 128-filter layers computed on three bf16 limbs per f32 operand (x = hi + mid + lo exactly;
+ * a product = its six limb products of weight >= 2^-16, each exact in f32, accumulated in f32 by v_mfma_f32_32x32x16_bf16): what is
+ * dropped is <= 2^-23 of a product, the size of an f32 multiply's own rounding.  Held to the same layer tolerance and box-set test. */
+#define SD_YOLO_F32X3 3
 int sd_yolo_create_prec(sd_yolo** out, const sd_yolo_layer* layers, int n_layers, const float anchors[18], int classes, int net_w,
                         int net_h, int max_batch, int precision);
 int sd_yolo_precision(const sd_yolo* y, int* precision);
@@ -501,6 +505,9 @@ int sd_yolo_layer_shape(const sd_yolo* y, int layer, int* h, int* w, int* c);
 int sd_yolo_flops(const sd_yolo* y, double* flops_per_image);
 /* The MFMA FLOPs the chosen mode actually executes per image (== sd_yolo_flops except in SD_YOLO_F32W). */
 int sd_yolo_mfma_flops(const sd_yolo* y, double* flops_per_image);
+/* bf16 MFMA FLOPs per image executed by the limb kernels of SD_YOLO_F32X3 (0 in the other modes; sd_yolo_mfma_flops then counts
+ * only the layers that stay on the f32 MFMA). */
+int sd_yolo_mfma_flops_bf16(const sd_yolo* y, double* flops_per_image);
 /* How many convolutions the mode computes as Winograd F(2 x 2, 3 x 3) (0 except in SD_YOLO_F32W). */
 int sd_yolo_winograd_layers(const sd_yolo* y, int* n_layers);
 /* blobFromImage + net.forward + the confidence filter (yolo.cc:63-68,163-183) for n 8-bit 3-channel images in HBM

@@ -10,17 +10,22 @@
 #include "k_yolo.h"
 #include "k_yolo32.h"
 #include "k_yolo32w.h"
+#include "k_yolo32b.h"
 
 struct sd_yolo {
     std::vector<sd_yolo_layer> L;
     struct Rt { int H = 0, W = 0, C = 0; int cinPad = 0, coutPad = 0; size_t wOff = 0, bOff = 0; _Float16* out = nullptr; int outC = 0; bool alias = false;
-                bool wino = false; size_t wOffW = 0; };        // SD_YOLO_F32W: this layer runs as Winograd F(2x2, 3x3), its transformed weights at d_wgtW + wOffW
+                bool wino = false; size_t wOffW = 0;
+                bool b3 = false, b3flat = false; int b3wm = 2; size_t wOffB = 0; };          // SD_YOLO_F32X3: this layer runs on bf16 limbs (k_yolo32b.h), its split weights at d_wgtB + wOffB (16-byte units)        // SD_YOLO_F32W: this layer runs as Winograd F(2x2, 3x3), its transformed weights at d_wgtW + wOffW
     std::vector<Rt> R;
     int netW = 0, netH = 0, classes = 80, maxBatch = 0, nconv = 0;
     int f32 = 0;                   // SD_YOLO_F32: activations / weights / arithmetic in f32 (k_yolo32.h); the `out` pointers then hold floats
     float* d_blob8 = nullptr; float* d_wgt32 = nullptr; bool attrF32 = false, attrNms = false;
     int wino = 0;                  // SD_YOLO_F32W (k_yolo32w.h): f32 mode with the eligible 3 x 3 stride-1 layers as Winograd F(2x2, 3x3)
     float* d_wgtW = nullptr; float* d_V = nullptr; size_t wTotalW = 0; bool attrWino = false;
+    int b3 = 0;                    // SD_YOLO_F32X3 (k_yolo32b.h): f32 mode with the >= 128-filter layers on three bf16 limbs per operand
+    uint4* d_wgtB = nullptr; size_t wTotalB = 0; bool attrB3 = false;
+    double mfmaFlopsBf16 = 0;      // per image: bf16 MFMA FLOPs executed by the limb kernels (six limb products per product)
     double mfmaFlops = 0;          // per image, as executed (Winograd layers: 16 multiplies per 2 x 2 block instead of 36)
     float anchors[18];
     _Float16* d_blob4 = nullptr;   // network input, NHWC f16 x 4 channels

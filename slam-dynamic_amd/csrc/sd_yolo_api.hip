@@ -49,7 +49,8 @@ int sd_yolo_create_prec(sd_yolo** out, const sd_yolo_layer* layers, int n_layers
 {
     if (!out) return SD_ERR_INVALID;
     *out = nullptr;
-    if (precision != SD_YOLO_F16 && precision != SD_YOLO_F32 && precision != SD_YOLO_F32W) return set_err(SD_ERR_INVALID, "precision must be SD_YOLO_F16, SD_YOLO_F32 or SD_YOLO_F32W");
+    if (precision != SD_YOLO_F16 && precision != SD_YOLO_F32 && precision != SD_YOLO_F32W && precision != SD_YOLO_F32X3)
+        return set_err(SD_ERR_INVALID, "precision must be SD_YOLO_F16, SD_YOLO_F32, SD_YOLO_F32W or SD_YOLO_F32X3");
     if (!layers || n_layers < 1 || !anchors || classes != 80 || net_w < 32 || net_h < 32 || (net_w % 32) || (net_h % 32) || max_batch < 1)
         return set_err(SD_ERR_INVALID, "bad detector arguments (classes must be 80, net size a multiple of 32)");
     int ndev = 0;
@@ -58,9 +59,10 @@ int sd_yolo_create_prec(sd_yolo** out, const sd_yolo_layer* layers, int n_layers
     y->L.assign(layers, layers + n_layers);
     y->R.resize(n_layers);
     y->netW = net_w; y->netH = net_h; y->classes = classes; y->maxBatch = max_batch;
-    y->f32 = precision == SD_YOLO_F32 || precision == SD_YOLO_F32W;
+    y->f32 = precision == SD_YOLO_F32 || precision == SD_YOLO_F32W || precision == SD_YOLO_F32X3;
     y->wino = precision == SD_YOLO_F32W;
-    size_t wOffW = 0, vMax = 0;
+    y->b3 = precision == SD_YOLO_F32X3;
+    size_t wOffW = 0, vMax = 0, wOffB = 0;
     const size_t eb = y->f32 ? 4 : 2;                     // bytes per activation element
     memcpy(y->anchors, anchors, sizeof(y->anchors));
     // ---- shapes
@@ -90,6 +92,12 @@ int sd_yolo_create_prec(sd_yolo** out, const sd_yolo_layer* layers, int n_layers
                 r.wOffW = wOffW; wOffW += (size_t)r.coutPad * 16 * r.cinPad;
                 vMax = std::max(vMax, blocks * 16 * r.cinPad);
                 y->mfmaFlops += 2.0 * blocks * 16.0 * (double)l.filters * cinReal;
+            } else if (y->b3 && i > 0 && l.filters > 64 && (r.cinPad % 16) == 0) {
+                // three bf16 limbs per operand: the layers k_conv_f32 runs on 128-filter tiles
+                r.b3 = true;
+                r.b3flat = l.size == 3 && l.stride == 1 && r.W <= 160;       // k_conv3x3_b3: the nine taps share one staged chunk
+                r.wOffB = wOffB; wOffB += (size_t)(r.coutPad / 128) * (l.size * l.size * (r.cinPad / 16)) * 2 * 6 * 64;      // 16-byte fragments
+                y->mfmaFlopsBf16 += 6 * 2.0 * r.H * r.W * (double)l.filters * l.size * l.size * cinReal;
             } else y->mfmaFlops += 2.0 * r.H * r.W * (double)l.filters * l.size * l.size * cinReal;
             y->nconv++;
         } else if (l.type == SD_YOLO_SHORTCUT) {
@@ -116,7 +124,7 @@ int sd_yolo_create_prec(sd_yolo** out, const sd_yolo_layer* layers, int n_layers
         H = r.H; W = r.W; C = r.C;
         if ((l.type == SD_YOLO_CONV) && (r.C % 4) && r.C != 3 * (5 + classes)) { delete y; return set_err(SD_ERR_UNSUPPORTED, "filters must be a multiple of 4"); }
     }
-    y->wTotal = wOff; y->bTotal = bOff; y->wTotalW = wOffW;
+    y->wTotal = wOff; y->bTotal = bOff; y->wTotalW = wOffW; y->wTotalB = wOffB;
     y->detCap = 8192;
     // ---- device memory
     auto alloc = [&](void** p, size_t bytes) -> bool {
@@ -133,6 +141,7 @@ int sd_yolo_create_prec(sd_yolo** out, const sd_yolo_layer* layers, int n_layers
 
     if (y->f32) ok = ok && alloc((void**)&y->d_wgt32, wOff * 4 + 64);
     if (y->wino && wOffW) { ok = ok && alloc((void**)&y->d_wgtW, wOffW * 4 + 64); ok = ok && alloc((void**)&y->d_V, nB * vMax * 4 + 64); }
+    if (y->b3 && wOffB) ok = ok && alloc((void**)&y->d_wgtB, wOffB * 16 + 3 * 2 * 6 * 64 * 16);     // slack: the kernels request weight fragments up to two steps past a tile's last
     else ok = ok && alloc((void**)&y->d_wgt, wOff * 2 + 64);
     ok = ok && alloc((void**)&y->d_bias, bOff * 4 + 64);
     ok = ok && alloc((void**)&y->d_dets, nB * y->detCap * sizeof(SdDet));
@@ -255,6 +264,38 @@ int sd_yolo_load_darknet_weights(sd_yolo* y, const float* p, size_t n_floats)
             }
             HIPCHK(hipMemcpy(y->d_wgtW, wW.data(), y->wTotalW * 4, hipMemcpyHostToDevice));
         }
+        if (y->wTotalB) {
+            // SD_YOLO_F32X3: every folded weight as three bf16 limbs (round to nearest even, each limb of what the ones before left: the sum
+            // of the three is the f32 weight exactly), [coutPad][taps][cin / 4][limb][4]
+            auto bf16_rne = [](float v) -> uint16_t {
+                uint32_t u; memcpy(&u, &v, 4);
+                if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);
+                return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+            };
+            auto bf16_val = [](uint16_t b) -> float { uint32_t u = (uint32_t)b << 16; float v; memcpy(&v, &u, 4); return v; };
+            // fragment order: [filter tile of 128][K step][wave row (64 filters)][limb][m (32 filters)][lane = filter % 32 + 32 * (k / 8)][k % 8]
+            std::vector<uint16_t> wB(y->wTotalB * 8, 0);
+            for (size_t i = 0; i < y->L.size(); i++) {
+                const sd_yolo::Rt& r = y->R[i];
+                if (y->L[i].type != SD_YOLO_CONV || !r.b3) continue;
+                const int cin = r.cinPad, taps = y->L[i].size * y->L[i].size, F = y->L[i].filters;
+                const size_t ksteps = (size_t)taps * (cin / 16);
+                for (int f = 0; f < F; f++)
+                    for (int t = 0; t < taps; t++)
+                        for (int c = 0; c < cin; c++) {
+                            const float v = w32[r.wOff + ((size_t)f * taps + t) * cin + c];
+                            const uint16_t hi = bf16_rne(v); const float r1 = v - bf16_val(hi);
+                            const uint16_t mid = bf16_rne(r1); const float r2 = r1 - bf16_val(mid);
+                            const uint16_t lo = bf16_rne(r2);
+                            const size_t ks = r.b3flat ? (size_t)(c / 16) * 9 + t : (size_t)t * (cin / 16) + c / 16;      // k_conv3x3_b3 walks [chunk][tap]
+                            const int k = c % 16, lane = f % 32 + 32 * (k / 8), bm = 64 * r.b3wm, wmr = (f % bm) / 64, m = (f % 64) / 32;
+                            const size_t frag0 = (((size_t)(f / bm) * ksteps + ks) * r.b3wm + wmr) * 6;
+                            const uint16_t limb[3] = {hi, mid, lo};
+                            for (int l = 0; l < 3; l++) wB[((r.wOffB + (frag0 + 2 * l + m) * 64 + lane) * 8) + k % 8] = limb[l];
+                        }
+            }
+            HIPCHK(hipMemcpy(y->d_wgtB, wB.data(), y->wTotalB * 16, hipMemcpyHostToDevice));
+        }
         y->weightsLoaded = true;
         return SD_OK;
     }
@@ -306,6 +347,13 @@ int sd_yolo_flops(const sd_yolo* y, double* flops_per_image)
     return SD_OK;
 }
 
+int sd_yolo_mfma_flops_bf16(const sd_yolo* y, double* flops_per_image)
+{
+    if (!y || !flops_per_image) return SD_ERR_INVALID;
+    *flops_per_image = y->mfmaFlopsBf16;
+    return SD_OK;
+}
+
 int sd_yolo_winograd_layers(const sd_yolo* y, int* n_layers)
 {
     if (!y || !n_layers) return SD_ERR_INVALID;
@@ -351,6 +399,11 @@ static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int hei
         HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<16, 1, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(16, 1, 1, 4)));
         HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<16, 2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(16, 2, 2, 4)));
         HIPCHK(hipFuncSetAttribute((const void*)k_wino_gemm_f32<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_WINO_LDS(16, 2)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv_b3, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3_LDS));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3F_LDS(160, 128)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3F_LDS(160, 128)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3<5, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3F_LDS(160, 128)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3F_LDS(160, 128)));
         y->attrF32 = true;
     }
     // tile variant of the >= 128-filter layers: 3 (default) = 128 x 128 tiles on 4-wave workgroups with 16-channel K steps, 40 KB of LDS and 144
@@ -398,7 +451,20 @@ static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int hei
                 A.res = (const float*)y->R[f].out; A.resStride = y->R[f].outC;
             }
             const int npix = n * r.H * r.W;
-            if (i == 0)                         // 3 (-> 8) input channels, <= 32 filters
+            if (r.b3) {
+                A.tilesX = (npix + 127) / 128; A.tilesY = r.coutPad / 128; A.groupY = f32_group_y(A.tilesY, 128, A.cin * l.size * l.size * 3 / 2);
+                if (r.b3flat) {
+                    const int np = (4 * (128 + 2 * W + 2) + 255) / 256;
+                    const size_t lds = SD_B3F_LDS(W, 128);
+                    const dim3 grd(SD_F32_GRID(A.tilesX, A.tilesY));
+                    const uint4* wq = (const uint4*)(y->d_wgtB + r.wOffB);
+                    if (np <= 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv3x3_b3<3, 2>), grd, dim3(256), lds, s, A, wq);
+                    else if (np == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv3x3_b3<4, 2>), grd, dim3(256), lds, s, A, wq);
+                    else if (np == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv3x3_b3<5, 2>), grd, dim3(256), lds, s, A, wq);
+                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv3x3_b3<8, 2>), grd, dim3(256), lds, s, A, wq);
+                } else
+                hipLaunchKernelGGL(k_conv_b3, dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(256), SD_B3_LDS, s, A, (const uint4*)(y->d_wgtB + r.wOffB));
+            } else if (i == 0)                         // 3 (-> 8) input channels, <= 32 filters
                 { A.tilesX = (npix + 511) / 512; A.tilesY = (l.filters + 31) / 32; A.groupY = f32_group_y(A.tilesY, 32, A.cin * l.size * l.size); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<8, 1, 1, 8>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(512), SD_F32_LDS(8, 1, 1, 8), s, A); }
             else if (l.filters <= 32 && small4)
                 { A.tilesX = (npix + 255) / 256; A.tilesY = 1; A.groupY = f32_group_y(A.tilesY, 32, A.cin * l.size * l.size); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 1, 4>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(256), SD_F32_LDS(16, 1, 1, 4), s, A); }
@@ -569,7 +635,7 @@ int sd_yolo_download_layer(sd_yolo* y, int layer, int image, uint16_t* out)
 int sd_yolo_precision(const sd_yolo* y, int* precision)
 {
     if (!y || !precision) return SD_ERR_INVALID;
-    *precision = y->wino ? SD_YOLO_F32W : (y->f32 ? SD_YOLO_F32 : SD_YOLO_F16);
+    *precision = y->b3 ? SD_YOLO_F32X3 : (y->wino ? SD_YOLO_F32W : (y->f32 ? SD_YOLO_F32 : SD_YOLO_F16));
     return SD_OK;
 }
 

@@ -161,7 +161,7 @@ class Detector:
         L.sd_yolo_boxes.argtypes = [vp, i, i, i, f, f, vp, vp, vp, i, C.POINTER(i)]
         L.sd_yolo_mask_device.argtypes = [vp, i, i, i, f, f, vp, sz, C.POINTER(i), vp]
         fe.check(L.sd_yolo_create_prec(C.byref(self.h), fe._p(self.layers), len(self.layers), fe._p(self.anchors), 80, net_w, net_h, max_batch,
-                                       {"f16": 0, "f32": 1, "f32w": 2}[precision]))
+                                       {"f16": 0, "f32": 1, "f32w": 2, "f32x3": 3}[precision]))
 
     def close(self):
         if self.h:
@@ -193,6 +193,10 @@ class Detector:
         """MFMA FLOPs per image as the mode executes them (== flops() except for "f32w", whose Winograd layers run 16 / 36 of the multiplies)."""
         d = C.c_double(); fe.check(fe.lib().sd_yolo_mfma_flops(self.h, C.byref(d))); return d.value
 
+    def mfma_flops_bf16(self):
+        d = C.c_double(); fe.lib().sd_yolo_mfma_flops_bf16.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        fe.check(fe.lib().sd_yolo_mfma_flops_bf16(self.h, C.byref(d))); return d.value
+
     def winograd_layers(self):
         n = C.c_int(); fe.lib().sd_yolo_winograd_layers.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         fe.check(fe.lib().sd_yolo_winograd_layers(self.h, C.byref(n))); return n.value
@@ -202,7 +206,7 @@ class Detector:
 
     def layer_output(self, layer, image=0):
         h, w, c = self.layer_shape(layer)
-        out = np.zeros((h, w, c), np.float32 if self.precision in ("f32", "f32w") else np.float16)
+        out = np.zeros((h, w, c), np.float32 if self.precision in ("f32", "f32w", "f32x3") else np.float16)
         fe.check(fe.lib().sd_yolo_download_layer(self.h, layer, image, fe._p(out)))
         return out
 

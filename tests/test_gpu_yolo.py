@@ -128,7 +128,8 @@ def _boxes_from_ref(yo, layers, anchors, ref, W, H):
     return yo.postprocess(rows_ref, W, H, 0.5, 0.4)
 
 
-@pytest.mark.parametrize("prec", ["f32", "f32w"])     # f32w: Winograd F(2x2, 3x3) on the 3 x 3 stride-1 layers, same tolerance and same box-set bar
+# f32w: Winograd F(2x2, 3x3) on the 3 x 3 stride-1 layers; f32x3: three bf16 limbs per f32 operand on the >= 128-filter layers -- same tolerance, same box-set bar
+@pytest.mark.parametrize("prec", ["f32", "f32w", "f32x3"])
 def test_f32_mode_layers_vs_torch_fp32(det, pkg, prec):
     d32 = pkg.yolo.Detector(det["layers"], det["anchors"], 640, 480, max_batch=1, precision=prec)
     try:
@@ -138,8 +139,10 @@ def test_f32_mode_layers_vs_torch_fp32(det, pkg, prec):
         worst = 0.0
         if prec == "f32w":
             assert d32.mfma_flops() < 0.6 * d32.flops() and d32.winograd_layers() == 31, "the Winograd layers must actually be in use"
+        elif prec == "f32x3":
+            assert d32.mfma_flops_bf16() > 5 * 0.9 * d32.flops() and d32.mfma_flops() < 0.1 * d32.flops(), "the limb kernels must actually be in use"
         else:
-            assert d32.mfma_flops() == d32.flops() and d32.winograd_layers() == 0
+            assert d32.mfma_flops() == d32.flops() and d32.winograd_layers() == 0 and d32.mfma_flops_bf16() == 0
         for layer in (0, 1, 2, 4, 11, 36, 61, 74, 76, 79, 80, 81, 86, 88, 93, 98, 100, 105):     # 76, 80, 88, 100: 3 x 3 layers without a fused shortcut
             got = d32.layer_output(layer).transpose(2, 0, 1)
             exp = det["ref"][layer][0].numpy()
@@ -173,16 +176,18 @@ def test_box_sets_of_32_images_f32_exact_f16_counted(det, pkg, orc, synth):
     d32 = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=B, precision="f32")
     d16 = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=B, precision="f16")
     d32w = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=B, precision="f32w")
-    same32 = same16 = same32w = boxes_ref = boxes16_match = 0
-    bad32, bad32w = [], []
+    d32x = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=B, precision="f32x3")
+    same32 = same16 = same32w = same32x = boxes_ref = boxes16_match = 0
+    bad32, bad32w, bad32x = [], [], []
     try:
-        d32.load_weights(payload); d16.load_weights(payload); d32w.load_weights(payload)
+        d32.load_weights(payload); d16.load_weights(payload); d32w.load_weights(payload); d32x.load_weights(payload)
         for b0 in range(0, n_img, B):
             dev = torch.from_numpy(np.stack(imgs[b0:b0 + B])).cuda()
             d32.forward_device(dev.data_ptr(), W, H, W * 3, W * H * 3, B, 0.5)
             d16.forward_device(dev.data_ptr(), W, H, W * 3, W * H * 3, B, 0.5)
             d32w.forward_device(dev.data_ptr(), W, H, W * 3, W * H * 3, B, 0.5)
-            g32 = d32.boxes_batch(B, W, H); g16 = d16.boxes_batch(B, W, H); g32w = d32w.boxes_batch(B, W, H)
+            d32x.forward_device(dev.data_ptr(), W, H, W * 3, W * H * 3, B, 0.5)
+            g32 = d32.boxes_batch(B, W, H); g16 = d16.boxes_batch(B, W, H); g32w = d32w.boxes_batch(B, W, H); g32x = d32x.boxes_batch(B, W, H)
             for k in range(B):
                 blob = yo.blob_from_image(imgs[b0 + k], 640, 480, orc.resize_linear)
                 eb, ec, ef = _boxes_from_ref(yo, layers, anchors, yo.torch_forward(layers, per, blob), W, H)
@@ -190,23 +195,27 @@ def test_box_sets_of_32_images_f32_exact_f16_counted(det, pkg, orc, synth):
                 ok32 = np.array_equal(g32[k][0], eb) and np.array_equal(g32[k][1], ec)
                 ok16 = np.array_equal(g16[k][0], eb) and np.array_equal(g16[k][1], ec)
                 ok32w = np.array_equal(g32w[k][0], eb) and np.array_equal(g32w[k][1], ec)
-                same32 += ok32; same16 += ok16; same32w += ok32w
+                ok32x = np.array_equal(g32x[k][0], eb) and np.array_equal(g32x[k][1], ec)
+                same32 += ok32; same16 += ok16; same32w += ok32w; same32x += ok32x
+                if not ok32x:
+                    bad32x.append((b0 + k, len(eb), len(g32x[k][0])))
                 if not ok32w:
                     bad32w.append((b0 + k, len(eb), len(g32w[k][0])))
                 boxes16_match += sum(1 for r in eb if any(np.array_equal(r, q) for q in g16[k][0]))
                 if not ok32:
                     bad32.append((b0 + k, len(eb), len(g32[k][0])))
     finally:
-        d32.close(); d16.close(); d32w.close()
-    print("box sets equal to the torch-fp32 oracle: f32 mode %d / %d images, f32w (Winograd) mode %d / %d, f16 mode %d / %d images (%d of %d reference boxes reproduced bit for bit)"
-          % (same32, n_img, same32w, n_img, same16, n_img, boxes16_match, boxes_ref))
+        d32.close(); d16.close(); d32w.close(); d32x.close()
+    print("box sets equal to the torch-fp32 oracle: f32 mode %d / %d images, f32w (Winograd) mode %d / %d, f32x3 (bf16 limbs) mode %d / %d, f16 mode %d / %d images (%d of %d reference boxes reproduced bit for bit)"
+          % (same32, n_img, same32w, n_img, same32x, n_img, same16, n_img, boxes16_match, boxes_ref))
     assert boxes_ref >= n_img, "the synthetic weights must yield boxes"
     assert same32 == n_img, "f32 mode differs from the torch-fp32 oracle on images %r" % bad32
     assert same32w == n_img, "f32w mode differs from the torch-fp32 oracle on images %r" % bad32w
+    assert same32x == n_img, "f32x3 mode differs from the torch-fp32 oracle on images %r" % bad32x
     assert boxes16_match >= 0.5 * boxes_ref, "f16 mode: fewer than half of the reference boxes reproduced exactly"
 
 
-@pytest.mark.parametrize("prec", ["f32", "f32w"])
+@pytest.mark.parametrize("prec", ["f32", "f32w", "f32x3"])
 def test_f32_modes_odd_feature_maps_and_batch(gpu, pkg, orc, synth, prec):
     """A 352 x 224 network input: feature maps of 11 x 7 (odd both ways: the Winograd blocks of the last row / column hang over the edge),
     22 x 14 and 44 x 28; three different images in one batch, every image compared with its own torch-fp32 forward."""
