@@ -23,7 +23,8 @@ if n_torch:
     torch.set_num_threads(min(16, torch.get_num_threads() or 8))
 t_same = [0, 0]; t_boxes = 0; t_found = [0, 0]
 da = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=B, precision="f32")
-db = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=B, precision="f32w")
+OTHER = os.environ.get("FUZZ_YOLO_MODE", "f32w")          # the mode compared with the direct f32 one: f32w (Winograd) or f32x3 (bf16 limbs)
+db = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=B, precision=OTHER)
 da.load_weights(payload); db.load_weights(payload)
 cfg = synth.KITTI_STEREO
 W, H = cfg["width"], cfg["height"]
@@ -62,10 +63,10 @@ for b0 in range(0, n_img, B):
                 t_same[m] += np.array_equal(r[k][0], eb) and np.array_equal(r[k][1], ec)
                 t_found[m] += sum(1 for q in eb if any(np.array_equal(q, z) for z in r[k][0]))
 da.close(); db.close()
-print("fuzz_yolo: %d images, box sets identical on %d; %d of %d f32 boxes found bit for bit in the f32w set; largest confidence difference on identical sets %.3g"
-      % (n_img, same, boxes_same, boxes, worst_conf))
+print("fuzz_yolo: %d images, %s against f32: box sets identical on %d; %d of %d f32 boxes found bit for bit in the %s set; largest confidence difference on identical sets %.3g"
+      % (n_img, OTHER, same, boxes_same, boxes, OTHER, worst_conf))
 if n_torch:
-    print("against the torch-fp32 forward on the first %d images: f32 box sets equal on %d (%d of %d boxes), f32w on %d (%d of %d boxes)"
-          % (n_torch, t_same[0], t_found[0], t_boxes, t_same[1], t_found[1], t_boxes))
+    print("against the torch-fp32 forward on the first %d images: f32 box sets equal on %d (%d of %d boxes), %s on %d (%d of %d boxes)"
+          % (n_torch, t_same[0], t_found[0], t_boxes, OTHER, t_same[1], t_found[1], t_boxes))
 if diff:
-    print("differing images (index, boxes f32, boxes f32w):", diff[:20])
+    print("differing images (index, boxes f32, boxes %s):" % OTHER, diff[:20])
