@@ -213,10 +213,11 @@ __global__ void __launch_bounds__(256, 2) k_conv_b3(SdConvArgsF A, const uint4* 
 // write (4 - 9 x fewer of each: the halo costs (128 + 2 W + 2) / 128), one barrier pair per 216 MFMAs instead of one per 24; what remains per
 // tap is six weight-fragment requests, six fragment reads and two address selects.  K order = [chunk][tap] (the host lays the weight
 // fragments out in that order).  NP = activation pieces per thread and chunk = ceil(4 R / 256).
-template <int NP, int WM>
-__global__ void __launch_bounds__(256, 2) k_conv3x3_b3(SdConvArgsF A, const uint4* __restrict__ wgt3)
+template <int NP, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) k_conv3x3_b3(SdConvArgsF A, const uint4* __restrict__ wgt3)
 {
-    constexpr int NT = 256, WN = 4 / WM, BM = 64 * WM, BN = 64 * WN, BK = 16;      // WM = 2: 128 filters x 128 pixels; WM = 1: 64 x 256, the four waves share ONE set of weight fragments
+    constexpr int NT = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN, BK = 16;      // <2, 2>: 128 filters x 128 pixels, two workgroups per CU; <2, 4>: 128 x 256 on eight waves, one per CU:
+                                                                               // half the weight-fragment bytes and 0.7 x the halo per MFMA
     extern __shared__ __align__(16) unsigned char smemb[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r32 = lane & 31, h = lane >> 5;
     const int wm = wv % WM, wn = wv / WM;

@@ -400,10 +400,10 @@ static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int hei
         HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<16, 2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(16, 2, 2, 4)));
         HIPCHK(hipFuncSetAttribute((const void*)k_wino_gemm_f32<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_WINO_LDS(16, 2)));
         HIPCHK(hipFuncSetAttribute((const void*)k_conv_b3, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3_LDS));
-        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3F_LDS(160, 128)));
-        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3F_LDS(160, 128)));
-        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3<5, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3F_LDS(160, 128)));
-        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3F_LDS(160, 128)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3<3, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3F_LDS(160, 128)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3<4, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3F_LDS(160, 128)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3<5, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3F_LDS(160, 128)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3<8, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3F_LDS(160, 128)));
         y->attrF32 = true;
     }
     // tile variant of the >= 128-filter layers: 3 (default) = 128 x 128 tiles on 4-wave workgroups with 16-channel K steps, 40 KB of LDS and 144
@@ -454,14 +454,14 @@ static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int hei
             if (r.b3) {
                 A.tilesX = (npix + 127) / 128; A.tilesY = r.coutPad / 128; A.groupY = f32_group_y(A.tilesY, 128, A.cin * l.size * l.size * 3 / 2);
                 if (r.b3flat) {
+                    const uint4* wq = (const uint4*)(y->d_wgtB + r.wOffB);
                     const int np = (4 * (128 + 2 * W + 2) + 255) / 256;
                     const size_t lds = SD_B3F_LDS(W, 128);
                     const dim3 grd(SD_F32_GRID(A.tilesX, A.tilesY));
-                    const uint4* wq = (const uint4*)(y->d_wgtB + r.wOffB);
-                    if (np <= 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv3x3_b3<3, 2>), grd, dim3(256), lds, s, A, wq);
-                    else if (np == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv3x3_b3<4, 2>), grd, dim3(256), lds, s, A, wq);
-                    else if (np == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv3x3_b3<5, 2>), grd, dim3(256), lds, s, A, wq);
-                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv3x3_b3<8, 2>), grd, dim3(256), lds, s, A, wq);
+                    if (np <= 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv3x3_b3<3, 2, 2>), grd, dim3(256), lds, s, A, wq);
+                    else if (np == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv3x3_b3<4, 2, 2>), grd, dim3(256), lds, s, A, wq);
+                    else if (np == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv3x3_b3<5, 2, 2>), grd, dim3(256), lds, s, A, wq);
+                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv3x3_b3<8, 2, 2>), grd, dim3(256), lds, s, A, wq);
                 } else
                 hipLaunchKernelGGL(k_conv_b3, dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(256), SD_B3_LDS, s, A, (const uint4*)(y->d_wgtB + r.wOffB));
             } else if (i == 0)                         // 3 (-> 8) input channels, <= 32 filters

@@ -101,7 +101,8 @@ private:
     sd_yolo* net = nullptr;
 
     // precision: SD_YOLO_F32 (default) computes like cv::dnn on DNN_TARGET_CPU does (yolo.cc:29), in f32; SD_YOLO_F32W the same with the
-    // 3 x 3 stride-1 layers as Winograd F(2x2, 3x3) (1.4 x faster, same tolerance and box-set tests); SD_YOLO_F16 is the throughput mode
+    // 3 x 3 stride-1 layers as Winograd F(2x2, 3x3) (1.4 x faster, same tolerance and box-set tests); SD_YOLO_F32X3 the f32 operands as three bf16
+    // limbs on the bf16 MFMA (1.45 x faster, same tests); SD_YOLO_F16 is the throughput mode
     // (f16 operands: 4.5 x faster, boxes can move by a pixel).
     void load(const std::string& modelConfiguration, const std::string& modelWeights, int precision)
     {
