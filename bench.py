@@ -779,7 +779,9 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline, vocab=None):
     if name == "kitti-batch":
         return run_sequence_batch(args, rank, world, dev, pkg, dist, detector=not args.kitti_no_detector)
     wl = Workload(name, args, rank, world, dev, pkg, dist, vocab=vocab)
-    steps, warm = (args.steps, args.warmup) if headline else (args.extra_steps, 1)
+    # extras: the detector-less workloads step in 2 - 5 ms, so 12 steps would be a 30 ms sample (one allocator hiccup moved `rgbd` by a quarter);
+    # they run 5 x as many steps behind 3 warm-up steps
+    steps, warm = (args.steps, args.warmup) if headline else ((args.extra_steps, 1) if name.startswith("stereo-yolo") else (5 * args.extra_steps, 3))
     prof_steps = 4 if (not args.no_profile and (headline or name in ("stereo", "rgbd-bow", "stereo-yolo-f32w", "stereo-yolo-f32x3"))) else 0
     wl.prepare(1 + warm + steps + prof_steps + 1)
     batch = wl.batch
