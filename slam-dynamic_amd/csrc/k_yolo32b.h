@@ -15,6 +15,7 @@
 typedef __bf16 sd_b8 __attribute__((ext_vector_type(8)));
 typedef __bf16 sd_b2 __attribute__((ext_vector_type(2)));
 typedef float sd_f2v __attribute__((ext_vector_type(2)));
+typedef unsigned int sd_u4w __attribute__((ext_vector_type(4)));
 
 // two floats -> their three bf16 limbs, packed (element 0 in the low half)
 __device__ __forceinline__ void sd_split3(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo)
@@ -384,3 +385,180 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) k_conv3x3_
     }
 }
 #define SD_B3F_LDS(W, BN) (3 * ((BN) + 2 * (W) + 2 + 1) * SD_B3_ROWB)
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_conv3x3_b3 with the WEIGHTS of a chunk staged too.  What bounds k_conv3x3_b3 is the issue of vector-memory instructions, not their bytes
+// or their latency: a 1 KB request costs the issuing wave ~60 cycles of its instruction stream among MFMAs (MI355X_MICROARCH.md, per-
+// instruction constants; tools/micro/mfma_operands.hip reproduces the kernel's step: 98 % of the bf16 MFMA rate without the six weight
+// requests per 24 MFMAs, 60 % with them, wherever they come from), and six of them per 768 MFMA cycles is half a wave's time.  Here a
+// workgroup of EIGHT waves owns 64 filters x 512 consecutive pixels (every wave the same 64 filters, its own 64 pixels) and stages per
+// 16-channel chunk BOTH operands once: the activations as in k_conv3x3_b3 (range + halo, split, three limb planes) and the chunk's 9 taps x
+// six weight fragments = 54 KB, copied as they are (the host's fragment order IS the LDS image: slot (tap, fragment) = 1 KB, read back with
+// ds_read_b128 at lane * 16).  Per thread and chunk: 7 + 6 requests of 16 bytes instead of 54 + 5; per tap nothing but twelve LDS reads and
+// 24 MFMAs, no barrier; two barriers per chunk.  One workgroup per CU (152 KB of LDS at W = 80), two waves per SIMD.
+#define SD_B3C_WBYTES (9 * 6 * 1024)
+#define SD_B3C_LDS(W) (3 * (512 + 2 * (W) + 2 + 1) * SD_B3_ROWB + SD_B3C_WBYTES)
+template <int NP>
+__global__ void __launch_bounds__(512, 1) k_conv3x3_b3c(SdConvArgsF A, const uint4* __restrict__ wgt3)
+{
+    constexpr int NT = 512, BM = 64, BN = 512, BK = 16, NWP = (SD_B3C_WBYTES / 16 + NT - 1) / NT;      // 3456 weight pieces: 6.75 -> 7 per thread
+    extern __shared__ __align__(16) unsigned char smemb[];
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6, r32 = lane & 31, h = lane >> 5;
+    const int perXcd = (A.tilesX + 7) >> 3;
+    const int slot = blockIdx.x >> 3, perGroup = perXcd * A.groupY;
+    const int grp = slot / perGroup, rg = slot - grp * perGroup;
+    const int tx = (blockIdx.x & 7) * perXcd + rg / A.groupY, ty = grp * A.groupY + rg % A.groupY;
+    if (tx >= A.tilesX) return;
+    const int pix0 = tx * BN, co0 = ty * BM;
+    const int npix = A.N * A.H * A.W;
+    const int W = A.W;
+    const int R = BN + 2 * W + 2;
+    const int PLANE = (R + 1) * SD_B3_ROWB;
+    unsigned char* wlds = smemb + 3 * PLANE;
+    const int nchunks = A.cin / BK;
+    const float* xptr[NP];
+    int xoff[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const int piece = tid + NT * i;
+        const int row = piece >> 2, q = piece & 3;
+        const bool on = row < R;
+        const int g = min(max(pix0 - W - 1 + row, 0), npix - 1);
+        xptr[i] = A.in + (size_t)g * A.cinStride + 4 * q;
+        xoff[i] = on ? row * SD_B3_ROWB + 8 * q : -1;
+    }
+    const uint4* wsrc = wgt3 + (size_t)ty * nchunks * (SD_B3C_WBYTES / 16) + tid;
+    const bool wlast = tid + NT * (NWP - 1) < SD_B3C_WBYTES / 16;      // the seventh piece exists for the first 384 threads
+    sd_f4 xr[NP];
+    sd_u4w wr[NWP];
+    auto fetch = [&]() {
+#pragma unroll
+        for (int i = 0; i < NWP; i++) wr[i] = *(const sd_u4w*)(wsrc + NT * i);      // all seven unconditionally (the last 128 threads' seventh piece is the next chunk's, not stored): a
+        wsrc += SD_B3C_WBYTES / 16;                               // conditionally written element sends the whole array to scratch and the requests wait right there
+#pragma unroll
+        for (int i = 0; i < NP; i++) { xr[i] = *(const sd_f4*)xptr[i]; xptr[i] += BK; }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int i = 0; i < NWP - 1; i++) *(sd_u4w*)(wlds + (tid + NT * i) * 16) = wr[i];
+        if (wlast) *(sd_u4w*)(wlds + (tid + NT * (NWP - 1)) * 16) = wr[NWP - 1];
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            if (xoff[i] < 0) continue;
+            uint2 l3[3];
+            sd_split3(xr[i][0], xr[i][1], l3[0].x, l3[1].x, l3[2].x);
+            sd_split3(xr[i][2], xr[i][3], l3[0].y, l3[1].y, l3[2].y);
+#pragma unroll
+            for (int l = 0; l < 3; l++) *(uint2*)(smemb + l * PLANE + xoff[i]) = l3[l];
+        }
+    };
+    int bbase[2];
+    unsigned tapok[2];
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+        const int pl = 64 * wn + 32 * n + r32, p = pix0 + pl;
+        bbase[n] = pl * SD_B3_ROWB + 16 * h;
+        unsigned m = 0;
+        if (p < npix) {
+            const int r = p % (A.H * W);
+            const int y = r / W, x = r - y * W;
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                if (yy >= 0 && yy < A.H && xx >= 0 && xx < W) m |= 1u << t;
+            }
+        }
+        tapok[n] = m;
+    }
+    const int zrow = R * SD_B3_ROWB + 16 * h;
+    if (tid < 3 * (SD_B3_ROWB / 4)) ((uint32_t*)(smemb + (tid / (SD_B3_ROWB / 4)) * PLANE + R * SD_B3_ROWB))[tid % (SD_B3_ROWB / 4)] = 0u;
+    sd_f16v acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+    sd_b8 fa[3][2], fb[3][2];
+    auto fragsW = [&](const int t, const int l) {
+#pragma unroll
+        for (int m = 0; m < 2; m++) fa[l][m] = *(const sd_b8*)(wlds + (t * 6 + 2 * l + m) * 1024 + lane * 16);
+    };
+    auto fragsX = [&](const int t, const int l) {
+        const int off = ((t / 3) * W + t % 3) * SD_B3_ROWB;
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            const int a = (tapok[n] >> t) & 1u ? bbase[n] + off : zrow;
+            fb[l][n] = *(const sd_b8*)(smemb + l * PLANE + a);
+        }
+    };
+    auto mfmas = [&](const int la, const int lb) {
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[la][m], fb[lb][n], acc[m][n], 0, 0, 0);
+    };
+    auto tap = [&](const int t) {
+        fragsW(t, 0); fragsX(t, 0);
+        fragsW(t, 1); fragsX(t, 1);
+        mfmas(0, 0);
+        fragsW(t, 2); fragsX(t, 2);
+        mfmas(0, 1);
+        mfmas(1, 0);
+        mfmas(1, 1);
+        mfmas(0, 2);
+        mfmas(2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    fetch();
+    store();
+    __syncthreads();
+    for (int c = 0; c < nchunks; c++) {
+        fetch();                                         // the next chunk's 13 requests per thread travel under this chunk's 216 MFMAs (unconditional: one chunk past the
+        __builtin_amdgcn_sched_barrier(0);               // tile's last lands in the weight buffer's slack / the next pixel's channels)
+        tap(0); tap(1); tap(2); tap(3); tap(4); tap(5); tap(6); tap(7); tap(8);
+        if (c + 1 < nchunks) {
+            __syncthreads();
+            store();
+            __syncthreads();
+        }
+    }
+    // ---- epilogue: as k_conv_b3, 64 filters
+    sd_f4 rr[2][2][4];
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+        const int p = pix0 + 64 * wn + 32 * n + r32;
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int co = co0 + 32 * m + 8 * g + 4 * h;
+                rr[n][m][g] = sd_f4{0.f, 0.f, 0.f, 0.f};
+                if (A.res && p < npix && co < A.cout) rr[n][m][g] = *(const sd_f4*)(A.res + (size_t)p * A.resStride + co);
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+        const int p = pix0 + 64 * wn + 32 * n + r32;
+        if (p >= npix) continue;
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int co = co0 + 32 * m + 8 * g + 4 * h;
+                if (co >= A.cout) continue;
+                sd_f4 v;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float x = acc[m][n][4 * g + e] + A.bias[co + e];
+                    if (A.leaky) x = x > 0.f ? x : 0.1f * x;
+                    v[e] = x + rr[n][m][g][e];
+                }
+                float* dst = A.out + (size_t)p * A.outStride + co;
+                if (co + 3 < A.cout) *(sd_f4*)dst = v;
+                else for (int e = 0; e < 4 && co + e < A.cout; e++) dst[e] = v[e];
+            }
+    }
+}

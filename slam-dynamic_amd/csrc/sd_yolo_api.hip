@@ -96,6 +96,7 @@ int sd_yolo_create_prec(sd_yolo** out, const sd_yolo_layer* layers, int n_layers
                 // three bf16 limbs per operand: the layers k_conv_f32 runs on 128-filter tiles
                 r.b3 = true;
                 r.b3flat = l.size == 3 && l.stride == 1 && r.W <= 160;       // k_conv3x3_b3: the nine taps share one staged chunk
+                r.b3wm = r.b3flat && r.W <= 80 ? 1 : 2;                      // 1: k_conv3x3_b3c (64-filter tiles, weights staged per chunk too); wider maps do not fit its LDS
                 r.wOffB = wOffB; wOffB += (size_t)(r.coutPad / 128) * (l.size * l.size * (r.cinPad / 16)) * 2 * 6 * 64;      // 16-byte fragments
                 y->mfmaFlopsBf16 += 6 * 2.0 * r.H * r.W * (double)l.filters * l.size * l.size * cinReal;
             } else y->mfmaFlops += 2.0 * r.H * r.W * (double)l.filters * l.size * l.size * cinReal;
@@ -141,7 +142,7 @@ int sd_yolo_create_prec(sd_yolo** out, const sd_yolo_layer* layers, int n_layers
 
     if (y->f32) ok = ok && alloc((void**)&y->d_wgt32, wOff * 4 + 64);
     if (y->wino && wOffW) { ok = ok && alloc((void**)&y->d_wgtW, wOffW * 4 + 64); ok = ok && alloc((void**)&y->d_V, nB * vMax * 4 + 64); }
-    if (y->b3 && wOffB) ok = ok && alloc((void**)&y->d_wgtB, wOffB * 16 + 3 * 2 * 6 * 64 * 16);     // slack: the kernels request weight fragments up to two steps past a tile's last
+    if (y->b3 && wOffB) ok = ok && alloc((void**)&y->d_wgtB, wOffB * 16 + 65536);     // slack: the kernels request weight fragments up to two steps past a tile's last
     else ok = ok && alloc((void**)&y->d_wgt, wOff * 2 + 64);
     ok = ok && alloc((void**)&y->d_bias, bOff * 4 + 64);
     ok = ok && alloc((void**)&y->d_dets, nB * y->detCap * sizeof(SdDet));
@@ -404,6 +405,8 @@ static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int hei
         HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3<4, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3F_LDS(160, 128)));
         HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3<5, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3F_LDS(160, 128)));
         HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3<8, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3F_LDS(160, 128)));
+HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3c<5>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3C_LDS(80)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3c<6>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3C_LDS(80)));
         y->attrF32 = true;
     }
     // tile variant of the >= 128-filter layers: 3 (default) = 128 x 128 tiles on 4-wave workgroups with 16-channel K steps, 40 KB of LDS and 144
@@ -453,7 +456,14 @@ static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int hei
             const int npix = n * r.H * r.W;
             if (r.b3) {
                 A.tilesX = (npix + 127) / 128; A.tilesY = r.coutPad / 128; A.groupY = f32_group_y(A.tilesY, 128, A.cin * l.size * l.size * 3 / 2);
-                if (r.b3flat) {
+                if (r.b3flat && r.b3wm == 1) {
+                    const uint4* wq = (const uint4*)(y->d_wgtB + r.wOffB);
+                    A.tilesX = (npix + 511) / 512; A.tilesY = r.coutPad / 64; A.groupY = f32_group_y(A.tilesY, 64, A.cin * 9 * 3 / 2);
+                    const int np = (4 * (512 + 2 * W + 2) + 511) / 512;
+                    const dim3 grd(SD_F32_GRID(A.tilesX, A.tilesY));
+                    if (np <= 5) hipLaunchKernelGGL(k_conv3x3_b3c<5>, grd, dim3(512), SD_B3C_LDS(W), s, A, wq);
+                    else hipLaunchKernelGGL(k_conv3x3_b3c<6>, grd, dim3(512), SD_B3C_LDS(W), s, A, wq);
+                } else if (r.b3flat) {
                     const uint4* wq = (const uint4*)(y->d_wgtB + r.wOffB);
                     const int np = (4 * (128 + 2 * W + 2) + 255) / 256;
                     const size_t lds = SD_B3F_LDS(W, 128);
