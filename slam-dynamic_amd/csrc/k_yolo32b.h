@@ -405,30 +405,43 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_b3c(SdConvArgsF A, const uin
     constexpr int NT = 512, BM = 64, BN = 512, BK = 16, NWP = (SD_B3C_WBYTES / 16 + NT - 1) / NT;      // 3456 weight pieces: 6.75 -> 7 per thread
     extern __shared__ __align__(16) unsigned char smemb[];
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6, r32 = lane & 31, h = lane >> 5;
-    const int perXcd = (A.tilesX + 7) >> 3;
-    const int slot = blockIdx.x >> 3, perGroup = perXcd * A.groupY;
-    const int grp = slot / perGroup, rg = slot - grp * perGroup;
-    const int tx = (blockIdx.x & 7) * perXcd + rg / A.groupY, ty = grp * A.groupY + rg % A.groupY;
-    if (tx >= A.tilesX) return;
-    const int pix0 = tx * BN, co0 = ty * BM;
+    // PERSISTENT workgroups: the launch is one workgroup per CU (8 XCDs x 32), and workgroup w of an XCD walks that XCD's tiles w, w + 32, ... in
+    // k_conv_f32's XCD-aware order.  With one workgroup per CU nothing else covers a tile's launch, first staging and epilogue (measured ~20 % of
+    // these layers), so the tiles are chained instead: the last chunk of a tile requests the FIRST chunk of the next one, the epilogue's stores
+    // leave while that chunk is split into LDS, and the matrix pipe only stops for the two barriers.
+    const int perXcd = (A.tilesX + 7) >> 3, perGroup = perXcd * A.groupY, slots = perXcd * A.tilesY, stride = gridDim.x >> 3;
     const int npix = A.N * A.H * A.W;
     const int W = A.W;
     const int R = BN + 2 * W + 2;
     const int PLANE = (R + 1) * SD_B3_ROWB;
     unsigned char* wlds = smemb + 3 * PLANE;
     const int nchunks = A.cin / BK;
-    const float* xptr[NP];
-    int xoff[NP];
+    auto tile_of = [&](int& slot, int& tx, int& ty) -> bool {      // the first valid tile at or after `slot` on this workgroup's list (the last XCD's
+        for (; slot < slots; slot += stride) {                       // list has holes: pixel tiles beyond tilesX)
+            const int grp = slot / perGroup, rg = slot - grp * perGroup;
+            tx = (blockIdx.x & 7) * perXcd + rg / A.groupY; ty = grp * A.groupY + rg % A.groupY;
+            if (tx < A.tilesX) return true;
+        }
+        return false;
+    };
+    // the staging map does not depend on the tile: piece i of this thread = (row, 4-channel quarter) of the staged pixel range
+    int xoff[NP], xrow[NP];
 #pragma unroll
     for (int i = 0; i < NP; i++) {
         const int piece = tid + NT * i;
-        const int row = piece >> 2, q = piece & 3;
-        const bool on = row < R;
-        const int g = min(max(pix0 - W - 1 + row, 0), npix - 1);
-        xptr[i] = A.in + (size_t)g * A.cinStride + 4 * q;
-        xoff[i] = on ? row * SD_B3_ROWB + 8 * q : -1;
+        xrow[i] = piece >> 2;
+        xoff[i] = (piece >> 2) < R ? (piece >> 2) * SD_B3_ROWB + 8 * (piece & 3) : -1;
     }
-    const uint4* wsrc = wgt3 + (size_t)ty * nchunks * (SD_B3C_WBYTES / 16) + tid;
+    const float* xptr[NP];
+    const uint4* wsrc = wgt3;
+    auto point_at = [&](const int tx, const int ty) {    // the staging pointers of a tile's first chunk
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const int g = min(max(tx * BN - W - 1 + xrow[i], 0), npix - 1);
+            xptr[i] = A.in + (size_t)g * A.cinStride + 4 * (tid & 3);
+        }
+        wsrc = wgt3 + (size_t)ty * nchunks * (SD_B3C_WBYTES / 16) + tid;
+    };
     const bool wlast = tid + NT * (NWP - 1) < SD_B3C_WBYTES / 16;      // the seventh piece exists for the first 384 threads
     sd_f4 xr[NP];
     sd_u4w wr[NWP];
@@ -454,32 +467,29 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_b3c(SdConvArgsF A, const uin
         }
     };
     int bbase[2];
+#pragma unroll
+    for (int n = 0; n < 2; n++) bbase[n] = (64 * wn + 32 * n + r32) * SD_B3_ROWB + 16 * h;
     unsigned tapok[2];
+    auto masks = [&](const int pix0) {                  // which taps of this lane's two pixels stay inside the image
 #pragma unroll
-    for (int n = 0; n < 2; n++) {
-        const int pl = 64 * wn + 32 * n + r32, p = pix0 + pl;
-        bbase[n] = pl * SD_B3_ROWB + 16 * h;
-        unsigned m = 0;
-        if (p < npix) {
-            const int r = p % (A.H * W);
-            const int y = r / W, x = r - y * W;
+        for (int n = 0; n < 2; n++) {
+            const int p = pix0 + 64 * wn + 32 * n + r32;
+            unsigned m = 0;
+            if (p < npix) {
+                const int r = p % (A.H * W);
+                const int y = r / W, x = r - y * W;
 #pragma unroll
-            for (int t = 0; t < 9; t++) {
-                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-                if (yy >= 0 && yy < A.H && xx >= 0 && xx < W) m |= 1u << t;
+                for (int t = 0; t < 9; t++) {
+                    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                    if (yy >= 0 && yy < A.H && xx >= 0 && xx < W) m |= 1u << t;
+                }
             }
+            tapok[n] = m;
         }
-        tapok[n] = m;
-    }
+    };
     const int zrow = R * SD_B3_ROWB + 16 * h;
     if (tid < 3 * (SD_B3_ROWB / 4)) ((uint32_t*)(smemb + (tid / (SD_B3_ROWB / 4)) * PLANE + R * SD_B3_ROWB))[tid % (SD_B3_ROWB / 4)] = 0u;
     sd_f16v acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int n = 0; n < 2; n++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
     sd_b8 fa[3][2], fb[3][2];
     auto fragsW = [&](const int t, const int l) {
 #pragma unroll
@@ -512,53 +522,71 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_b3c(SdConvArgsF A, const uin
         mfmas(2, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
+    int slot = blockIdx.x >> 3, tx, ty;
+    bool have = tile_of(slot, tx, ty);
+    if (!have) return;                                   // (slots of an XCD beyond its last pixel tile sit at the end of its list)
+    point_at(tx, ty);
     fetch();
     store();
     __syncthreads();
-    for (int c = 0; c < nchunks; c++) {
-        fetch();                                         // the next chunk's 13 requests per thread travel under this chunk's 216 MFMAs (unconditional: one chunk past the
-        __builtin_amdgcn_sched_barrier(0);               // tile's last lands in the weight buffer's slack / the next pixel's channels)
-        tap(0); tap(1); tap(2); tap(3); tap(4); tap(5); tap(6); tap(7); tap(8);
-        if (c + 1 < nchunks) {
-            __syncthreads();
-            store();
-            __syncthreads();
+    while (have) {
+        const int pix0 = tx * BN, co0 = ty * BM;
+        masks(pix0);
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+        int ntx, nty, nslot = slot + stride;
+        const bool more = tile_of(nslot, ntx, nty);
+        for (int c = 0; c < nchunks; c++) {
+            if (c + 1 == nchunks && more) point_at(ntx, nty);      // the last chunk of a tile requests the first chunk of the next
+            fetch();                                     // 13 requests per thread under this chunk's 216 MFMAs (unconditional: past the very last chunk they land in the
+            __builtin_amdgcn_sched_barrier(0);           // weight buffer's slack / the next pixel's channels and are dropped)
+            tap(0); tap(1); tap(2); tap(3); tap(4); tap(5); tap(6); tap(7); tap(8);
+            if (c + 1 < nchunks || more) {
+                __syncthreads();
+                store();
+                __syncthreads();
+            }
         }
-    }
-    // ---- epilogue: as k_conv_b3, 64 filters
-    sd_f4 rr[2][2][4];
+        // ---- epilogue: as k_conv_b3, 64 filters (its loads and stores overlap the next tile's first taps)
+        sd_f4 rr[2][2][4];
 #pragma unroll
-    for (int n = 0; n < 2; n++) {
-        const int p = pix0 + 64 * wn + 32 * n + r32;
+        for (int n = 0; n < 2; n++) {
+            const int p = pix0 + 64 * wn + 32 * n + r32;
 #pragma unroll
-        for (int m = 0; m < 2; m++)
+            for (int m = 0; m < 2; m++)
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int co = co0 + 32 * m + 8 * g + 4 * h;
-                rr[n][m][g] = sd_f4{0.f, 0.f, 0.f, 0.f};
-                if (A.res && p < npix && co < A.cout) rr[n][m][g] = *(const sd_f4*)(A.res + (size_t)p * A.resStride + co);
-            }
-    }
-#pragma unroll
-    for (int n = 0; n < 2; n++) {
-        const int p = pix0 + 64 * wn + 32 * n + r32;
-        if (p >= npix) continue;
-#pragma unroll
-        for (int m = 0; m < 2; m++)
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int co = co0 + 32 * m + 8 * g + 4 * h;
-                if (co >= A.cout) continue;
-                sd_f4 v;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float x = acc[m][n][4 * g + e] + A.bias[co + e];
-                    if (A.leaky) x = x > 0.f ? x : 0.1f * x;
-                    v[e] = x + rr[n][m][g][e];
+                for (int g = 0; g < 4; g++) {
+                    const int co = co0 + 32 * m + 8 * g + 4 * h;
+                    rr[n][m][g] = sd_f4{0.f, 0.f, 0.f, 0.f};
+                    if (A.res && p < npix && co < A.cout) rr[n][m][g] = *(const sd_f4*)(A.res + (size_t)p * A.resStride + co);
                 }
-                float* dst = A.out + (size_t)p * A.outStride + co;
-                if (co + 3 < A.cout) *(sd_f4*)dst = v;
-                else for (int e = 0; e < 4 && co + e < A.cout; e++) dst[e] = v[e];
-            }
+        }
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            const int p = pix0 + 64 * wn + 32 * n + r32;
+            if (p >= npix) continue;
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int co = co0 + 32 * m + 8 * g + 4 * h;
+                    if (co >= A.cout) continue;
+                    sd_f4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        float x = acc[m][n][4 * g + e] + A.bias[co + e];
+                        if (A.leaky) x = x > 0.f ? x : 0.1f * x;
+                        v[e] = x + rr[n][m][g][e];
+                    }
+                    float* dst = A.out + (size_t)p * A.outStride + co;
+                    if (co + 3 < A.cout) *(sd_f4*)dst = v;
+                    else for (int e = 0; e < 4 && co + e < A.cout; e++) dst[e] = v[e];
+                }
+        }
+        slot = nslot; tx = ntx; ty = nty; have = more;
     }
 }

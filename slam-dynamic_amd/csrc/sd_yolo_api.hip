@@ -460,7 +460,7 @@ HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3c<5>, hipFuncAttributeMaxDyn
                     const uint4* wq = (const uint4*)(y->d_wgtB + r.wOffB);
                     A.tilesX = (npix + 511) / 512; A.tilesY = r.coutPad / 64; A.groupY = f32_group_y(A.tilesY, 64, A.cin * 9 * 3 / 2);
                     const int np = (4 * (512 + 2 * W + 2) + 511) / 512;
-                    const dim3 grd(SD_F32_GRID(A.tilesX, A.tilesY));
+                    const dim3 grd(8 * (unsigned)std::min(((A.tilesX + 7) / 8) * A.tilesY, 32));      // persistent: one workgroup per CU, 32 per XCD
                     if (np <= 5) hipLaunchKernelGGL(k_conv3x3_b3c<5>, grd, dim3(512), SD_B3C_LDS(W), s, A, wq);
                     else hipLaunchKernelGGL(k_conv3x3_b3c<6>, grd, dim3(512), SD_B3C_LDS(W), s, A, wq);
                 } else if (r.b3flat) {
