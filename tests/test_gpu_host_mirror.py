@@ -32,7 +32,7 @@ def test_cpp_orbextractor_matches_oracle(gpu, fe, orc, synth, tmp_path):
     assert np.array_equal(plane, o.pyramid(1))
 
 
-@pytest.mark.parametrize("prec", ["default", "f16", "f32w"])
+@pytest.mark.parametrize("prec", ["default", "f16", "f32w", "f32x3"])
 def test_cpp_yolov3segment_matches_python_detector(gpu, pkg, fe, synth, tmp_path, prec):
     """host/yolo.h: Darknet cfg + weights files -> Segmentation_ boxes and Segmentation mask, equal to the ctypes Detector's.  The class
     computes in f32 unless told otherwise (cv::dnn's arithmetic, yolo.cc:29); the other two modes are constructor arguments."""
@@ -55,7 +55,7 @@ def test_cpp_yolov3segment_matches_python_detector(gpu, pkg, fe, synth, tmp_path
     H, W = img.shape[:2]
     raw = tmp_path / "img.raw"; out = tmp_path / "out.bin"
     raw.write_bytes(img.tobytes())
-    subprocess.check_call([exe, str(cfg), str(wts), str(W), str(H), str(raw), str(out)] + ([] if prec == "default" else [str({"f16": 0, "f32w": 2}[prec])]))
+    subprocess.check_call([exe, str(cfg), str(wts), str(W), str(H), str(raw), str(out)] + ([] if prec == "default" else [str({"f16": 0, "f32w": 2, "f32x3": 3}[prec])]))
     blob = out.read_bytes()
     n = int(np.frombuffer(blob, np.int32, 1)[0])
     boxes = np.frombuffer(blob, np.float64, 4 * n, 4).reshape(n, 4)
