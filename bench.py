@@ -947,7 +947,7 @@ WORKLOAD_TEXT = {
     "stereo-yolo-f32w": "the same chain with the detector's 3 x 3 stride-1 layers (>= 64 input channels) computed as Winograd F(2x2, 3x3), still f32 operands and f32 "
                         "accumulation: 2.25 x fewer MFMA FLOPs on those layers, same layer tolerance (2e-5 relative L2) and same 32 / 32 box-set equality against the "
                         "torch-fp32 oracle as the f32 mode (tests/test_gpu_yolo.py); kept beside the headline, whose detector computes the direct sums",
-    "stereo-yolo-f32x3": "the same chain with the detector's >= 128-filter layers computed on three bf16 limbs per f32 operand (x = hi + mid + lo exactly, six exact limb "
+    "stereo-yolo-f32x3": "the same chain with the detector's >= 64-filter layers computed on three bf16 limbs per f32 operand (x = hi + mid + lo exactly, six exact limb "
                          "products per product, f32 accumulation on v_mfma_f32_32x32x16_bf16): what is dropped is <= 2^-23 of a product; same layer tolerance and same 32 / 32 "
                          "box-set equality as the f32 mode (tests/test_gpu_yolo.py); kept beside the headline",
     "stereo-yolo-f16": "the same chain with the detector in its throughput mode (f16 operands, f32 accumulation): its box sets differ from the f32 reference's "

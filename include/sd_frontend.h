@@ -491,7 +491,7 @@ int sd_yolo_create(sd_yolo** out, const sd_yolo_layer* layers, int n_layers, con
 #define SD_YOLO_F16 0
 #define SD_YOLO_F32 1
 #define SD_YOLO_F32W 2
-/* SD_YOLO_F32X3 = SD_YOLO_F32 with the >= 128-filter layers computed on three bf16 limbs per f32 operand (x = hi + mid + lo exactly;
+/* SD_YOLO_F32X3 = SD_YOLO_F32 with the >= 64-filter layers computed on three bf16 limbs per f32 operand (x = hi + mid + lo exactly;
  * a product = its six limb products of weight >= 2^-16, each exact in f32, accumulated in f32 by v_mfma_f32_32x32x16_bf16): what is
  * dropped is <= 2^-23 of a product, the size of an f32 multiply's own rounding.  Held to the same layer tolerance and box-set test. */
 #define SD_YOLO_F32X3 3

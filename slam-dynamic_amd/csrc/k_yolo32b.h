@@ -28,7 +28,7 @@ __device__ __forceinline__ void sd_split3(float x0, float x1, uint32_t& hi, uint
 }
 
 #define SD_B3_ROWB 48                          // LDS row: 16 bf16 (one MFMA K chunk) + 16 bytes: 16 consecutive rows cover the 64 banks once
-#define SD_B3_LDS (2 * 3 * 128 * SD_B3_ROWB)   // two stages x three limb planes x 128 pixel rows
+#define SD_B3_LDS(WM) (2 * 3 * (256 / (WM)) * SD_B3_ROWB)   // two stages x three limb planes x 128 | 256 pixel rows
 
 // 128 filters x 128 pixels per 4-wave workgroup (wave 64 x 64 = 2 x 2 MFMA tiles), K in steps of 16 channels of one filter tap = ONE bf16 MFMA
 // K chunk: 24 MFMAs (768 cycles) per wave and step.  Only the ACTIVATIONS go through LDS (f32 from HBM, split by the staging pass, three limb
@@ -36,14 +36,15 @@ __device__ __forceinline__ void sd_split3(float x0, float x1, uint32_t& hi, uint
 // [lane] x 16 bytes, the exact register image of an MFMA A operand -- and every wave requests its own six fragments per step straight from
 // L2 two steps ahead.  (With the weights staged through LDS like the activations the kernel was bound by the LDS itself: 72 KB moved per
 // workgroup and step against 768 MFMA cycles; measured 43 % of the time with the matrix pipe busy.)
+template <int WM>      // 2: 128 filters x 128 pixels; 1: 64 x 256 (the 64-filter layers), every wave the same 64 filters
 __global__ void __launch_bounds__(256, 2) k_conv_b3(SdConvArgsF A, const uint4* __restrict__ wgt3)
 {
-    constexpr int NT = 256, BM = 128, BN = 128, BK = 16, CPR = 4;
+    constexpr int NT = 256, WN = 4 / WM, BM = 64 * WM, BN = 64 * WN, BK = 16, CPR = 4;
     constexpr int XC = BN * CPR / NT;                              // 2 four-channel pieces per thread and step
     constexpr int PLANE = BN * SD_B3_ROWB, STAGE = 3 * PLANE;
     extern __shared__ __align__(16) unsigned char smemb[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r32 = lane & 31, h = lane >> 5;
-    const int wm = wv & 1, wn = wv >> 1;
+    const int wm = wv % WM, wn = wv / WM;
     const int perXcd = (A.tilesX + 7) >> 3;
     const int slot = blockIdx.x >> 3, perGroup = perXcd * A.groupY;
     const int grp = slot / perGroup, rg = slot - grp * perGroup;
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_b3(SdConvArgsF A, const uint4* 
             for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
     sd_f4 xr[2][XC];
     sd_b8 fa[3][3][2];                                   // [register set][limb][m]: the weights' fragments of steps s, s + 1, s + 2
-    const uint4* aptr = wgt3 + ((size_t)ty * ksteps * 2 + wm) * (6 * 64) + lane;       // this wave's six fragments of a step are 6 KB apart from the next step's by 2 x 6 KB
+    const uint4* aptr = wgt3 + ((size_t)ty * ksteps * WM + wm) * (6 * 64) + lane;      // this wave's six fragments of a step; the next step's are WM x 6 KB on
     const float* xptr[XC];
     int xinc[XC];
     int c0 = 0, kh = 0, kw = 0;
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_b3(SdConvArgsF A, const uint4* 
         for (int l = 0; l < 3; l++)
 #pragma unroll
             for (int m = 0; m < 2; m++) fa[set][l][m] = __builtin_bit_cast(sd_b8, aptr[(2 * l + m) * 64]);
-        aptr += 2 * 6 * 64;
+        aptr += WM * 6 * 64;
     };
     auto fetchX = [&](const int set) {
 #pragma unroll

@@ -92,11 +92,11 @@ int sd_yolo_create_prec(sd_yolo** out, const sd_yolo_layer* layers, int n_layers
                 r.wOffW = wOffW; wOffW += (size_t)r.coutPad * 16 * r.cinPad;
                 vMax = std::max(vMax, blocks * 16 * r.cinPad);
                 y->mfmaFlops += 2.0 * blocks * 16.0 * (double)l.filters * cinReal;
-            } else if (y->b3 && i > 0 && l.filters > 64 && (r.cinPad % 16) == 0) {
+            } else if (y->b3 && i > 0 && l.filters >= 64 && (l.filters > 64 || (l.filters % 64) == 0) && (r.cinPad % 16) == 0) {
                 // three bf16 limbs per operand: the layers k_conv_f32 runs on 128-filter tiles
                 r.b3 = true;
-                r.b3flat = l.size == 3 && l.stride == 1 && r.W <= 160;       // k_conv3x3_b3: the nine taps share one staged chunk
-                r.b3wm = r.b3flat && r.W <= 80 ? 1 : 2;                      // 1: k_conv3x3_b3c (64-filter tiles, weights staged per chunk too); wider maps do not fit its LDS
+                r.b3flat = l.size == 3 && l.stride == 1 && r.W <= 160 && l.filters > 64;       // k_conv3x3_b3: the nine taps share one staged chunk
+                r.b3wm = (r.b3flat && r.W <= 80) || l.filters == 64 ? 1 : 2;                      // 1: k_conv3x3_b3c (64-filter tiles, weights staged per chunk too); wider maps do not fit its LDS
                 r.wOffB = wOffB; wOffB += (size_t)(r.coutPad / 128) * (l.size * l.size * (r.cinPad / 16)) * 2 * 6 * 64;      // 16-byte fragments
                 y->mfmaFlopsBf16 += 6 * 2.0 * r.H * r.W * (double)l.filters * l.size * l.size * cinReal;
             } else y->mfmaFlops += 2.0 * r.H * r.W * (double)l.filters * l.size * l.size * cinReal;
@@ -400,7 +400,8 @@ static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int hei
         HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<16, 1, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(16, 1, 1, 4)));
         HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<16, 2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(16, 2, 2, 4)));
         HIPCHK(hipFuncSetAttribute((const void*)k_wino_gemm_f32<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_WINO_LDS(16, 2)));
-        HIPCHK(hipFuncSetAttribute((const void*)k_conv_b3, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3_LDS));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv_b3<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3_LDS(1)));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv_b3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3_LDS(2)));
         HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3<3, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3F_LDS(160, 128)));
         HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3<4, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3F_LDS(160, 128)));
         HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3<5, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_B3F_LDS(160, 128)));
@@ -472,8 +473,11 @@ HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3c<5>, hipFuncAttributeMaxDyn
                     else if (np == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv3x3_b3<4, 2, 2>), grd, dim3(256), lds, s, A, wq);
                     else if (np == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv3x3_b3<5, 2, 2>), grd, dim3(256), lds, s, A, wq);
                     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv3x3_b3<8, 2, 2>), grd, dim3(256), lds, s, A, wq);
+                } else if (r.b3wm == 1) {              // the 64-filter layers
+                    A.tilesX = (npix + 255) / 256; A.tilesY = 1; A.groupY = 1;
+                    hipLaunchKernelGGL(k_conv_b3<1>, dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(256), SD_B3_LDS(1), s, A, (const uint4*)(y->d_wgtB + r.wOffB));
                 } else
-                hipLaunchKernelGGL(k_conv_b3, dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(256), SD_B3_LDS, s, A, (const uint4*)(y->d_wgtB + r.wOffB));
+                hipLaunchKernelGGL(k_conv_b3<2>, dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(256), SD_B3_LDS(2), s, A, (const uint4*)(y->d_wgtB + r.wOffB));
             } else if (i == 0)                         // 3 (-> 8) input channels, <= 32 filters
                 { A.tilesX = (npix + 511) / 512; A.tilesY = (l.filters + 31) / 32; A.groupY = f32_group_y(A.tilesY, 32, A.cin * l.size * l.size); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<8, 1, 1, 8>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(512), SD_F32_LDS(8, 1, 1, 8), s, A); }
             else if (l.filters <= 32 && small4)
