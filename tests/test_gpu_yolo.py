@@ -253,3 +253,31 @@ def test_f32_modes_odd_feature_maps_and_batch(gpu, pkg, orc, synth, prec):
         assert total > 0, "the synthetic weights must yield boxes at this size too"
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("prec", ["f32", "f32w", "f32x3"])
+def test_f32_modes_do_not_depend_on_the_batch_slot(gpu, pkg, synth, prec):
+    """The same image at slots 0 and 4 of a five-image batch, and alone: heads and boxes bit for bit the same (every output pixel is one dot product walked
+    in one fixed order, whatever tile of whatever workgroup it falls into)."""
+    import torch
+    layers, anchors = pkg.yolo.v3_layers()
+    payload, _ = pkg.yolo.synth_weights(layers, seed=3)
+    cfg = synth.KITTI03_RGBD
+    imgs = [np.ascontiguousarray(synth.rgbd_frame(6, k, cfg)[0][:, :, ::-1]) for k in range(4)]
+    batch = [imgs[0], imgs[1], imgs[2], imgs[3], imgs[0]]
+    H, W = imgs[0].shape[:2]
+    d = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=5, precision=prec)
+    try:
+        d.load_weights(payload)
+        dev = torch.from_numpy(np.stack(batch)).cuda()
+        d.forward_device(dev.data_ptr(), W, H, W * 3, W * H * 3, 5, 0.5)
+        heads = {(k, li): d.layer_output(li, image=k).copy() for k in (0, 4) for li in (81, 93, 105)}
+        b5 = d.boxes_batch(5, W, H)
+        for li in (81, 93, 105):
+            assert np.array_equal(heads[(0, li)], heads[(4, li)]), "%s: head %d differs between slots 0 and 4" % (prec, li)
+        assert np.array_equal(b5[0][0], b5[4][0]) and np.array_equal(b5[0][2], b5[4][2]) and len(b5[0][0]) > 0
+        d.forward_device(dev.data_ptr(), W, H, W * 3, W * H * 3, 1, 0.5)
+        for li in (81, 93, 105):
+            assert np.array_equal(d.layer_output(li, image=0), heads[(0, li)]), "%s: head %d differs between a batch of one and of five" % (prec, li)
+    finally:
+        d.close()
