@@ -19,19 +19,19 @@ quoted on:
                 rank 0 broadcasts over RCCL at start-up
   tum-mask      BASELINE configs[3]: TUM3 640x480 RGB-D, DepthMapFactor 5000, mask + boxes, cull + dense back-projection
                 of the unmasked pixels (pointcloudmapping.cc:59-103) -- the consumer of the semantic mask
-  kitti-batch   BASELINE configs[4]: 11 sequences x 256 colour stereo frames, WHOLE sequences assigned to ranks (longest first), the
-                stereo-yolo chain on every frame; detector + extraction + stereo matching batched over consecutive frames of a
-                rank's sequences (a sequence cannot be cut: boxTrack's ids depend on its whole history), the recurrence frame by
-                frame; strong scaling
+  kitti-batch   BASELINE configs[4]: 11 sequences x 256 colour stereo frames, the stereo-yolo chain on every frame, FRAMES sharded over the
+                ranks: the history-free half of a frame (detector, extraction, stereo matching: > 95 % of its time) runs on whichever rank
+                the frame is dealt to, one all-to-all per time block hands the results to the rank that owns the sequence, where the
+                recurrence runs frame by frame (a sequence cannot be cut: boxTrack's ids depend on its whole history); strong scaling
 The non-default single-GPU workloads are also run (short) by the default invocation and reported under "extra".
 
 Multi-GPU: one process per GPU.  `python bench.py --gpus N` without a torch.distributed environment starts the N ranks
 itself (child processes, before anything touches the GPU); under `python -m torch.distributed.run` it joins the given
-world.  Lanes are independent: no data-path collective.  Start-up: RCCL broadcast of the packed ORB vocabulary from rank 0.
+world.  Lanes are independent: no data-path collective (kitti-batch: one all-to-all of frame records per time block).  Start-up: RCCL broadcast of the packed ORB vocabulary from rank 0.
 Per step: asynchronous gather (to rank 0) of the per-frame result records (N, N_s, keypoints, descriptors, uRight, depth,
 boxes / box_idx / box_status), overlapped with the next step.  value = frames of ALL ranks / max rank time.
 
-Prints ONE JSON line on rank 0.
+Prints ONE compact JSON line (< 4 KB) on rank 0; the full record (per-kernel tables, the extras' rooflines) goes to bench_detail.json.
 """
 import argparse
 import json
@@ -48,6 +48,7 @@ import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming)
 MFMA_PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "f32w": 157.3, "f32x3": 2500.0}   # dense peaks, MI355X_MICROARCH.md
+AUTO_EXTRAS = ("stereo-yolo-f32x3", "stereo", "rgbd", "tum-mask", "kitti-batch")
 WORKLOADS = ["stereo-yolo", "stereo-yolo-f32w", "stereo-yolo-f32x3", "stereo-yolo-f16", "stereo", "rgbd", "rgbd-cull", "rgbd-bow", "tum-mask", "kitti-batch"]
 
 
@@ -226,6 +227,91 @@ def spawn_ranks(n, argv, script=None):
         p.wait()
         rc = rc or p.returncode
     return rc
+
+
+# --------------------------------------------------------------------------- the printed line (compact) and the detail record (side file)
+COMPACT_LIMIT = 4096          # the driver keeps a few KB of stdout: the FINAL line must stay well below that (round 3's 24 KB line was not parsed)
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_profile", "algorithmic_flops_per_launch",
+              "algorithmic_bytes_per_launch", "avg_launch_ms", "images_per_launch", "batch", "operands")
+
+
+def _clip(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 3] + "..."
+
+
+def compact_roofline(r):
+    """The roofline object of the printed line: the top-level fields only (per-kernel tables stay in the detail record)."""
+    if not r:
+        return None
+    out = {k: r[k] for k in _ROOF_KEYS if r.get(k) is not None}
+    for k in ("traffic", "traffic_profile"):
+        out.setdefault(k, None)
+    if "kernel" in out:
+        out["kernel"] = _clip(out["kernel"], 120)
+    fe = r.get("front_end")
+    if fe:                                    # the dominant HBM-bound kernel of the front end beside the detector's MFMA block
+        out["front_end"] = {k: fe[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms")
+                            if fe.get(k) is not None}
+    return out
+
+
+def compact_line(full, detail_path=None):
+    """The ONE line bench.py prints: metric / value / config / roofline / cpu_baseline and one number per extra, < COMPACT_LIMIT bytes.
+    Everything else (per-kernel tables, the extras' rooflines, the long sample texts) is in the detail record."""
+    cfg = full.get("config") or {}
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    out["config"] = {"workload": _clip(cfg.get("workload", ""), 700)}
+    for k in ("lanes_per_gpu", "images_per_frame", "frames_timed", "timed_seconds", "detector_arithmetic", "sharding", "frames_per_block_per_lane",
+              "frames_in_one_extraction_batch", "max_detector_boxes_in_a_frame"):
+        if cfg.get(k) is not None:
+            out["config"][k] = _clip(cfg[k], 160) if isinstance(cfg[k], str) else cfg[k]
+    out["roofline"] = compact_roofline(full.get("roofline"))
+    cpu = full.get("cpu_baseline")
+    if cpu:
+        out["cpu_baseline"] = {"value": cpu.get("value"), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind"),
+                               "sample": _clip(cpu.get("sample", ""), 420)}
+        if cpu.get("all_cores"):
+            out["cpu_baseline"]["front_end_all_cores"] = {"value": cpu["all_cores"].get("value"), "threads": cpu["all_cores"].get("threads")}
+    else:
+        out["cpu_baseline"] = None
+    out["extra"] = {k: (v.get("value") if isinstance(v, dict) and "value" in v else {"error": _clip(v.get("error", "?"), 80)} if isinstance(v, dict) else v)
+                    for k, v in (full.get("extra") or {}).items()}
+    for k in ("value_f32x3", "dtype_f32x3", "gathered_record_check", "vocabulary_broadcast_ms"):
+        if full.get(k) is not None:
+            out[k] = full[k]
+    if detail_path:
+        out["detail"] = detail_path
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) >= COMPACT_LIMIT:             # never print a line the driver cannot keep: drop the optional parts, longest first
+        for k in ("gathered_record_check", "extra"):
+            out.pop(k, None)
+            line = json.dumps(out, separators=(",", ":"))
+            if len(line) < COMPACT_LIMIT:
+                break
+        if len(line) >= COMPACT_LIMIT:
+            out["config"] = {"workload": _clip(cfg.get("workload", ""), 200)}
+            if out.get("cpu_baseline"):
+                out["cpu_baseline"]["sample"] = _clip(out["cpu_baseline"]["sample"], 120)
+            line = json.dumps(out, separators=(",", ":"))
+    return line
+
+
+def write_detail(full, name="bench_detail.json"):
+    """The full record next to bench.py (and under gpurun_out/ when that directory exists, so that it comes back from a GPU box)."""
+    paths = [os.path.join(ROOT, name)]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", name))
+    written = None
+    for p_ in paths:
+        try:
+            with open(p_, "w") as f:
+                json.dump(full, f, indent=1)
+            written = written or os.path.relpath(p_, ROOT)
+        except OSError:
+            continue
+    return written
 
 
 # --------------------------------------------------------------------------- synthetic inputs
@@ -572,130 +658,261 @@ class Workload:
 
 
 def block_plan(T, S, block_frames, resident):
-    """kitti-batch: (D, [(t0, n, [resident frame index of t0 .. t0 + n - 1])]) -- D = frames per lane and block so that S * D >= block_frames, the T
+    """(D, [(t0, n, [resident frame index of t0 .. t0 + n - 1])]) -- D = frames per lane and block so that S * D >= block_frames, the T
     frames of a sequence walked back and forth over `resident` generated ones."""
     D = max(1, min(T, -(-block_frames // max(1, S))))
     P = min(resident, T)
     return D, [(t0, min(D, T - t0), [pingpong_index(t, P) for t in range(t0, min(t0 + D, T))]) for t0 in range(0, T, D)]
 
 
+def frame_shard_plan(n_seq, T, world, block_frames, resident=24):
+    """BASELINE configs[4] with FRAMES -- not sequences -- sharded over the ranks (north star: "independent frames shard across the 8 GPUs").
+
+    A frame's history-free half (detector, cvtColor, ORB extraction of both eyes, stereo matching: everything before Frame::boxTrack,
+    Frame.cc:129-161, > 95 % of its time) may run on ANY rank; the recurrence (Frame.cc:162 onward, Tracking.cc:620-666, 952-959) stays with
+    the rank that owns the sequence.  Time is cut into blocks of D consecutive frames of every sequence; the n_seq * n frames ("units") of a
+    block, in sequence-major order u = q * n + k, are cut into `world` contiguous pieces of equal size (+- 1, the pieces rotated over the ranks
+    from block to block); each rank runs the history-free half of its piece in one batch and the units' records go to the owners in ONE
+    all-to-all per block.  D is chosen so that a rank's piece holds about `block_frames` units.
+
+    -> dict(owner, lanes (per rank: the sequences of its tracker lanes, padded by repetition to S), S, D, blocks); a block = dict(t0, n, idx
+    (resident frame index per k), units [(q, k)], piece [(lo, hi) per rank])."""
+    if world > n_seq:
+        raise ValueError("more ranks than sequences")
+    owner = shard_sequences(n_seq, [T] * n_seq, world)
+    seqs_of = [[q for q in range(n_seq) if owner[q] == r] for r in range(world)]
+    S = max(len(x) for x in seqs_of)
+    lanes = [x + [x[-1]] * (S - len(x)) for x in seqs_of]
+    D = max(1, min(T, -(-block_frames * world // n_seq)))
+    P = min(resident, T)
+    blocks = []
+    for bi, t0 in enumerate(range(0, T, D)):
+        n = min(D, T - t0)
+        U = n_seq * n
+        bounds = [(U * j) // world for j in range(world + 1)]
+        piece = [(bounds[(r + bi) % world], bounds[(r + bi) % world + 1]) for r in range(world)]
+        blocks.append(dict(t0=t0, n=n, idx=[pingpong_index(t, P) for t in range(t0, t0 + n)], units=[(q, k) for q in range(n_seq) for k in range(n)], piece=piece))
+    return dict(owner=owner, lanes=lanes, S=S, D=D, blocks=blocks, n_seq=n_seq, T=T, world=world)
+
+
+def frame_shard_rank_view(plan, block, rank):
+    """What `rank` does with one block of frame_shard_plan: mine = its units (q, k) in piece order; send_perm = positions of `mine` grouped by the
+    owner of the unit's sequence (the all-to-all wants rows grouped by destination), send_splits[dst]; recv_units = the units it receives, source
+    by source, recv_splits[src]; pool_index[k * S + lane] = row of recv_units that is frame k of the lane's sequence (a padding lane repeats one)."""
+    owner, world = plan["owner"], plan["world"]
+    units, piece = block["units"], block["piece"]
+    lo, hi = piece[rank]
+    mine = units[lo:hi]
+    send_perm = sorted(range(len(mine)), key=lambda i: (owner[mine[i][0]], i))
+    send_splits = [sum(1 for u in mine if owner[u[0]] == d) for d in range(world)]
+    recv_units, recv_splits = [], []
+    for src in range(world):
+        a, b = piece[src]
+        got = sorted((u for u in units[a:b] if owner[u[0]] == rank), key=lambda u: 0)      # stable: the source's own order
+        recv_units += got
+        recv_splits.append(len(got))
+    pos = {u: i for i, u in enumerate(recv_units)}
+    pool_index = [pos[(q, k)] for k in range(block["n"]) for q in plan["lanes"][rank]]
+    return dict(mine=mine, send_perm=send_perm, send_splits=send_splits, recv_units=recv_units, recv_splits=recv_splits, pool_index=pool_index)
+
+
+def exchange_rows(dist, world, send, send_splits, recv_splits):
+    """The hand-over of a block: rows of `send` (grouped by destination rank) -> the rows this rank receives, source by source.  RCCL:
+    one asynchronous all_to_all_single with split sizes (every unit travels over the direct xGMI link between its worker and its owner; a block
+    is tens of MB, the links idle otherwise); gloo (CPU tests, single-GPU rehearsal): the same call on host copies.  -> (rows, work or None)."""
+    import torch
+    n_recv = int(sum(recv_splits))
+    if dist is None or world == 1:
+        return send, None
+    out = torch.empty((n_recv,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+    if dist.get_backend() == "nccl":
+        return out, dist.all_to_all_single(out, send, output_split_sizes=list(recv_splits), input_split_sizes=list(send_splits), async_op=True)
+    host = torch.empty(out.shape, dtype=out.dtype)
+    dist.all_to_all_single(host, send.cpu().contiguous(), output_split_sizes=list(recv_splits), input_split_sizes=list(send_splits))
+    out.copy_(host)
+    return out, None
+
+
 class SequenceBatchWorkload:
-    """BASELINE configs[4] ("kitti-batch"): 11 KITTI stereo sequences x T frames, WHOLE sequences assigned to ranks (longest first), the f32
-    detector in the loop.  A rank owns S sequences (11 at N = 1, 1-2 at N = 8): too few lanes to fill the chip frame by frame, and a sequence
-    cannot be cut into independently processed chunks -- Frame::boxTrack's ids (`max + 1`, Frame.cc:545-550) depend on the whole history, so
-    no finite halo reproduces them.  Instead the frame is split: its history-free half (cvtColor, ORB extraction of both eyes, stereo
-    matching: sd_tracker_prefetch) and the detector run on D consecutive frames of every owned sequence in ONE batch (S * D >= 64 frames),
-    one block ahead on their own streams; the recurrence (boxTrack -> firstSeparate -> TrackHomo -> Separate -> UpdateFrame -> match vs
-    mLastFrame) then runs frame by frame on the prefetched results (sd_tracker_track with no image).  Every frame's result is the
-    sequential one (tests/test_gpu_pipeline.py::test_time_batched_prefetch_equals_sequential)."""
+    """BASELINE configs[4] ("kitti-batch"): 11 KITTI stereo sequences x T frames with the f32 detector in the loop, FRAMES sharded over the
+    ranks (frame_shard_plan).  A sequence cannot be cut into independently processed chunks -- Frame::boxTrack's ids (`max + 1`,
+    Frame.cc:545-550) depend on its whole history -- but only the recurrence is bound to it.  Per block of D frames of every sequence each
+    rank, as a WORKER, runs detector + sd_tracker_prefetch (cvtColor, ORB extraction of both eyes, stereo matching) on its equal share of the
+    block's frames in one batch (a one-lane worker tracker: the batch entries are its consecutive "frames"), exports the results as records
+    with the detector's boxes behind them, and one all-to-all moves every record to the rank that owns its sequence; as an OWNER it imports
+    its sequences' records as a prefetched block (sd_tracker_import_prefetched) and runs the recurrence frame by frame (sd_tracker_track with
+    no image).  One block ahead on separate streams, two blocks outstanding.  N = 1 runs the very same path (the exchange is the identity).
+    Every frame's result is the sequential one (tests/test_gpu_headline.py::test_kitti_batch_as_benched*)."""
+
+    BOX_BYTES = 2048 + 16              # behind a record: SD_MAX_BOXES x 4 f64 (cv::Rect2d) + the box count (int32, padded)
 
     def __init__(self, args, rank, world, dev, pkg, dist, detector=True):
         import torch
         self.torch = torch
         fe, synth = pkg.frontend, pkg.synth
-        self.fe, self.synth, self.pkg, self.dev, self.rank, self.world = fe, synth, pkg, dev, rank, world
+        self.fe, self.synth, self.pkg, self.dev, self.rank, self.world, self.dist = fe, synth, pkg, dev, rank, world, dist
         self.name, self.kind, self.cfg, self.sensor, self.ipl = "kitti-batch", "stereo", synth.KITTI_STEREO, fe.SENSOR_STEREO, 2
         self.detector, self.det_prec, self.with_boxes, self.strong, self.bow, self.cloud = detector, "f32", True, True, False, False
         cfg = self.cfg
         self.W, self.H = cfg["width"], cfg["height"]
-        n_seq, self.T = 11, args.kitti_frames
-        owner = shard_sequences(n_seq, [self.T] * n_seq, world)
-        self.my_sequences = [q for q in range(n_seq) if owner[q] == rank]
-        self.n_owned = len(self.my_sequences)
-        # every rank runs the same number of lanes (the gathered records have one size): a rank with fewer sequences repeats one, uncounted
-        self.S = max(sum(1 for q in range(n_seq) if owner[q] == r) for r in range(world))
-        while len(self.my_sequences) < self.S:
-            self.my_sequences.append(self.my_sequences[-1] if self.my_sequences else 0)
+        n_seq, self.T = int(getattr(args, "kitti_sequences", 11)), args.kitti_frames
+        self.plan = frame_shard_plan(n_seq, self.T, world, args.block_frames, 24)
+        self.S, self.D = self.plan["S"], self.plan["D"]
+        self.my_sequences = self.plan["lanes"][rank]
+        self.n_owned = sum(1 for q in range(n_seq) if self.plan["owner"][q] == rank)
+        self.views = [frame_shard_rank_view(self.plan, B, rank) for B in self.plan["blocks"]]
+        self.U_max = max(len(v["mine"]) for v in self.views)
         self.total_frames_all_ranks = n_seq * self.T
-        self.D, self.plan = block_plan(self.T, self.S, args.block_frames, 24)    # frames per lane and block: S * D >= --block-frames (64)
-        self.distinct = self.S
+        self.distinct = self.n_owned
+        assert fe.MAXB * 32 + 16 == self.BOX_BYTES
         self.ex = fe.ORBextractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+        # owner: the lanes are this rank's sequences; worker: ONE lane whose consecutive "frames" are the batch entries of a block's piece
         self.trk = fe.Tracker(self.ex, cfg, self.sensor, self.S, channels=3, rgb_order=True, track_last=True, lookahead=self.D)
+        self.worker = fe.Tracker(self.ex, cfg, self.sensor, 1, channels=3, rgb_order=True, track_last=False, lookahead=self.U_max)
         self.batch = self.trk.batch
+        self.R = self.trk.record_bytes()
+        assert self.R == self.worker.record_bytes() and self.R % 16 == 0
+        self.RB = self.R + self.BOX_BYTES
         self.main = torch.cuda.current_stream()
         self.pre_stream = torch.cuda.Stream(device=dev)
+        self.det_stream = torch.cuda.Stream(device=dev)
+        self.xchg_stream = torch.cuda.Stream(device=dev)
         self.det = None
         self.max_det_boxes = 0
+        M = fe.MAXB
         if detector:
             layers, anchors = pkg.yolo.v3_layers()
-            self.det = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=self.S * self.D, precision="f32")
+            self.det = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=self.U_max, precision="f32")
             self.det.load_weights(pkg.yolo.synth_weights(layers, seed=3)[0])
-            self.det_stream = torch.cuda.Stream(device=dev)
-            n, M = self.S * self.D, fe.MAXB
-            self.det_dev = [dict(b=torch.zeros((n, M, 4), dtype=torch.float64, device=dev), c=torch.zeros((n, M), dtype=torch.int32, device=dev),
-                                 f=torch.zeros((n, M), dtype=torch.float32, device=dev), n=torch.zeros((n,), dtype=torch.int32, device=dev)) for _ in range(2)]
-            self.det_host = [dict(b=torch.zeros((n, M, 4), dtype=torch.float64).pin_memory(), n=torch.zeros((n,), dtype=torch.int32).pin_memory()) for _ in range(2)]
-            self.det_ev = [torch.cuda.Event() for _ in range(2)]
+            self.det_dev = dict(b=torch.zeros((self.U_max, M, 4), dtype=torch.float64, device=dev), c=torch.zeros((self.U_max, M), dtype=torch.int32, device=dev),
+                                f=torch.zeros((self.U_max, M), dtype=torch.float32, device=dev), n=torch.zeros((self.U_max,), dtype=torch.int32, device=dev))
+        # two blocks outstanding: records of my piece (worker side), the received rows in pool order (owner side), the boxes on the host
+        self.rec = [torch.zeros((self.U_max, self.RB), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.pool = [torch.zeros((self.D * self.S, self.RB), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.host_tail = [torch.zeros((self.D * self.S, self.BOX_BYTES), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.ready = [torch.cuda.Event() for _ in range(2)]
         self.blocks = []
 
     def prepare(self):
-        resident = 24
-        """Generate `resident` time steps of every owned sequence on the host, walk them back and forth up to T frames (consecutive frames stay
-        consecutive views, time stamps keep increasing) and park the frames in HBM block by block in frame-major order [D, S, 2, H, W, 3]."""
+        """Generate `resident` time steps of every sequence this rank touches on the host (walked back and forth up to T frames: consecutive
+        frames stay consecutive views, time stamps keep increasing) and park the frames of its pieces in HBM block by block, [units, 2, H, W, 3]."""
         torch, synth, cfg = self.torch, self.synth, self.cfg
-        P = min(resident, self.T)
-        per_seq = [[synth_timestep(synth, "stereo", cfg, 10 + q, t) for t in range(P)] for q in self.my_sequences[:max(1, self.n_owned)]]
-        while len(per_seq) < self.S:
-            per_seq.append(per_seq[-1])
-        dev_frames = [torch.from_numpy(np.stack([per_seq[l][p]["images"] for l in range(self.S)])).to(self.dev) for p in range(P)]      # [S, 2, H, W, 3] each
-        self.given_boxes = [[per_seq[l][p]["boxes"] for l in range(self.S)] for p in range(P)]
+        P = min(24, self.T)
         self.P = P
-        for t0, n, idx in self.plan:
-            self.blocks.append(dict(t0=t0, n=n, idx=idx, images=torch.stack([dev_frames[i] for i in idx]).contiguous()))
-        del dev_frames
+        need = sorted({(q, B["idx"][k]) for B, v in zip(self.plan["blocks"], self.views) for (q, k) in v["mine"]})
+        host = {}
+        for q, p in need:
+            fr = synth_timestep(synth, "stereo", cfg, 10 + q, p)
+            host[(q, p)] = (torch.from_numpy(fr["images"]).to(self.dev), fr["boxes"])
+        M = self.fe.MAXB
+        for B, v in zip(self.plan["blocks"], self.views):
+            imgs = torch.stack([host[(q, B["idx"][k])][0] for (q, k) in v["mine"]]).contiguous() if v["mine"] else None
+            given = None
+            if self.det is None:                     # --kitti-no-detector: the 3 given boxes per frame travel exactly like the detector's
+                tail = np.zeros((len(v["mine"]), self.BOX_BYTES), np.uint8)
+                for i, (q, k) in enumerate(v["mine"]):
+                    g = np.asarray(host[(q, B["idx"][k])][1], np.float64).reshape(-1, 4)
+                    tail[i, :len(g) * 32] = g.view(np.uint8).reshape(-1)
+                    tail[i, M * 32:M * 32 + 4] = np.array([len(g)], np.int32).view(np.uint8)
+                given = torch.from_numpy(tail).to(self.dev)
+            dv = lambda a: torch.tensor(a, dtype=torch.int64, device=self.dev)
+            ident = v["send_perm"] == list(range(len(v["mine"])))
+            self.blocks.append(dict(t0=B["t0"], n=B["n"], idx=B["idx"], images=imgs, given=given, view=v, send_perm=None if ident else dv(v["send_perm"]),
+                                    pool_index=dv(v["pool_index"])))
+        del host
 
     def enqueue(self, bi):
-        """Detector (forward + NMS on the device + download) and the front half of block bi, each on its own stream; nothing waits."""
+        """Worker side of block bi: detector (forward + NMS on the device) and the history-free half of this rank's piece, each on its own stream;
+        records + boxes packed and grouped by destination.  Nothing waits on the host."""
         torch = self.torch
         B = self.blocks[bi]
-        W, H, S = self.W, self.H, self.S
-        n = B["n"] * S
-        if self.det is not None:
-            k = bi & 1
-            ds = self.det_stream.cuda_stream
-            d = self.det_dev[k]
-            self.det.forward_device(B["images"].data_ptr(), W, H, W * 3, 2 * W * H * 3, n, 0.5, ds)
-            self.det.boxes_device(n, W, H, d["b"].data_ptr(), d["c"].data_ptr(), d["f"].data_ptr(), d["n"].data_ptr(), stream=ds)
-            with torch.cuda.stream(self.det_stream):
-                self.det_host[k]["b"][:n].copy_(d["b"][:n], non_blocking=True)
-                self.det_host[k]["n"][:n].copy_(d["n"][:n], non_blocking=True)
-                self.det_ev[k].record(self.det_stream)
-        self.trk.prefetch(B["images"].data_ptr(), W * 3, W * H * 3, B["n"], stream=self.pre_stream.cuda_stream)
+        v = B["view"]
+        W, H = self.W, self.H
+        U = len(v["mine"])
+        k = bi & 1
+        rec = self.rec[k]
+        M32 = self.fe.MAXB * 32
+        if U:
+            if self.det is not None:
+                ds = self.det_stream.cuda_stream
+                d = self.det_dev
+                self.det.forward_device(B["images"].data_ptr(), W, H, W * 3, 2 * W * H * 3, U, 0.5, ds)
+                self.det.boxes_device(U, W, H, d["b"].data_ptr(), d["c"].data_ptr(), d["f"].data_ptr(), d["n"].data_ptr(), stream=ds)
+                with torch.cuda.stream(self.det_stream):
+                    rec[:U, self.R:self.R + M32].copy_(d["b"][:U].view(torch.uint8).view(U, M32), non_blocking=True)
+                    rec[:U, self.R + M32:self.R + M32 + 4].copy_(d["n"][:U].view(torch.uint8).view(U, 4), non_blocking=True)
+            else:
+                with torch.cuda.stream(self.det_stream):
+                    rec[:U, self.R:].copy_(B["given"], non_blocking=True)
+            ps = self.pre_stream.cuda_stream
+            self.worker.prefetch(B["images"].data_ptr(), W * 3, W * H * 3, U, stream=ps)      # one lane: U consecutive "frames"
+            self.worker.export_prefetched(0, U, rec.data_ptr(), record_stride=self.RB, stream=ps)
+            self.worker.discard_prefetched()
+        with torch.cuda.stream(self.xchg_stream):
+            self.xchg_stream.wait_stream(self.det_stream)
+            self.xchg_stream.wait_stream(self.pre_stream)
+            B["send"] = rec[:U] if B["send_perm"] is None else rec[:U].index_select(0, B["send_perm"])      # rows grouped by destination rank
 
-    def run(self, n_blocks=None, after_step=None):
-        """All (or the first n_blocks) blocks: block b + 1 is enqueued before block b's frames are tracked.  -> the last step's lane results."""
-        fe = self.fe
+    def _to_pool(self, bi):
+        """Owner side, on the exchange stream: the received rows in pool order (frame-major over this rank's lanes), their box tails to the host."""
+        B, k = self.blocks[bi], bi & 1
+        n = B["n"] * self.S
+        self.torch.index_select(B["rows"], 0, B["pool_index"], out=self.pool[k][:n])
+        self.host_tail[k][:n].copy_(self.pool[k][:n, self.R:], non_blocking=True)
+        self.ready[k].record(self.xchg_stream)
+        B["rows"] = None
+
+    def consume_begin(self, bi):
+        """-> (boxes [n * S, M, 4] f64, n_boxes [n * S]) of block bi on the host; its records are imported as the tracker's next prefetched block."""
+        # The all-to-all is issued HERE, not in enqueue(): RCCL runs a communicator's collectives in issue order, and an exchange queued a block
+        # early would sit -- waiting for that block's detector pass -- in front of the per-step result gathers of the block being tracked.
+        torch = self.torch
+        B, k = self.blocks[bi], bi & 1
+        v = B["view"]
+        with torch.cuda.stream(self.xchg_stream):
+            B["rows"], work = exchange_rows(self.dist, self.world, B["send"], v["send_splits"], v["recv_splits"])
+            if work is not None:
+                work.wait()
+            self._to_pool(bi)
+            B["send"] = None
+        self.main.wait_stream(self.xchg_stream)
+        self.trk.import_prefetched(self.pool[k].data_ptr(), B["n"], record_stride=self.RB, stream=self.main.cuda_stream)
+        self.ready[k].synchronize()
+        n, M = B["n"] * self.S, self.fe.MAXB
+        tail = self.host_tail[k].numpy()[:n]
+        boxes = tail[:, :M * 32].copy().view(np.float64).reshape(n, M, 4)
+        nb = tail[:, M * 32:M * 32 + 4].copy().view(np.int32).reshape(n)
+        if (nb < 0).any():
+            raise RuntimeError("detector post-processing on the device exceeded its capacity")
+        if n:
+            self.max_det_boxes = max(self.max_det_boxes, int(nb.max()))
+        return boxes, nb
+
+    def run(self, n_blocks=None, after_step=None, on_frame=None):
+        """All (or the first n_blocks) blocks: block b + 1 is enqueued before block b's frames are tracked.  on_frame(t, lane results): test hook.
+        -> the last step's lane results."""
         nb = len(self.blocks) if n_blocks is None else min(n_blocks, len(self.blocks))
-        W, H, S, M = self.W, self.H, self.S, self.fe.MAXB
+        W, H, S = self.W, self.H, self.S
         res = None
         self.enqueue(0)
         for bi in range(nb):
             if bi + 1 < nb:
                 self.enqueue(bi + 1)
             B = self.blocks[bi]
-            if self.det is not None:
-                self.det_ev[bi & 1].synchronize()
-                nb_all = self.det_host[bi & 1]["n"].numpy()[:B["n"] * S]
-                if (nb_all < 0).any():
-                    raise RuntimeError("detector post-processing on the device exceeded its capacity")
-                self.max_det_boxes = max(self.max_det_boxes, int(nb_all.max()))
-                bx_all = self.det_host[bi & 1]["b"].numpy()
+            bx_all, nb_all = self.consume_begin(bi)
             for k in range(B["n"]):
                 t = B["t0"] + k
-                if self.det is not None:
-                    boxes = bx_all[k * S:(k + 1) * S].copy(); n_boxes = nb_all[k * S:(k + 1) * S].astype(np.int32)
-                else:
-                    boxes = np.zeros((S, M, 4), np.float64); n_boxes = np.zeros(S, np.int32)
-                    for l in range(S):
-                        g = self.given_boxes[B["idx"][k]][l]; n_boxes[l] = len(g); boxes[l, :len(g)] = g
-                res = self.trk.track(0, W * 3, W * H * 3, np.full(S, t / float(self.cfg["fps"]), np.float64), boxes=boxes, n_boxes=n_boxes,
-                                     stream=self.main.cuda_stream)
+                res = self.trk.track(0, W * 3, W * H * 3, np.full(S, t / float(self.cfg["fps"]), np.float64), boxes=bx_all[k * S:(k + 1) * S],
+                                     n_boxes=nb_all[k * S:(k + 1) * S], stream=self.main.cuda_stream)
+                if on_frame is not None:
+                    on_frame(t, res)
                 if after_step is not None:
                     after_step()
         return res
 
     def close(self):
         self.trk.close()
+        self.worker.close()
         if self.det is not None:
             self.det.close()
 
@@ -732,8 +949,8 @@ def run_sequence_batch(args, rank, world, dev, pkg, dist, detector=True):
         R = res[0]
         out = {"workload": "kitti-batch", "value": round(frames / elapsed, 2), "ms_per_step": round(elapsed / wl.T * 1e3, 4), "steps": wl.T, "frames": frames,
                "timed_s": round(elapsed, 3), "lanes_per_gpu": wl.S, "images_per_frame": 2, "frames_per_block_per_lane": wl.D, "blocks": len(wl.blocks),
-               "frames_in_one_extraction_batch": wl.S * wl.D, "distinct_frames_generated_per_sequence": wl.P,
-               "frames_truncated": 0, "max_detector_boxes_in_a_frame": wl.max_det_boxes if wl.det is not None else None,
+               "frames_in_one_extraction_batch": wl.U_max, "distinct_frames_generated_per_sequence": wl.P, "record_bytes_per_frame": wl.RB,
+               "max_detector_boxes_in_a_frame": wl.max_det_boxes if wl.det is not None else None,
                "lane0_last_frame": {"N": R.N, "N_s": R.N_s, "N_d": R.N_d, "n_boxes": R.n_boxes, "track_flag": R.track_flag, "separate_ret": R.separate_ret,
                                     "n_track_matches": R.n_track_matches, "n_last_matches": R.n_last_matches}}
         if gatherer is not None:
@@ -819,7 +1036,7 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline, vocab=None):
         R = res[0]
         out = {"workload": name, "value": round(value, 2), "ms_per_step": round(elapsed / steps * 1e3, 4), "steps": steps, "frames": frames,
                "timed_s": round(elapsed, 3), "lanes_per_gpu": wl.S, "images_per_frame": wl.ipl,
-               "frames_truncated": 0, "max_detector_boxes_in_a_frame": wl.max_det_boxes if wl.det is not None else None,
+               "max_detector_boxes_in_a_frame": wl.max_det_boxes if wl.det is not None else None,
                "lane0_last_frame": {"N": R.N, "N_s": R.N_s, "N_d": R.N_d, "n_boxes": R.n_boxes, "track_flag": R.track_flag, "separate_ret": R.separate_ret,
                                     "n_track_matches": R.n_track_matches, "n_last_matches": R.n_last_matches}}
         if gatherer is not None:               # rank 0 decodes a record it received from the LAST rank: the gather carries usable data
@@ -907,7 +1124,7 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline, vocab=None):
                             "f32_mfma_tflops": round(tf, 2)}
                     frac = (fb / (MFMA_PEAK_TFLOPS["f32x3"] * 1e12) + fl / (MFMA_PEAK_TFLOPS["f32"] * 1e12)) * wl.S / (det_ms * 1e-3)
                     tf = fb * wl.S / (det_ms * 1e-3) / 1e12
-                    fl = fb
+                    limb["executed_bf16_flops_per_launch"] = int(fb * wl.S)
                 # The kernel that decides this workload is the detector's convolution (k_conv_f32 / the f16 conv kernels: > 90 % of the GPU
                 # time), so IT is the roofline object; one "launch" = the convolution launches of one detector batch, timed alone on the
                 # detector's stream.  The dominant HBM-bound kernel of the front end stays beside it under "front_end".
@@ -927,9 +1144,10 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline, vocab=None):
                                                         else "k_conv_f32 / k_wino_input + k_wino_gemm_f32: the %d convolutions of one %d-image detector batch" % (n_conv * wl.n_det, wl.S) if prec == "f32w"
                                                         else "the f16 convolution kernels of one %d-image detector batch" % wl.S),
                        "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS[prec], "unit": "TFLOP/s", "frac": round(frac, 4), "limb_mode": limb,
-                       "traffic": det_traffic, "traffic_profile": det_prof, "algorithmic_flops_per_launch": int(fl * wl.S), "avg_launch_ms": round(det_ms, 3),
+                       "traffic": det_traffic, "traffic_profile": det_prof, "algorithmic_flops_per_launch": int(nominal * wl.S), "avg_launch_ms": round(det_ms, 3),
+                       "executed_mfma_flops_per_launch": int(fl * wl.S),        # f32-MFMA FLOPs the mode runs (f32w: fewer than nominal; f32x3: the first layers only, the limb FLOPs are under limb_mode)
                        "algorithmic_bytes_per_launch": detector_algorithmic_bytes(wl.det.layers, wl.det.net_w, wl.det.net_h, wl.S, 2 if prec == "f16" else 4),
-                       "operands": prec, "images_per_s": round(wl.S / (det_ms * 1e-3), 1), "gflop_per_image": round(fl / 1e9, 2), "batch": wl.S,
+                       "operands": prec, "images_per_s": round(wl.S / (det_ms * 1e-3), 1), "gflop_per_image": round(nominal / 1e9, 2), "batch": wl.S,
                        "nominal_direct_convolution": {"gflop_per_image": round(nominal / 1e9, 2), "tflops": round(nominal * wl.S / (det_ms * 1e-3) / 1e12, 1)},
                        "measured": "3 detector passes alone (%d sub-batch(es) of %d images on their own streams, as in the timed steps) between events on those streams (untimed pass)" % (wl.n_det, wl.S_det),
                        "weights": "synthetic (yolov3.weights is a download that never was in the reference)",
@@ -959,9 +1177,10 @@ WORKLOAD_TEXT = {
     "rgbd-cull": "KITTI-03 RGB-D 1241x376, 2000 feat/frame, 3 given boxes per frame: extract + match + boxTrack + firstSeparate + TrackHomo + Separate + UpdateFrame",
     "tum-mask": "TUM3 RGB-D 640x480, 1000 feat/frame, DepthMapFactor 5000, 30 fps, mask + 3 boxes per frame: extract + match + cull + dense back-projection of the "
                 "pixels outside (dynamic box AND mask) (BASELINE configs[3])",
-    "kitti-batch": "11 synthetic KITTI stereo colour sequences x %d frames, whole sequences per rank (BASELINE configs[4]), the configs[2] chain on every frame "
-                   "(YOLOv3 f32 -> boxes -> TrackStereo with the cull): detector + extraction + stereo matching batched over consecutive frames of the owned "
-                   "sequences (sd_tracker_prefetch), the per-stream recurrence frame by frame; results identical to the sequential run",
+    "kitti-batch": "11 synthetic KITTI stereo colour sequences x %d frames (BASELINE configs[4]), the configs[2] chain on every frame (YOLOv3 f32 -> boxes -> "
+                   "TrackStereo with the cull); FRAMES sharded over the ranks: detector + extraction + stereo matching of a time block's frames dealt evenly to "
+                   "all ranks (sd_tracker_prefetch -> records), one all-to-all per block to the sequence owners (sd_tracker_import_prefetched), the per-stream "
+                   "recurrence frame by frame on the owner; results identical to the sequential run",
 }
 
 
@@ -973,14 +1192,18 @@ def main():
     ap.add_argument("--lanes", "--batch", type=int, default=256, dest="lanes", help="independent camera streams per GPU = frames per step per GPU")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic sequences generated on the host (replicated over the lanes on the device)")
     ap.add_argument("--workload", choices=WORKLOADS, default="stereo-yolo")
-    ap.add_argument("--extra", default="auto", help="comma-separated workloads also run (short) and reported under 'extra'; 'auto' = stereo,rgbd,rgbd-cull at N=1, none otherwise; 'none'")
+    ap.add_argument("--extra", default="auto", help="comma-separated workloads also run (short) and reported under 'extra'; 'auto' = " + ",".join(AUTO_EXTRAS) + " at N=1, none otherwise; 'none'")
     ap.add_argument("--extra-steps", type=int, default=12)
     ap.add_argument("--kitti-frames", type=int, default=256)
-    ap.add_argument("--block-frames", type=int, default=128, help="kitti-batch: frames (over all owned sequences) whose detector pass / extraction / stereo matching form one batch")
+    ap.add_argument("--kitti-sequences", type=int, default=11, help="kitti-batch: sequences of the job (BASELINE configs[4]: KITTI 00-10 = 11)")
+    ap.add_argument("--block-frames", type=int, default=128, help="kitti-batch: frames per rank whose detector pass / extraction / stereo matching form one batch "
+                    "(a time block = ceil(block_frames * ranks / sequences) consecutive frames of every sequence, its frames dealt evenly to the ranks)")
     ap.add_argument("--kitti-no-detector", action="store_true", help="kitti-batch with the 3 given boxes per frame instead of the detector")
     ap.add_argument("--det-split", type=int, default=1, help="sub-batches the detector processes a step's images in, each on its own stream "
                     "(measured on MI355X: 1 -> 995.5, 2 -> 995.1, 4 -> 989.7 frames/s: the convolutions' drain phases are not worth filling)")
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of host time for the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--detail", default="bench_detail.json", help="file (next to bench.py, and under gpurun_out/ when present) that receives the FULL record; "
+                    "the printed line is its compact form")
     ap.add_argument("--no-profile", action="store_true", help="skip the separate per-kernel pass (no roofline block)")
     args = ap.parse_args()
 
@@ -1048,19 +1271,31 @@ def main():
     extras = {}
     names = []
     if args.extra == "auto":
-        names = [w for w in ("stereo-yolo-f32w", "stereo-yolo-f32x3", "stereo-yolo-f16", "stereo", "rgbd", "rgbd-cull", "rgbd-bow", "tum-mask", "kitti-batch") if w != args.workload] if world == 1 else []
+        # the other BASELINE configs (configs[1] rgbd, configs[3] tum-mask, configs[4] kitti-batch), the detector-less stereo front end (the HBM-side
+        # kernel table) and the f32x3 detector chain (value_f32x3); every other workload only on request (--extra a,b,c)
+        names = [w for w in AUTO_EXTRAS if w != args.workload] if world == 1 else []
     elif args.extra != "none":
         names = [w for w in args.extra.split(",") if w]
     for w in names:
         if w not in WORKLOADS:
             raise SystemExit("unknown workload " + w)
-        o, _ = run_workload(w, args, rank, world, dev, pkg, dist, headline=False, vocab=vocab)
+        try:
+            o, _ = run_workload(w, args, rank, world, dev, pkg, dist, headline=False, vocab=vocab)
+        except Exception as exc:                     # an extra must never cost the headline its line
+            if world > 1:
+                raise                                 # ... except where ranks would fall out of step
+            extras[w] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            continue
         if rank == 0:
             extras[w] = {"value": o["value"], "unit": "frames/s", "ms_per_step": o["ms_per_step"], "steps": o["steps"], "lanes_per_gpu": o["lanes_per_gpu"],
                          "scaling": "strong" if w == "kitti-batch" else "weak",
                          "workload": WORKLOAD_TEXT[w] % args.kitti_frames if w == "kitti-batch" else WORKLOAD_TEXT[w], "lane0_last_frame": o["lane0_last_frame"]}
             for k in ("roofline", "frames", "frames_per_block_per_lane", "frames_in_one_extraction_batch", "blocks", "distinct_frames_generated_per_sequence",
-                      "max_detector_boxes_in_a_frame", "frames_truncated"):
+                      "max_detector_boxes_in_a_frame"):
                 if k in o:
                     extras[w][k] = o[k]
 
@@ -1090,7 +1325,7 @@ def main():
                                     if world > 1 else "single GPU")},
             "roofline": head.get("roofline"), "cpu_baseline": cpu, "extra": extras,
         }
-        for k in ("frames_truncated", "max_detector_boxes_in_a_frame", "frames_per_block_per_lane", "frames_in_one_extraction_batch", "blocks",
+        for k in ("max_detector_boxes_in_a_frame", "frames_per_block_per_lane", "frames_in_one_extraction_batch", "blocks",
                   "distinct_frames_generated_per_sequence"):
             if k in head:
                 out["config"][k] = head[k]
@@ -1099,7 +1334,14 @@ def main():
         out["vocabulary"] = {"nodes": vocab.info()["n_nodes"], "words": vocab.info()["n_words"], "packed_bytes": int(voc_bytes)}
         if voc_ms is not None:
             out["vocabulary_broadcast_ms"] = round(voc_ms, 3)
-        print(json.dumps(out))
+        x3 = extras.get("stereo-yolo-f32x3")
+        if args.workload == "stereo-yolo" and x3 and "value" in x3:
+            # the same chain with the detector's f32 operands carried as three bf16 limbs (tests/test_gpu_yolo.py holds it to the direct mode's bars and
+            # to a float64 forward): a second figure beside `value`, which stays the direct f32 sums
+            out["value_f32x3"] = x3["value"]
+            out["dtype_f32x3"] = "u8+f32 operands as 3xbf16 limbs, f32 accumulate"
+        detail = write_detail(out, args.detail)
+        print(compact_line(out, detail))
         sys.stdout.flush()
     if dist is not None:
         dist.barrier()

@@ -285,7 +285,12 @@ int sd_box_track(double* boxes, int n_box, int cap, const double* last_objects, 
  * N_s, empty boxes are erased exactly as the reference does it (quirk included), per-box keypoint lists
  * (mvdynKeys/mdynDescriptors/mvudynRight/mvdynDepth) are index lists into the frame's arrays.
  * boxes: [n_frames][SD_MAX_BOXES][4], box_idx: [n_frames][SD_MAX_BOXES] (boxTrack outputs).  Run after the
- * stereo / RGB-D step (the lookup is per keypoint, so the order relative to the reorder is immaterial). */
+ * stereo / RGB-D step (the lookup is per keypoint, so the order relative to the reorder is immaterial).
+ * BOUND (this library's, the reference has none -- Frame.cc:555-604 works on std::vectors): the dynamic-object path keeps a frame's
+ * key-point masks and a box's descriptors in LDS, 2048 key points per image at most.  An extractor whose nFeatures yields more than 2048
+ * key points per image (every shipped YAML asks for <= 2000; the 2 * nFeatures monocular initialisation extractor never meets boxes:
+ * Frame.cc:406-461 takes none) makes this call return SD_ERR_UNSUPPORTED; sd_batch_separate flags a box with more than 2048 key points on
+ * either side as SD_ERR_CAPACITY at the next synchronisation.  Nothing is ever truncated silently. */
 int sd_batch_first_separate(sd_batch* b, int n_frames, const int32_t* slots, const double* boxes, const int32_t* n_boxes,
                             const int32_t* box_idx, void* stream);
 /* Frame::objects / box_idx / box_status and the per-box lists of a slot.  kept_orig[j] = index (before the
@@ -427,6 +432,27 @@ int sd_tracker_track_host(sd_tracker* t, const uint8_t* const* images, size_t st
  * calls.  Needs params.lookahead >= n_frames; two blocks may be outstanding (extract block b + 1 while block b is tracked). */
 int sd_tracker_prefetch(sd_tracker* t, const uint8_t* d_images, size_t stride, size_t image_pitch, const void* d_depth,
                         size_t depth_stride_elems, size_t depth_pitch_elems, int n_frames, void* stream);
+/* Frames -- not streams -- sharded over GPUs (BASELINE configs[4] on N > 1 ranks: "independent frames shard across the 8 GPUs").  Everything
+ * a frame computes before Frame::boxTrack (src/Frame.cc:129-161: GrabImage*'s cvtColor, ORB extraction of both eyes, UndistortKeyPoints,
+ * ComputeStereoMatches / ComputeStereoFromRGBD) depends on the frame's images alone; the recurrence (Frame.cc:162 onward, Tracking.cc:620-666,
+ * 952-959) stays with the GPU that owns the stream.  So ANY GPU may run sd_tracker_prefetch on any frames (a "worker" tracker whose lanes are
+ * simply batch entries), export the results as fixed-stride records, move them (RCCL all-to-all, the caller's business) and the owner imports
+ * them as a prefetched block that sd_tracker_track(d_images == NULL) consumes exactly like a block it had extracted itself.
+ *   record = N, per-level counts, mvKeys, mDescriptors, mvuRight, mvDepth, stereo SADs [, mvKeysUn when Camera.k1 != 0], each padded to 16 bytes:
+ *            sd_tracker_prefetched_record_bytes(t) bytes (0 for a tracker without lookahead), the same for every tracker built with the same
+ *            extractor parameters, image size and distortion setting -- the pyramid is not part of it (nothing after the association reads it).
+ *   export : frames [first_frame, first_frame + n_frames) of the NEWEST outstanding prefetched block -> d_records[(k * n_lanes + s)] in
+ *            frame-major order, on `stream` (waits for the block's extraction).  The caller orders a later prefetch into the same block behind it
+ *            (same stream or an event).
+ *   import : n_frames * n_lanes records in frame-major order become the next outstanding block (params.lookahead >= n_frames; two blocks may be
+ *            outstanding); d_records may be reused once `stream` has passed this call.
+ *   discard: a worker drops its newest block after exporting it (it will never track it).
+ *   record_stride >= the record size, a multiple of 16 (d_records 16-byte aligned): the caller may keep its own bytes behind a record -- the
+ *            detector's boxes of the frame travel there in bench.py. */
+size_t sd_tracker_prefetched_record_bytes(const sd_tracker* t);
+int sd_tracker_export_prefetched(sd_tracker* t, int first_frame, int n_frames, void* d_records, size_t record_stride, void* stream);
+int sd_tracker_import_prefetched(sd_tracker* t, const void* d_records, size_t record_stride, int n_frames, void* stream);
+int sd_tracker_discard_prefetched(sd_tracker* t);
 /* The SLAM state a caller with a live back end owns, handed over the boundary (all optional; without them the tracker runs in its
  * sharded batch mode):
  *  - the pose prior is the Tcw / Twc argument of sd_tracker_track: `mCurrentFrame.SetPose(mVelocity*mLastFrame.mTcw)` (Tracking.cc:982)

@@ -1,6 +1,7 @@
 // Small kernels of the frame-level boundary (sd_tracker, sd_tracker.inc): everything here is per-lane bookkeeping that must
 // not cost a host round trip -- the heavy work is in k_extract.h / k_fast.h / k_frame.h / k_motion.h / k_cull.h.
 //   k_copy_frames     Frame's copy constructor (src/Frame.cc:39-63) for a list of (src, dst) slots in one launch
+//   k_frame_records   the history-free half of prefetched frames <-> fixed-stride records (frames computed on one GPU, consumed on another)
 //   k_lane_gate       `if(!mCurrentFrame.objects.empty() && ...)` (src/Tracking.cc:622) evaluated on the device
 //   k_reset_boxes     the constructors without boxes: objects.clear(), N_d = 0
 //   k_fill_mono       `mvuRight = vector<float>(N,-1); mvDepth = vector<float>(N,-1);` (src/Frame.cc:432-434)
@@ -36,6 +37,24 @@ __global__ void __launch_bounds__(256) k_copy_frames_x(SdCopyTableX T, int srcFi
     const unsigned n = T.slotBytes[seg];
     const char* s = T.src[seg] + (size_t)(srcFirst + l * slotStep) * n;
     char* d = T.dst[seg] + (size_t)(l * slotStep) * n;
+    const bool a16 = ((((size_t)s) | ((size_t)d)) & 15) == 0;
+    const unsigned quads = a16 ? n >> 4 : 0;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < quads; i += gridDim.x * 256) ((uint4*)d)[i] = ((const uint4*)s)[i];
+    for (unsigned i = (quads << 4) + blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) d[i] = s[i];
+}
+
+// Prefetched frames as self-contained records (sd_tracker_export_prefetched / _import_prefetched: a frame's history-free half computed on one GPU,
+// consumed by the GPU that owns the stream).  Record r = the segments of pool entry `first + r` back to back, each padded to 16 bytes; entry e is
+// slot e * slotStep of the workspace.  toRecord = 1 packs, 0 unpacks.  grid (blocks, segments, records).
+struct SdRecordTable { char* base[SD_COPY_SEGS]; unsigned slotBytes[SD_COPY_SEGS]; unsigned offset[SD_COPY_SEGS]; int n; unsigned recordBytes; };
+__global__ void __launch_bounds__(256) k_frame_records(SdRecordTable T, char* __restrict__ records, int first, int slotStep, int toRecord)
+{
+    const int seg = blockIdx.y, r = blockIdx.z;
+    const unsigned n = T.slotBytes[seg];
+    char* a = T.base[seg] + (size_t)((first + r) * slotStep) * n;                  // workspace side
+    char* c = records + (size_t)r * T.recordBytes + T.offset[seg];                 // record side (16-byte aligned by construction)
+    const char* s = toRecord ? a : c;
+    char* d = toRecord ? c : a;
     const bool a16 = ((((size_t)s) | ((size_t)d)) & 15) == 0;
     const unsigned quads = a16 ? n >> 4 : 0;
     for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < quads; i += gridDim.x * 256) ((uint4*)d)[i] = ((const uint4*)s)[i];

@@ -140,10 +140,13 @@ int sd_yolo_create_prec(sd_yolo** out, const sd_yolo_layer* layers, int n_layers
     ok = ok && alloc((void**)&y->d_zero, 256);
     if (ok) ok = hipMemset(y->d_zero, 0, 256) == hipSuccess;
 
-    if (y->f32) ok = ok && alloc((void**)&y->d_wgt32, wOff * 4 + 64);
-    if (y->wino && wOffW) { ok = ok && alloc((void**)&y->d_wgtW, wOffW * 4 + 64); ok = ok && alloc((void**)&y->d_V, nB * vMax * 4 + 64); }
-    if (y->b3 && wOffB) ok = ok && alloc((void**)&y->d_wgtB, wOffB * 16 + 65536);     // slack: the kernels request weight fragments up to two steps past a tile's last
-    else ok = ok && alloc((void**)&y->d_wgt, wOff * 2 + 64);
+    if (!y->f32) {
+        ok = ok && alloc((void**)&y->d_wgt, wOff * 2 + 64);                             // f16 weights: the f16 mode only
+    } else {
+        ok = ok && alloc((void**)&y->d_wgt32, wOff * 4 + 64);
+        if (y->wino && wOffW) { ok = ok && alloc((void**)&y->d_wgtW, wOffW * 4 + 64); ok = ok && alloc((void**)&y->d_V, nB * vMax * 4 + 64); }
+        if (y->b3 && wOffB) ok = ok && alloc((void**)&y->d_wgtB, wOffB * 16 + 65536);  // slack: the kernels request weight fragments up to two steps past a tile's last
+    }
     ok = ok && alloc((void**)&y->d_bias, bOff * 4 + 64);
     ok = ok && alloc((void**)&y->d_dets, nB * y->detCap * sizeof(SdDet));
     ok = ok && alloc((void**)&y->d_ndet, nB * 4);

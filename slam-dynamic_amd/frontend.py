@@ -61,6 +61,11 @@ def lib():
         L.sd_tracker_set_mappoints.argtypes = [vp, vp, vp, vp]
         L.sd_tracker_set_state.argtypes = [vp, vp]
         L.sd_tracker_prefetch.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, vp]
+        L.sd_tracker_prefetched_record_bytes.argtypes = [vp]
+        L.sd_tracker_prefetched_record_bytes.restype = sz
+        L.sd_tracker_export_prefetched.argtypes = [vp, i, i, vp, sz, vp]
+        L.sd_tracker_import_prefetched.argtypes = [vp, vp, sz, i, vp]
+        L.sd_tracker_discard_prefetched.argtypes = [vp]
         L.sd_batch_extract_host.argtypes = [vp, vp, sz, sz, i]
         L.sd_batch_results_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i)]
         L.sd_batch_counts.argtypes = [vp, vp, i]
@@ -555,6 +560,24 @@ class Tracker:
         batch: images in frame-major order (frame k, lane s, eye e).  The following n_frames track() calls pass d_images = 0."""
         check(lib().sd_tracker_prefetch(self.h, C.c_void_p(d_images), stride, image_pitch, C.c_void_p(d_depth or 0), depth_stride, depth_pitch, n_frames,
                                         C.c_void_p(stream or 0)))
+
+    def record_bytes(self):
+        """Bytes of one prefetched-frame record (sd_tracker_prefetched_record_bytes); 0 without lookahead."""
+        return int(lib().sd_tracker_prefetched_record_bytes(self.h))
+
+    def export_prefetched(self, first_frame, n_frames, d_records, record_stride=0, stream=None):
+        """Frames [first_frame, first_frame + n_frames) of the newest prefetched block -> records at d_records (record_stride bytes apart, 0 = packed),
+        frame-major (frame k, lane s)."""
+        check(lib().sd_tracker_export_prefetched(self.h, int(first_frame), int(n_frames), C.c_void_p(d_records), int(record_stride or self.record_bytes()),
+                                                 C.c_void_p(stream or 0)))
+
+    def import_prefetched(self, d_records, n_frames, record_stride=0, stream=None):
+        """n_frames * n_lanes records (frame-major) become the next outstanding prefetched block: frames whose history-free half ran elsewhere."""
+        check(lib().sd_tracker_import_prefetched(self.h, C.c_void_p(d_records), int(record_stride or self.record_bytes()), int(n_frames), C.c_void_p(stream or 0)))
+
+    def discard_prefetched(self):
+        """A worker drops its newest prefetched block after exporting it."""
+        check(lib().sd_tracker_discard_prefetched(self.h))
 
     def set_state(self, state):
         """state: per lane, bit0 = initialised, bit1 = mState == OK && !mVelocity.empty(); None = the automatic rule."""

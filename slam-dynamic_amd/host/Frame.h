@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "ORBextractor.h"
@@ -104,31 +105,30 @@ public:
     // results of Track_new's dynamic block for this frame
     int mnTrackHomoFlag = 0, mnSeparateRet = 0, mnRefFrameId = -1, mnTrackMatches = 0, mnLastMatches = -1;
 
-    // Frame::GetFeaturesInArea (src/Frame.cc:735-788) on the host copy of the grid
+    // Frame::GetFeaturesInArea (src/Frame.cc:735-788): key points of the grid cells a square window of half-width r touches, filtered by
+    // |du| < r, |dv| < r and an optional octave range.  Cells are visited column by column, a cell's members in key-point order (the order the
+    // matchers' tie-breaks depend on; the device walks the same order over its cell-sorted index list, k_proj_candidates).
     std::vector<size_t> GetFeaturesInArea(const float& x, const float& y, const float& r, const int minLevel = -1, const int maxLevel = -1) const
     {
-        std::vector<size_t> vIndices;
-        vIndices.reserve(N);
-        const int nMinCellX = std::max(0, (int)std::floor((x - mnMinX - r) * mfGridElementWidthInv));
-        if (nMinCellX >= FRAME_GRID_COLS) return vIndices;
-        const int nMaxCellX = std::min((int)FRAME_GRID_COLS - 1, (int)std::ceil((x - mnMinX + r) * mfGridElementWidthInv));
-        if (nMaxCellX < 0) return vIndices;
-        const int nMinCellY = std::max(0, (int)std::floor((y - mnMinY - r) * mfGridElementHeightInv));
-        if (nMinCellY >= FRAME_GRID_ROWS) return vIndices;
-        const int nMaxCellY = std::min((int)FRAME_GRID_ROWS - 1, (int)std::ceil((y - mnMinY + r) * mfGridElementHeightInv));
-        if (nMaxCellY < 0) return vIndices;
-        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
-        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
-            for (int iy = nMinCellY; iy <= nMaxCellY; iy++)
-                for (size_t j = 0; j < mGrid[ix][iy].size(); j++) {
-                    const sd_keypoint& kpUn = mvKeysUn[mGrid[ix][iy][j]];
-                    if (bCheckLevels) {
-                        if (kpUn.octave < minLevel) continue;
-                        if (maxLevel >= 0 && kpUn.octave > maxLevel) continue;
-                    }
-                    if (std::fabs(kpUn.x - x) < r && std::fabs(kpUn.y - y) < r) vIndices.push_back(mGrid[ix][iy][j]);
+        std::vector<size_t> hits;
+        hits.reserve(N);
+        // one axis of the window -> inclusive cell interval, empty (first > second) when the window misses the grid on that axis
+        auto span = [r](float centre, float origin, float invCell, int nCells) {
+            const int lo = (int)std::floor((centre - origin - r) * invCell), hi = (int)std::ceil((centre - origin + r) * invCell);
+            if (lo >= nCells || hi < 0) return std::pair<int, int>(1, 0);
+            return std::pair<int, int>(lo < 0 ? 0 : lo, hi > nCells - 1 ? nCells - 1 : hi);
+        };
+        const std::pair<int, int> cols = span(x, mnMinX, mfGridElementWidthInv, FRAME_GRID_COLS), rows = span(y, mnMinY, mfGridElementHeightInv, FRAME_GRID_ROWS);
+        if (cols.first > cols.second || rows.first > rows.second) return hits;
+        const bool levelFilter = minLevel > 0 || maxLevel >= 0;
+        for (int c = cols.first; c <= cols.second; c++)
+            for (int w = rows.first; w <= rows.second; w++)
+                for (const std::size_t idx : mGrid[c][w]) {
+                    const sd_keypoint& k = mvKeysUn[idx];
+                    const bool levelOk = !levelFilter || (k.octave >= minLevel && (maxLevel < 0 || k.octave <= maxLevel));
+                    if (levelOk && std::fabs(k.x - x) < r && std::fabs(k.y - y) < r) hits.push_back(idx);
                 }
-        return vIndices;
+        return hits;
     }
     bool isInImage(const float& x, const float& y) const { return x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY; }   // include/Frame.h:93-96
 };

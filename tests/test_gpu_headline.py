@@ -62,3 +62,31 @@ def test_headline_chain_colour_stereo_f32_detector(gpu, fe, orc, synth, pkg):
         wl.close()
     assert most > 16, "the sequences must contain a frame with more than 16 detector boxes (had at most %d)" % most
     assert len(flags) >= 2 * S and any(f != 0 for f in flags), "TrackHomo must have run on frames 3 and 4: %r" % flags
+
+
+def _run_ranks(argv, timeout=900):
+    import subprocess
+    script = os.path.join(graft.ROOT, "tests", "kitti_batch_ranks.py")
+    p = subprocess.run([sys.executable, script] + argv, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, "kitti_batch_ranks.py %s failed:\n%s\n%s" % (" ".join(argv), p.stdout[-3000:], p.stderr[-3000:])
+    return [l for l in p.stdout.splitlines() if l.startswith("KITTI_BATCH_OK")]
+
+
+def test_kitti_batch_as_benched_f32_detector(gpu):
+    """BASELINE configs[4] exactly as bench.py times it at N = 1 (bench.SequenceBatchWorkload.run; /root/reference Examples/Stereo/stereo_kitti.cc:81-155):
+    two 3-channel stereo sequences x 7 frames, the f32 detector over blocks of D = 3 frames per sequence, the history-free half through
+    sd_tracker_prefetch -> export -> import, boxes handed over behind the records, three blocks (3 + 3 + 1 frames: the second outstanding block is
+    consumed while the third is in flight).  Every frame of every lane == torch-fp32 boxes -> SequenceOracle."""
+    ok = _run_ranks(["--gpus", "1", "--sequences", "2", "--frames", "7", "--block-frames", "6"])
+    assert len(ok) == 1 and "blocks 3 D 3" in ok[0] and "frames 14" in ok[0], ok
+
+
+def test_kitti_batch_frames_sharded_over_two_ranks(gpu):
+    """configs[4] on two ranks (processes sharing the one GPU, gloo): three sequences -- rank 0 owns two, rank 1 one (its second lane repeats it) --,
+    every time block's frames dealt evenly to the two ranks whoever owns them, records + boxes through the all-to-all; every frame on every rank
+    equals the sequential oracle.  Given boxes (no detector: two f32 detectors' activations per process are not what this test is about) and
+    once with the detector on a shorter run."""
+    ok = _run_ranks(["--gpus", "2", "--sequences", "3", "--frames", "7", "--block-frames", "5", "--no-detector"])
+    assert len(ok) == 1 or len(ok) == 2, ok          # rank 0's line is always passed through
+    ok = _run_ranks(["--gpus", "2", "--sequences", "3", "--frames", "5", "--block-frames", "4"])
+    assert ok, ok

@@ -1,8 +1,10 @@
 """Host logic of bench.py and the synthetic harness (no GPU): sharding, byte accounting, gloo collectives."""
+import json
 import os
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -212,3 +214,171 @@ def test_sequence_batch_block_plan():
         assert all(abs(a - b) == 1 for a, b in zip(flat, flat[1:])) and max(flat) == 23 and min(flat) == 0      # consecutive frames stay neighbouring views
     D, plan = bench.block_plan(5, 2, 64, 24)
     assert D == 5 and plan == [(0, 5, [0, 1, 2, 3, 4])]
+
+
+def _canned_full_record(n_extras=12, kernels=16):
+    """A full bench record at least as heavy as round 3's 24 KB one (per-kernel tables, the extras' rooflines, long sample texts)."""
+    table = {"k_%02d" % i: {"alg_bytes_per_step": 987829248 + i, "ms_per_step": 0.336, "launches_per_step": 1.0, "achieved_GBs": 2940.4, "frac": 0.3675,
+                             "traffic_bytes_per_step": 1056616106, "traffic_over_alg": 1.07, "traffic_profile": "r04_headline_pmc.csv"} for i in range(kernels)}
+    fe_roof = {"bound": "hbm", "kernel": "k_fast_cells", "achieved": 463.84, "peak": 8000.0, "unit": "GB/s", "frac": 0.05798, "traffic": 801017941,
+               "traffic_profile": "r04_headline_pmc.csv", "algorithmic_bytes_per_launch": 739377664, "avg_launch_ms": 1.594, "images_per_launch": 512,
+               "kernels": table, "kernels_ms_per_step": {k: 0.3 for k in table}, "measured": "x" * 300, "note": "y" * 400}
+    roof = {"bound": "mfma", "kernel": "k_conv_f32 x 75 launches = the convolutions of one 256-image detector batch", "achieved": 128.3, "peak": 157.3,
+            "unit": "TFLOP/s", "frac": 0.8154, "limb_mode": None, "traffic": 364475262150, "traffic_profile": "r04_headline_pmc.csv",
+            "algorithmic_flops_per_launch": 29931130060800, "avg_launch_ms": 233.371, "algorithmic_bytes_per_launch": 171526021504, "operands": "f32",
+            "batch": 256, "measured": "m" * 300, "weights": "w" * 100, "front_end": fe_roof}
+    extras = {"extra-%d" % i: {"value": 1000.0 + i, "unit": "frames/s", "ms_per_step": 1.0, "workload": "t" * 500, "roofline": fe_roof} for i in range(n_extras)}
+    extras["broken"] = {"error": "RuntimeError: " + "e" * 300}
+    return {"metric": "tracking frames/sec (extract+match+dynamic-cull), KITTI 1241x376", "value": 1067.57, "unit": "frames/s", "n_gpus": 1, "rccl_ranks": 1,
+            "steps": 20, "warmup": 5, "ms_per_step": 239.7978, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8+f32",
+            "data": "synthetic", "config": {"workload": bench.WORKLOAD_TEXT["stereo-yolo"] + "; " + "q" * 400, "lanes_per_gpu": 256, "images_per_frame": 2,
+                                             "frames_timed": 5120, "timed_seconds": 4.8, "detector_arithmetic": "f32 operands, f32 accumulation (v_mfma_f32_32x32x2_f32)",
+                                             "sharding": "single GPU", "lane0_last_frame": {"N": 2000}},
+            "roofline": roof, "cpu_baseline": {"value": 9.997, "unit": "frames/s", "cores": 16, "kind": "port", "sample": "s" * 900,
+                                               "front_end_ms": {"median": 33.4}, "all_cores": {"value": 206.66, "threads": 16, "sample": "z" * 100}},
+            "extra": extras, "vocabulary": {"nodes": 1049641}, "value_f32x3": 1566.08, "dtype_f32x3": "u8+f32 operands as 3xbf16 limbs, f32 accumulate"}
+
+
+def test_bench_line_is_compact_and_complete(tmp_path):
+    """The driver keeps only a few KB of stdout: the printed line must parse, stay below 4 KB whatever the detail record holds, and still
+    carry metric / value / config.workload / roofline / cpu_baseline and one number per extra (round 3's 24 KB line was lost)."""
+    full = _canned_full_record()
+    assert len(json.dumps(full)) > 24000
+    line = bench.compact_line(full, "bench_detail.json")
+    assert "\n" not in line and len(line) < 4096
+    j = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert j[k] == full[k], k
+    assert j["config"]["workload"].startswith("KITTI stereo 1241x376") and j["config"]["lanes_per_gpu"] == 256
+    r = j["roofline"]
+    assert r["bound"] == "mfma" and r["frac"] == 0.8154 and r["achieved"] == 128.3 and r["peak"] == 157.3 and r["unit"] == "TFLOP/s"
+    assert r["traffic"] == 364475262150 and r["avg_launch_ms"] == 233.371 and "kernels" not in r and "kernels" not in r["front_end"]
+    assert r["front_end"]["kernel"] == "k_fast_cells" and r["front_end"]["bound"] == "hbm"
+    c = j["cpu_baseline"]
+    assert (c["value"], c["cores"], c["kind"], c["unit"]) == (9.997, 16, "port", "frames/s") and len(c["sample"]) <= 420
+    assert j["extra"]["extra-3"] == 1003.0 and "error" in j["extra"]["broken"]
+    assert j["value_f32x3"] == 1566.08 and j["detail"] == "bench_detail.json"
+    # a record with no roofline / cpu baseline / extras (N > 1 ranks) still gives a valid line with the contract's keys
+    bare = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config")}
+    j2 = json.loads(bench.compact_line(bare))
+    assert j2["roofline"] is None and j2["cpu_baseline"] is None and j2["extra"] == {}
+    # a pathological record (hundreds of extras) is cut down rather than printed over the limit
+    huge = _canned_full_record(n_extras=400)
+    l3 = bench.compact_line(huge, "bench_detail.json")
+    assert len(l3) < 4096 and json.loads(l3)["roofline"]["frac"] == 0.8154
+    # the detail record is what compact_line was given, on disk
+    old_root = bench.ROOT
+    try:
+        bench.ROOT = str(tmp_path)
+        os.makedirs(os.path.join(str(tmp_path), "gpurun_out"))
+        assert bench.write_detail(full, "d.json") == "d.json"
+        assert json.load(open(os.path.join(str(tmp_path), "gpurun_out", "d.json")))["extra"]["extra-0"]["roofline"]["kernels"]
+    finally:
+        bench.ROOT = old_root
+
+
+def test_bench_auto_extras_are_the_baseline_configs():
+    assert set(("rgbd", "tum-mask", "kitti-batch")) <= set(bench.AUTO_EXTRAS) and len(bench.AUTO_EXTRAS) <= 5
+    assert all(w in bench.WORKLOADS for w in bench.AUTO_EXTRAS)
+
+
+def _simulate_frame_shard(plan):
+    """Run frame_shard_plan's hand-over on the host for every rank at once: each unit's row is its (sequence, absolute frame) pair.
+    -> (units a rank computed over the whole job, per rank the [(t, lane sequences)] its tracker consumed in order)."""
+    world = plan["world"]
+    computed = [0] * world
+    consumed = [[] for _ in range(world)]
+    for B in plan["blocks"]:
+        views = [bench.frame_shard_rank_view(plan, B, r) for r in range(world)]
+        covered = sorted(u for v in views for u in v["mine"])
+        assert covered == sorted(B["units"]) and len(set(covered)) == len(covered)             # every frame of the block is computed exactly once
+        sent = []
+        for r, v in enumerate(views):
+            computed[r] += len(v["mine"])
+            rows = [v["mine"][i] for i in v["send_perm"]]                                      # grouped by destination
+            assert sum(v["send_splits"]) == len(rows)
+            cut, o = [], 0
+            for d in range(world):
+                cut.append(rows[o:o + v["send_splits"][d]]); o += v["send_splits"][d]
+                assert all(plan["owner"][q] == d for q, _ in cut[-1])
+            sent.append(cut)
+        for r, v in enumerate(views):
+            recv = [u for src in range(world) for u in sent[src][r]]                           # what an all-to-all delivers, source by source
+            assert [len(sent[src][r]) for src in range(world)] == v["recv_splits"] and recv == v["recv_units"]
+            pool = [recv[i] for i in v["pool_index"]]
+            S = plan["S"]
+            for k in range(B["n"]):
+                assert pool[k * S:(k + 1) * S] == [(q, k) for q in plan["lanes"][r]]
+                consumed[r].append((B["t0"] + k, [q for q, _ in pool[k * S:(k + 1) * S]]))
+    return computed, consumed
+
+
+def test_frame_shard_plan_balances_frames_and_delivers_every_frame_to_its_owner():
+    """configs[4], north star: "independent frames shard across the 8 GPUs".  The history-free half of the 11 x 256 frames is spread evenly over the
+    ranks (round 3 sharded whole sequences: 2 : 1 at 8 ranks), every frame reaches the owner of its sequence, and an owner's tracker consumes its
+    sequences' frames in time order."""
+    for world in (1, 2, 3, 4, 8):
+        plan = bench.frame_shard_plan(11, 256, world, 128, 24)
+        computed, consumed = _simulate_frame_shard(plan)
+        assert sum(computed) == 11 * 256
+        mean = sum(computed) / world
+        assert max(computed) / mean - 1 <= 0.05, (world, computed)                             # history-free load imbalance <= 5 %
+        per_block = [len(bench.frame_shard_rank_view(plan, B, r)["mine"]) for B in plan["blocks"][:-1] for r in range(world)]
+        assert not per_block or min(per_block) >= 120                                          # a detector batch stays about --block-frames images
+        owned = sorted(q for r in range(world) for q in set(plan["lanes"][r]))
+        assert owned == list(range(11))
+        for r in range(world):
+            assert [t for t, _ in consumed[r]] == list(range(256))
+            assert all(seqs == plan["lanes"][r] for _, seqs in consumed[r])
+        for B in plan["blocks"]:
+            assert all(abs(a - b) == 1 for a, b in zip(B["idx"], B["idx"][1:]))                # consecutive frames stay neighbouring views
+    small = bench.frame_shard_plan(11, 7, 2, 16, 24)                                           # a short job: one block + a ragged second one
+    assert small["D"] == 3 and [B["n"] for B in small["blocks"]] == [3, 3, 1]
+    _simulate_frame_shard(small)
+    with pytest.raises(ValueError):
+        bench.frame_shard_plan(11, 256, 12, 128)
+
+
+def _frame_shard_gloo_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        plan = bench.frame_shard_plan(11, 7, world, 16, 24)
+        ok = True
+        for bi, B in enumerate(plan["blocks"]):
+            v = bench.frame_shard_rank_view(plan, B, rank)
+            # a row = [sequence, absolute frame, producing rank] + payload derived from them: what a record carries
+            rows = torch.tensor([[q_, B["t0"] + k, rank, (q_ * 1000 + B["t0"] + k) % 251] for q_, k in v["mine"]], dtype=torch.int32).view(-1, 4)
+            send = rows[torch.tensor(v["send_perm"], dtype=torch.int64)] if len(v["mine"]) else rows
+            got, work = bench.exchange_rows(dist, world, send, v["send_splits"], v["recv_splits"])
+            if work is not None:
+                work.wait()
+            pool = got[torch.tensor(v["pool_index"], dtype=torch.int64)]
+            S = plan["S"]
+            for k in range(B["n"]):
+                for l, q_ in enumerate(plan["lanes"][rank]):
+                    row = pool[k * S + l].tolist()
+                    ok = ok and row[0] == q_ and row[1] == B["t0"] + k and row[3] == (q_ * 1000 + B["t0"] + k) % 251
+                    src = [r for r in range(world) if B["piece"][r][0] <= B["units"].index((q_, k)) < B["piece"][r][1]]
+                    ok = ok and row[2] == src[0]
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frame_shard_hand_over_gloo_world2():
+    """The block hand-over (bench.exchange_rows: all_to_all_single with split sizes) between two real processes: every owner ends up with the rows of
+    its sequences' frames, in pool order, whichever rank produced them."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_frame_shard_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps: p.start()
+    out = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps: p.join(60)
+    assert out == [(0, True), (1, True)]
