@@ -875,8 +875,9 @@ class SequenceBatchWorkload:
                 work.wait()
             self._to_pool(bi)
             B["send"] = None
-        self.main.wait_stream(self.xchg_stream)
-        self.trk.import_prefetched(self.pool[k].data_ptr(), B["n"], record_stride=self.RB, stream=self.main.cuda_stream)
+            # the import runs on the exchange stream too (the library's own streams are non-blocking: nothing orders them against torch's
+            # streams but an explicit stream argument); sd_tracker_track waits for the block's event
+            self.trk.import_prefetched(self.pool[k].data_ptr(), B["n"], record_stride=self.RB, stream=self.xchg_stream.cuda_stream)
         self.ready[k].synchronize()
         n, M = B["n"] * self.S, self.fe.MAXB
         tail = self.host_tail[k].numpy()[:n]

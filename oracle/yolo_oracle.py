@@ -15,24 +15,30 @@ def blob_from_image(bgr, net_w, net_h, resize_linear):
     return rgb * np.float32(1 / 255.0)
 
 
-def torch_forward(layers, per_conv, blob):
-    """fp32 forward of the Darknet graph; returns the list of layer outputs (torch tensors, NCHW)."""
+def torch_forward(layers, per_conv, blob, dtype=None):
+    """fp32 forward of the Darknet graph; returns the list of layer outputs (torch tensors, NCHW).  dtype=torch.float64: the same graph on
+    the same f32 weights / blob widened to double -- the ground truth the f32-class detector modes are ranked against (every mode, and torch's own
+    fp32 forward, is a differently ordered rounding of THIS)."""
     import torch
     import torch.nn.functional as F
-    x = torch.from_numpy(blob)[None]
+    dt = dtype or torch.float32
+    x = torch.from_numpy(blob)[None].to(dt)
     outs = []
     with torch.no_grad():
         for i, l in enumerate(layers):
             t = int(l["type"])
             if t == CONV:
                 p = per_conv[i]
-                w = torch.from_numpy(p["w"])
+                w = torch.from_numpy(p["w"]).to(dt)
                 x = F.conv2d(x, w, None, stride=int(l["stride"]), padding=int(l["size"]) // 2)
                 if l["batch_normalize"]:
-                    s = torch.from_numpy(p["gamma"] / np.sqrt(p["var"] + np.float32(1e-6)))
-                    x = (x - torch.from_numpy(p["mean"])[None, :, None, None]) * s[None, :, None, None] + torch.from_numpy(p["beta"])[None, :, None, None]
+                    if dt == torch.float32:
+                        s = torch.from_numpy(p["gamma"] / np.sqrt(p["var"] + np.float32(1e-6)))
+                    else:
+                        s = torch.from_numpy(p["gamma"]).to(dt) / torch.sqrt(torch.from_numpy(p["var"]).to(dt) + 1e-6)
+                    x = (x - torch.from_numpy(p["mean"]).to(dt)[None, :, None, None]) * s[None, :, None, None] + torch.from_numpy(p["beta"]).to(dt)[None, :, None, None]
                 else:
-                    x = x + torch.from_numpy(p["bias"])[None, :, None, None]
+                    x = x + torch.from_numpy(p["bias"]).to(dt)[None, :, None, None]
                 if l["leaky"]:
                     x = F.leaky_relu(x, 0.1)
             elif t == SHORTCUT:

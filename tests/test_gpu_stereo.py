@@ -46,3 +46,45 @@ def test_rgbd_depth_lookup_matches_oracle(gpu, fe, orc, synth):
     assert np.array_equal(ur[:n].view(np.uint32), our.view(np.uint32))
     assert np.array_equal(dep[:n].view(np.uint32), odep.view(np.uint32))
     b.close()
+
+
+def test_stereo_dense_band_takes_the_multi_pass_branches(gpu, fe, orc, synth):
+    """All texture of a 752 x 160 pair sits in a 36-row band and the extractor is asked for 4000 features: a 16-row chunk of k_stereo_match then
+    holds far more than SD_SR_LEFT (128) left key points and its row band more than SD_SR_CAND (256) right candidates, so the `lb` / `cb` pass
+    loops (csrc/k_frame.h) run several times and `s_best` carries (distance, iR) across candidate passes -- the branches the KITTI / TUM
+    geometries never reach.  Bit-exact against the oracle's Frame::ComputeStereoMatches (/root/reference/src/Frame.cc:874-1048)."""
+    cfg = synth.KITTI_STEREO
+    W, H = 752, 160
+    rng = np.random.Generator(np.random.PCG64(20260104))
+    left = np.full((H, W + 16), 128, np.uint8)
+    for y in range(62, 98, 3):                          # 3 x 3 blocks of random intensity: corners everywhere in the band
+        for x in range(0, W + 16, 3):
+            left[y:y + 3, x:x + 3] = rng.integers(20, 236)
+    right = np.ascontiguousarray(left[:, 9:9 + W])      # disparity 9 px
+    left = np.ascontiguousarray(left[:, :W])
+    ex = fe.ORBextractor(4000, cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+    b = fe.Batch(ex, W, H, 2)
+    try:
+        b.extract_host(np.stack([left, right]))
+        b.stereo_match(1, cfg["bf"], cfg["fx"])
+        oL = orc.Extractor(4000, cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+        oR = orc.Extractor(4000, cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+        kL, dL = oL(left); kR, dR = oR(right)
+        kpg, descg, _ = b.download(0)
+        assert kpg.tobytes() == kL.tobytes() and np.array_equal(descg, dL), "left extraction"
+        rows = np.floor(kL["y"]).astype(int)
+        chunk = np.bincount(rows // 16, minlength=H // 16 + 1)
+        assert chunk.max() > 2 * 128, "a 16-row chunk must hold several passes of left key points (has %d)" % chunk.max()
+        rrows = np.floor(kR["y"]).astype(int)
+        c = int(np.argmax(chunk))
+        band = int(((rrows >= 16 * c - 9) & (rrows <= 16 * c + 24)).sum())
+        assert band > 2 * 256, "the chunk's row band must hold several passes of right candidates (has %d)" % band
+        our, odep, osad, nm = orc.stereo_matches(oL, oR, kL, dL, kR, dR, cfg["bf"], cfg["fx"])
+        ur, dep, sad = b.download_stereo(0)
+        n = len(kL)
+        assert nm > 300, "the shifted pair must match (%d)" % nm
+        assert np.array_equal(sad[:n], osad), "SAD distances"
+        assert np.array_equal(ur[:n].view(np.uint32), our.view(np.uint32)), "mvuRight"
+        assert np.array_equal(dep[:n].view(np.uint32), odep.view(np.uint32)), "mvDepth"
+    finally:
+        b.close()

@@ -281,3 +281,83 @@ def test_f32_modes_do_not_depend_on_the_batch_slot(gpu, pkg, synth, prec):
             assert np.array_equal(d.layer_output(li, image=0), heads[(0, li)]), "%s: head %d differs between a batch of one and of five" % (prec, li)
     finally:
         d.close()
+
+
+F64_LAYERS = (0, 1, 2, 4, 11, 36, 61, 74, 76, 79, 80, 81, 86, 88, 93, 98, 100, 105)      # 18 layers: body, both routes, the three heads
+
+
+def _f64_error_table(pkg, yo, orc, layers, anchors, per, payload, imgs, NW, NH, modes=("f32", "f32w", "f32x3")):
+    """Relative L2 error of every mode's layer outputs -- and of torch's own fp32 forward -- against a torch FLOAT64 forward of the same f32 weights
+    and blob.  -> {mode: {layer: worst error over the images}}"""
+    import torch
+    H, W = imgs[0].shape[:2]
+    dev = torch.from_numpy(np.stack(imgs)).cuda()
+    blobs = [yo.blob_from_image(im, NW, NH, orc.resize_linear) for im in imgs]
+    truth = [yo.torch_forward(layers, per, b, dtype=torch.float64) for b in blobs]
+    table = {"torch-fp32": {}}
+    for k, b in enumerate(blobs):
+        r32 = yo.torch_forward(layers, per, b)
+        for layer in F64_LAYERS:
+            e = float(torch.linalg.norm(r32[layer][0].double() - truth[k][layer][0]) / torch.linalg.norm(truth[k][layer][0]))
+            table["torch-fp32"][layer] = max(table["torch-fp32"].get(layer, 0.0), e)
+    for prec in modes:
+        d = pkg.yolo.Detector(layers, anchors, NW, NH, max_batch=len(imgs), precision=prec)
+        try:
+            d.load_weights(payload)
+            d.forward_device(dev.data_ptr(), W, H, W * 3, W * H * 3, len(imgs), 0.5)
+            table[prec] = {}
+            for k in range(len(imgs)):
+                for layer in F64_LAYERS:
+                    got = torch.from_numpy(d.layer_output(layer, image=k).transpose(2, 0, 1).astype(np.float64))
+                    exp = truth[k][layer][0]
+                    assert got.shape == exp.shape, (prec, layer)
+                    e = float(torch.linalg.norm(got - exp) / torch.linalg.norm(exp))
+                    table[prec][layer] = max(table[prec].get(layer, 0.0), e)
+        finally:
+            d.close()
+    return table
+
+
+def _format_f64_table(title, table):
+    modes = list(table)
+    lines = [title, "layer  " + "  ".join("%11s" % m for m in modes) + "   f32w/f32  f32x3/f32"]
+    for layer in F64_LAYERS:
+        e = [table[m][layer] for m in modes]
+        base = table["f32"][layer]
+        lines.append("%5d  " % layer + "  ".join("%11.3e" % v for v in e) + "   %8.2f  %9.2f" % (table["f32w"][layer] / base, table["f32x3"][layer] / base))
+    return "\n".join(lines)
+
+
+def test_f32_class_modes_ranked_against_a_float64_forward(gpu, pkg, orc, synth):
+    """Which of the three f32-class detector modes is "the reference's arithmetic" (cv::dnn computes in f32 on the CPU with an unknown summation
+    order, /root/reference/src/yolo.cc:27-29,63-68) cannot be decided by comparing f32 evaluations with each other -- each is a differently ordered
+    rounding of the same real-valued network.  So every mode is measured against a float64 forward of the same f32 weights and input (torch, CPU):
+    at the full 640 x 480 network (18 layers: body, routes, all three heads) and on the 352 x 224 network with three images per batch (odd maps).
+    The bar: per layer, the Winograd mode (f32w) and the bf16-limb mode (f32x3) may be at most 1.5 x as far from the float64 result as the direct f32
+    mode is (floor 2e-7: below that the direct mode's own error is a handful of ulps of a layer's norm).  torch's fp32 forward is listed beside them:
+    it is the checker of the other tests, and it is no closer to float64 than the kernels are."""
+    import os
+    import torch
+    import __graft_entry__ as graft
+    yo = graft.load_yolo_oracle()
+    layers, anchors = pkg.yolo.v3_layers()
+    payload, per = pkg.yolo.synth_weights(layers, seed=3)
+    cfg = synth.KITTI03_RGBD
+    torch.set_num_threads(min(16, torch.get_num_threads() or 8))
+    full = [np.ascontiguousarray(synth.rgbd_frame(6, 0, cfg)[0][:, :, ::-1])]
+    small = [np.ascontiguousarray(synth.rgbd_frame(6, k, cfg)[0][:, :, ::-1]) for k in range(3)]
+    small[1] = np.ascontiguousarray(small[1][::-1]); small[2] = np.ascontiguousarray(small[2][:, ::-1])
+    t_full = _f64_error_table(pkg, yo, orc, layers, anchors, per, payload, full, 640, 480)
+    t_small = _f64_error_table(pkg, yo, orc, layers, anchors, per, payload, small, 352, 224)
+    text = _format_f64_table("relative L2 error vs a torch float64 forward, 640 x 480, 1 image", t_full) + "\n\n" + \
+        _format_f64_table("relative L2 error vs a torch float64 forward, 352 x 224, worst of 3 images", t_small) + "\n"
+    print(text)
+    out = os.path.join(graft.ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        open(os.path.join(out, "yolo_f64_errors.txt"), "w").write(text)
+    for name, tb in (("640x480", t_full), ("352x224", t_small)):
+        for layer in F64_LAYERS:
+            base = tb["f32"][layer]
+            assert base < 5e-6, "%s layer %d: the direct f32 mode is %.3g from float64" % (name, layer, base)
+            for mode in ("f32w", "f32x3"):
+                assert tb[mode][layer] <= max(1.5 * base, 2e-7), "%s layer %d: %s is %.3g from float64, the direct f32 mode %.3g" % (name, layer, mode, tb[mode][layer], base)
