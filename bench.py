@@ -531,14 +531,23 @@ class Workload:
             # (a high-priority detector stream -- torch.cuda.Stream(priority=-1) -- was measured: 1,042.4 / 1,042.9 frames/s against 1,041.5 / 1,042.5: no effect)
             self.det_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_det)]
             self.det_stream = self.det_streams[0]
-            self.det_in_flight = -1
-            self.lookahead = True             # the next frame's forward pass is launched before this frame's front end
-            S_ = self.S                       # two result slots: forward + NMS + download of frame t + 1 are queued before frame t's boxes are consumed
+            # Overlap mode (f32-class modes): a pass's blobFromImage and region decodes run on the detector's internal streams, NMS + download on a
+            # stream of their own, and TWO passes are kept enqueued ahead of the frame being tracked -- the convolutions of pass t + 1 start the
+            # moment pass t's last convolution ends, while t's decode / NMS / download and the host's turn-around run beside them.
+            self.box_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_det)]
+            self.depth = 2 if self.det_prec != "f16" else 1
+            if self.det_prec != "f16":
+                for d_ in self.dets:
+                    d_.set_overlap(True)
+            self.det_enqueued = -1            # last time step whose pass has been enqueued
+            self.lookahead = True             # passes are launched ahead of the frame whose front end runs
+            S_ = self.S                       # depth + 1 result slots: forward + NMS + download of frames t + 1 .. t + depth are queued before frame t's boxes are consumed
             M = fe.MAXB                       # SD_MAX_BOXES: the detector's box table and the tracker's have the same stride, nothing is cut
+            slots = self.depth + 1
             self.det_dev = [dict(b=torch.zeros((S_, M, 4), dtype=torch.float64, device=dev), c=torch.zeros((S_, M), dtype=torch.int32, device=dev),
-                                 f=torch.zeros((S_, M), dtype=torch.float32, device=dev), n=torch.zeros((S_,), dtype=torch.int32, device=dev)) for _ in range(2)]
-            self.det_host = [dict(b=torch.zeros((S_, M, 4), dtype=torch.float64).pin_memory(), n=torch.zeros((S_,), dtype=torch.int32).pin_memory()) for _ in range(2)]
-            self.det_ev = [[torch.cuda.Event() for _ in range(self.n_det)] for _ in range(2)]
+                                 f=torch.zeros((S_, M), dtype=torch.float32, device=dev), n=torch.zeros((S_,), dtype=torch.int32, device=dev)) for _ in range(slots)]
+            self.det_host = [dict(b=torch.zeros((S_, M, 4), dtype=torch.float64).pin_memory(), n=torch.zeros((S_,), dtype=torch.int32).pin_memory()) for _ in range(slots)]
+            self.det_ev = [[torch.cuda.Event() for _ in range(self.n_det)] for _ in range(slots)]
         self.cloud = name == "tum-mask"          # PointCloudMapping::generatePointCloud on every frame: the consumer of the semantic mask
         if self.cloud:
             self.cap_pts = ((self.W + 2) // 3) * ((self.H + 2) // 3)
@@ -594,9 +603,10 @@ class Workload:
         W, H, S = self.W, self.H, self.S
         boxes, n_boxes = (fr["boxes"], fr["n_boxes"]) if self.with_boxes else (None, None)
         if self.det is not None:
-            if self.det_in_flight != self.t:      # first step: nothing was launched ahead
-                self.enqueue_detector(self.t)
-            k = self.t & 1
+            last = self.n_total - 1 if self.lookahead else self.t
+            while self.det_enqueued < min(self.t + self.depth - 1, last):      # first step / after a reset: nothing was launched ahead
+                self.enqueue_detector(self.det_enqueued + 1)
+            k = self.t % (self.depth + 1)
             for e in self.det_ev[k]:
                 e.synchronize()                   # yolo->Segmentation_(imLeft) of THIS frame is on the host (stereo_kitti.cc:107)
             nb_all = self.det_host[k]["n"].numpy()
@@ -605,8 +615,8 @@ class Workload:
             n_boxes = nb_all.astype(np.int32)      # every box the detector kept goes on, as `SLAM.TrackStereo(imLeft, imRight, boxes, t)` does (stereo_kitti.cc:107-122);
             self.max_det_boxes = max(self.max_det_boxes, int(nb_all.max()))      # an overflow of the box tables is SD_ERR_CAPACITY, never a cut
             boxes = self.det_host[k]["b"].numpy().copy()
-            if self.lookahead and self.t + 1 < self.n_total:     # the next frame's detector pass is queued behind this one's download
-                self.enqueue_detector(self.t + 1)
+            if self.lookahead and self.det_enqueued < min(self.t + self.depth, last):     # one more pass goes out behind the ones in flight
+                self.enqueue_detector(self.det_enqueued + 1)
         res = self.trk.track(fr["images"].data_ptr(), W * 3, W * H * 3, fr["stamps"], boxes=boxes, n_boxes=n_boxes,
                              d_depth=fr["depth"].data_ptr() if fr["depth"] is not None else 0, depth_stride=W, depth_pitch=W * H,
                              stream=self.main.cuda_stream)
@@ -631,24 +641,24 @@ class Workload:
         return res
 
     def enqueue_detector(self, t):
-        """forward + postprocess_ (device NMS) + download of frame t's boxes on the detector stream, nothing waits."""
+        """forward (convolution stream) + postprocess_ (device NMS) + download of frame t's boxes (box stream), nothing waits on the host."""
         torch = self.torch
         W, H, S = self.W, self.H, self.S
-        k = t & 1
+        k = t % (self.depth + 1)
         fr = self.frame_at(t)
         d = self.det_dev[k]
         Sn = self.S_det
         for p in range(self.n_det):
-            st = self.det_streams[p]
-            ds = st.cuda_stream
+            ds = self.det_streams[p].cuda_stream
+            bst = self.box_streams[p] if self.det_prec != "f16" else self.det_streams[p]
             lo, hi = p * Sn, (p + 1) * Sn
             self.dets[p].forward_device(fr["images"].data_ptr() + lo * self.ipl * W * H * 3, W, H, W * 3, self.ipl * W * H * 3, Sn, 0.5, ds)
-            self.dets[p].boxes_device(Sn, W, H, d["b"][lo:hi].data_ptr(), d["c"][lo:hi].data_ptr(), d["f"][lo:hi].data_ptr(), d["n"][lo:hi].data_ptr(), stream=ds)
-            with torch.cuda.stream(st):
+            self.dets[p].boxes_device(Sn, W, H, d["b"][lo:hi].data_ptr(), d["c"][lo:hi].data_ptr(), d["f"][lo:hi].data_ptr(), d["n"][lo:hi].data_ptr(), stream=bst.cuda_stream)
+            with torch.cuda.stream(bst):
                 self.det_host[k]["b"][lo:hi].copy_(d["b"][lo:hi], non_blocking=True)
                 self.det_host[k]["n"][lo:hi].copy_(d["n"][lo:hi], non_blocking=True)
-                self.det_ev[k][p].record(st)
-        self.det_in_flight = t
+                self.det_ev[k][p].record(bst)
+        self.det_enqueued = t
 
     def close(self):
         self.trk.close()
@@ -1072,7 +1082,7 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline, vocab=None):
                 e1[p].record(wl.det_streams[p])
             torch.cuda.synchronize()
             det_ms = max(e0.elapsed_time(e) for e in e1) / 3
-            wl.det_in_flight = -1               # the profiled steps below run exactly like the timed ones (next frame's detector pass beside the front end)
+            wl.det_enqueued = wl.t - 1          # the profiled steps below run exactly like the timed ones (the passes ahead are enqueued again)
         for _ in range(prof_steps):
             wl.step()
         torch.cuda.synchronize()

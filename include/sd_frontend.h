@@ -562,6 +562,14 @@ int sd_yolo_boxes(sd_yolo* y, int image, int frame_cols, int frame_rows, float c
  * [n_images][SD_MAX_BOXES], n_boxes[n_images].  _device writes device buffers and does not synchronise; _batch also
  * downloads (one synchronisation for the whole batch).  More than 4096 rows above the threshold or more than
  * SD_MAX_BOXES kept boxes in an image -> SD_ERR_CAPACITY (use the per-image host form). */
+/* Overlap mode (f32-class modes; off by default).  A pass is blobFromImage -> 75 convolutions -> three region decodes -> (caller) NMS + download; on ONE
+ * stream the small kernels at both ends (about 1.5 % of a 256-image pass) serialise with the next pass's convolutions.  With overlap on,
+ * sd_yolo_forward_device(stream) issues the convolutions on `stream`, blobFromImage on an internal stream ahead of them and the decodes on another
+ * behind their heads (events order them; consecutive passes are protected against each other the same way), and sd_yolo_boxes_device / _batch wait for
+ * the decodes on THEIR stream argument -- give them a stream of their own and enqueue the next pass before consuming this one's boxes
+ * (bench.py: two passes ahead).  `stream` of sd_yolo_forward_device is then NOT a completion point for the decoded rows; the host forms
+ * (sd_yolo_boxes, sd_yolo_mask_*) synchronise the device as before.  Results are the same bits either way (tests/test_gpu_yolo.py). */
+int sd_yolo_set_overlap(sd_yolo* y, int on);
 int sd_yolo_boxes_device(sd_yolo* y, int n_images, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold,
                          double* d_boxes, int32_t* d_class_ids, float* d_confidences, int32_t* d_n_boxes, void* stream);
 int sd_yolo_boxes_batch(sd_yolo* y, int n_images, int frame_cols, int frame_rows, float conf_threshold, float nms_threshold,

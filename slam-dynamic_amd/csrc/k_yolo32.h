@@ -322,3 +322,21 @@ __global__ void __launch_bounds__(256) k_blob_from_image_f32(const uint8_t* __re
     float* o = dst + ((size_t)img * dh * dw + (size_t)y * dw + x) * 4;
     *(sd_f4*)o = sd_f4{swapRB ? ch[2] : ch[0], ch[1], swapRB ? ch[0] : ch[2], 0.f};
 }
+
+
+// [upsample] x 2 (nearest) of `a` (C1 channels at stride aStride, h x w) into channels [0, C1) of `out` (2h x 2w, Ct channels per pixel).  The second
+// input of the [route] is not touched: in the f32-class modes its producer writes it in place (sd_yolo_create_prec).  One 16-byte piece per thread:
+// a piece is read once per output pixel (four times in all, three of them from L2) and written once.
+__global__ void __launch_bounds__(256) k_upsample_into_f32(const float* __restrict__ a, int C1, int aStride, int h, int w, float* __restrict__ out, int Ct, int N)
+{
+    const int q = C1 / 4, H2 = 2 * h, W2 = 2 * w;
+    const size_t total = (size_t)N * H2 * W2 * q;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % q);
+        const size_t p = i / q;
+        const int x = (int)(p % W2);
+        const size_t r = p / W2;
+        const int y = (int)(r % H2), n = (int)(r / H2);
+        *(sd_f4*)(out + p * Ct + 4 * c4) = *(const sd_f4*)(a + (((size_t)n * h + (y >> 1)) * w + (x >> 1)) * aStride + 4 * c4);
+    }
+}

@@ -41,6 +41,12 @@ struct sd_yolo {
     bool attrGlds = false, attrFlat3 = false;      // dynamic-LDS limits of the convolution kernels raised on this device
     int lastN = 0;
     hipStream_t stream = nullptr;
+    // overlap mode (sd_yolo_set_overlap, f32-class modes): blobFromImage of a pass on sPre, the region decodes on sPost, ordered against the convolution
+    // stream by events, so that with two passes enqueued the next pass's convolutions start while this pass's decode / NMS / download still run
+    bool overlap = false, haveL0 = false, haveDecoded = false, haveNms = false;
+    hipStream_t sPre = nullptr, sPost = nullptr;
+    hipEvent_t evBlob = nullptr, evL0 = nullptr, evHead[3] = {nullptr, nullptr, nullptr}, evDecoded = nullptr, evNms = nullptr;
+    // 2-input [route]s whose second input is written in place by its producer (f32-class modes): only the up-sampled half is copied
     std::vector<void*> owned;
     double convFlops = 0;     // per image
 };

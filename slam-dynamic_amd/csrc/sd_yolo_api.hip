@@ -35,6 +35,10 @@ static void yolo_free(sd_yolo* y)
     if (y->d_hostImg) (void)hipFree(y->d_hostImg);
     if (y->d_hostMask) (void)hipFree(y->d_hostMask);
     if (y->stream) (void)hipStreamDestroy(y->stream);
+    if (y->sPre) (void)hipStreamDestroy(y->sPre);
+    if (y->sPost) (void)hipStreamDestroy(y->sPost);
+    hipEvent_t evs[] = {y->evBlob, y->evL0, y->evHead[0], y->evHead[1], y->evHead[2], y->evDecoded, y->evNms};
+    for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     delete y;
 }
 
@@ -183,9 +187,51 @@ int sd_yolo_create_prec(sd_yolo** out, const sd_yolo_layer* layers, int n_layers
             r.out = y->R[i - 1].out; r.alias = true; r.outC = y->R[i - 1].outC;
         }
     }
+    // f32-class modes: the second input of a 2-input [route] (yolov3.cfg: layers 61 and 36, the skip connections of the two up-sampling branches) is
+    // written IN PLACE -- its producer's output pointer becomes the route buffer at the channel offset, its stride the route's channel count -- so the
+    // route copies only the up-sampled half (k_upsample_into_f32).  Possible when the producer is a convolution (with or without a fused shortcut)
+    // and its tensor is dense; every consumer reads it through (pointer, channel stride) anyway.
+    for (int i = 0; ok && y->f32 && i < n_layers; i++) {
+        const sd_yolo_layer& l = y->L[i];
+        if (l.type != SD_YOLO_ROUTE || l.nfrom != 2) continue;
+        const int fa = yolo_resolve(i, l.from[0]), fb = yolo_resolve(i, l.from[1]);
+        const int src = yolo_resolve(fa, -1);
+        sd_yolo::Rt& rb = y->R[fb];
+        const int conv = y->L[fb].type == SD_YOLO_CONV ? fb : (y->L[fb].type == SD_YOLO_SHORTCUT && rb.alias ? fb - 1 : -1);
+        if (conv < 0 || y->L[fa].type != SD_YOLO_UPSAMPLE || rb.outC != rb.C || y->R[conv].outC != y->R[conv].C || (y->R[src].C % 4) || (rb.C % 4)) continue;
+        bool soleRoute = true;                             // one route only may own the tensor's storage
+        for (int j = 0; j < n_layers; j++)
+            if (j != i && y->L[j].type == SD_YOLO_ROUTE)
+                for (int k = 0; k < y->L[j].nfrom; k++) if (yolo_resolve(j, y->L[j].from[k]) == fb) soleRoute = false;
+        if (!soleRoute) continue;
+        float* at = (float*)y->R[i].out + y->R[src].C;
+        y->R[conv].out = (_Float16*)at; y->R[conv].outC = y->R[i].C;
+        rb.out = (_Float16*)at; rb.outC = y->R[i].C;
+        y->R[i].alias = true;                              // marks the route: its second input is already in place
+    }
     if (ok) ok = hipStreamCreateWithFlags(&y->stream, hipStreamNonBlocking) == hipSuccess;
     if (!ok) { yolo_free(y); return set_err(SD_ERR_HIP, "detector allocation failed"); }
     *out = y;
+    return SD_OK;
+}
+
+// Overlap mode (f32-class modes): blobFromImage runs on an internal stream ahead of the pass's first convolution, the three region decodes on
+// another one behind their heads' convolutions, ordered by events; sd_yolo_boxes_device (on ITS stream argument) waits for the decodes.  With
+// the next pass already enqueued on the convolution stream, its convolutions start while this pass's decode / NMS / download run beside them.
+// The stream given to sd_yolo_forward_device then is NOT a completion point for the decoded rows: consume them through sd_yolo_boxes_device /
+// sd_yolo_boxes_batch (any stream) or the host forms (they synchronise the device).
+int sd_yolo_set_overlap(sd_yolo* y, int on)
+{
+    if (!y) return SD_ERR_INVALID;
+    if (on && !y->f32) return set_err(SD_ERR_UNSUPPORTED, "overlap mode exists for the f32-class detector modes");
+    if (on && !y->sPre) {
+        HIPCHK(hipStreamCreateWithFlags(&y->sPre, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&y->sPost, hipStreamNonBlocking));
+        hipEvent_t* evs[] = {&y->evBlob, &y->evL0, &y->evHead[0], &y->evHead[1], &y->evHead[2], &y->evDecoded, &y->evNms};
+        for (hipEvent_t* e : evs) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    if (!on && y->overlap) HIPCHK(hipDeviceSynchronize());
+    y->overlap = on != 0;
     return SD_OK;
 }
 
@@ -387,12 +433,20 @@ static int f32_group_y(int tilesY, int bm, int kdim)
 static int yolo_forward_f32(sd_yolo* y, const uint8_t* d_bgr, int width, int height, size_t stride, size_t image_pitch, int n,
                             float conf_threshold, hipStream_t s)
 {
+    const bool ov = y->overlap;
+    hipStream_t sb = ov ? y->sPre : s, sd = ov ? y->sPost : s;          // blobFromImage / region decodes
+    if (ov && y->haveL0) HIPCHK(hipStreamWaitEvent(sb, y->evL0, 0));    // the previous pass's first convolution has read the blob
     {
         dim3 blk(64, 4), grd((y->netW + 63) / 64, (y->netH + 3) / 4, n);
-        hipLaunchKernelGGL(k_blob_from_image_f32, grd, blk, 0, s, d_bgr, width, height, stride, image_pitch, y->d_ct, y->d_rt, y->d_blob8, y->netW, y->netH, 1);
+        hipLaunchKernelGGL(k_blob_from_image_f32, grd, blk, 0, sb, d_bgr, width, height, stride, image_pitch, y->d_ct, y->d_rt, y->d_blob8, y->netW, y->netH, 1);
     }
     LAUNCH_CHECK("k_blob_from_image_f32");
-    HIPCHK(hipMemsetAsync(y->d_ndet, 0, (size_t)n * 4, s));
+    if (ov) {
+        HIPCHK(hipEventRecord(y->evBlob, sb));
+        HIPCHK(hipStreamWaitEvent(s, y->evBlob, 0));
+    }
+    int head = 0;
+    bool headGuard = ov && y->haveDecoded;              // before the first head tensor is overwritten: the previous pass's decodes have read them
     if (!y->attrF32) {
         HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<32, 2, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(32, 2, 2, 8)));
         HIPCHK(hipFuncSetAttribute((const void*)k_conv_f32<32, 2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SD_F32_LDS(32, 2, 2, 4)));
@@ -448,6 +502,7 @@ HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3c<5>, hipFuncAttributeMaxDyn
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wino_gemm_f32<16, 2>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(256), SD_WINO_LDS(16, 2), s, A);
             LAUNCH_CHECK("k_wino_gemm_f32");
         } else if (l.type == SD_YOLO_CONV) {
+            if (headGuard && i + 1 < y->L.size() && y->L[i + 1].type == SD_YOLO_YOLO) { HIPCHK(hipStreamWaitEvent(s, y->evDecoded, 0)); headGuard = false; }
             SdConvArgsF A;
             A.in = cur; A.wgt = y->d_wgt32 + r.wOff; A.bias = y->d_bias + r.bOff; A.res = nullptr; A.out = (float*)r.out; A.zero = (const float*)y->d_zero;
             A.N = n; A.H = H; A.W = W; A.cin = i == 0 ? 8 : r.cinPad; A.cinStride = Cs; A.pair = i == 0 ? 1 : 0;
@@ -504,22 +559,39 @@ HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3c<5>, hipFuncAttributeMaxDyn
             const int fa = yolo_resolve((int)i, l.from[0]), fb = yolo_resolve((int)i, l.from[1]);
             const int src = yolo_resolve(fa, -1);
             const sd_yolo::Rt& ra = y->R[src]; const sd_yolo::Rt& rb = y->R[fb];
-            if (ra.outC != ra.C || rb.outC != rb.C || (ra.C % 4) || (rb.C % 4)) return set_err(SD_ERR_UNSUPPORTED, "route inputs must be dense, channels % 4 == 0");
-            // the copy kernel moves 16-byte pieces: an f32 channel counts as two halfs
-            hipLaunchKernelGGL(k_upsample_concat, dim3(2048), dim3(256), 0, s, ra.out, 2 * ra.C, ra.H, ra.W, rb.out, 2 * rb.C, r.out, n);
-            LAUNCH_CHECK("k_upsample_concat");
+            if (r.alias) {                             // the skip tensor was written in place by its producer: only the up-sampled half moves
+                const size_t quads = (size_t)n * r.H * r.W * (ra.C / 4);
+                hipLaunchKernelGGL(k_upsample_into_f32, dim3((unsigned)std::min<size_t>((quads + 255) / 256, 4096)), dim3(256), 0, s, (const float*)ra.out, ra.C, ra.outC, ra.H, ra.W,
+                                   (float*)r.out, r.C, n);
+                LAUNCH_CHECK("k_upsample_into_f32");
+            } else {
+                if (ra.outC != ra.C || rb.outC != rb.C || (ra.C % 4) || (rb.C % 4)) return set_err(SD_ERR_UNSUPPORTED, "route inputs must be dense, channels % 4 == 0");
+                // the copy kernel moves 16-byte pieces: an f32 channel counts as two halfs
+                hipLaunchKernelGGL(k_upsample_concat, dim3(2048), dim3(256), 0, s, ra.out, 2 * ra.C, ra.H, ra.W, rb.out, 2 * rb.C, r.out, n);
+                LAUNCH_CHECK("k_upsample_concat");
+            }
         } else if (l.type == SD_YOLO_YOLO) {
             const float* an = y->anchors;
             const int rows = n * r.H * r.W * 3;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_region_decode<float>), dim3((rows + 255) / 256), dim3(256), 0, s, (const float*)r.out, r.outC, r.H, r.W, n, an[2 * l.mask[0]],
+            if (ov && head < 3) {
+                HIPCHK(hipEventRecord(y->evHead[head], s));
+                HIPCHK(hipStreamWaitEvent(sd, y->evHead[head], 0));
+                if (head == 0 && y->haveNms) HIPCHK(hipStreamWaitEvent(sd, y->evNms, 0));     // the previous pass's NMS has read the row lists
+            }
+            if (head == 0) HIPCHK(hipMemsetAsync(y->d_ndet, 0, (size_t)n * 4, sd));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_region_decode<float>), dim3((rows + 255) / 256), dim3(256), 0, sd, (const float*)r.out, r.outC, r.H, r.W, n, an[2 * l.mask[0]],
                                an[2 * l.mask[0] + 1], an[2 * l.mask[1]], an[2 * l.mask[1] + 1], an[2 * l.mask[2]], an[2 * l.mask[2] + 1],
                                y->netW, y->netH, conf_threshold, rowBase, y->d_dets, y->d_ndet, y->detCap, n == 1 ? y->d_raw : nullptr);
             LAUNCH_CHECK("k_region_decode");
             rowBase += r.H * r.W * 3;
+            head++;
         }
+        if (ov && i == 0) { HIPCHK(hipEventRecord(y->evL0, s)); y->haveL0 = true; }
         if (l.type != SD_YOLO_YOLO && l.type != SD_YOLO_UPSAMPLE) { cur = (const float*)r.out; H = r.H; W = r.W; Cs = r.outC; }
         if (l.type == SD_YOLO_YOLO) { cur = (const float*)r.out; }
     }
+    if (head == 0) HIPCHK(hipMemsetAsync(y->d_ndet, 0, (size_t)n * 4, sd));          // a network without a [yolo] layer yields no rows
+    if (ov) { HIPCHK(hipEventRecord(y->evDecoded, sd)); y->haveDecoded = true; }
     return SD_OK;
 }
 
@@ -540,7 +612,7 @@ int sd_yolo_forward_device(sd_yolo* y, const uint8_t* d_bgr, int width, int heig
         int rc = yolo_forward_f32(y, d_bgr, width, height, stride, image_pitch, n, conf_threshold, s);
         if (rc != SD_OK) return rc;
         y->lastN = n;
-        if (!stream_) HIPCHK(hipStreamSynchronize(s));
+        if (!stream_) { HIPCHK(hipStreamSynchronize(s)); if (y->overlap) HIPCHK(hipStreamSynchronize(y->sPost)); }
         return SD_OK;
     }
     {
@@ -792,9 +864,11 @@ int sd_yolo_boxes_device(sd_yolo* y, int n_images, int frame_cols, int frame_row
     if (n_images == 0) return SD_OK;
     hipStream_t s = stream_ ? (hipStream_t)stream_ : y->stream;
     if (!y->attrNms) { HIPCHK(hipFuncSetAttribute((const void*)k_yolo_nms, hipFuncAttributeMaxDynamicSharedMemorySize, SD_NMS_LDS)); y->attrNms = true; }
+    if (y->overlap && y->haveDecoded) HIPCHK(hipStreamWaitEvent(s, y->evDecoded, 0));      // the decodes of the last pass (internal stream)
     hipLaunchKernelGGL(k_yolo_nms, dim3(n_images), dim3(256), SD_NMS_LDS, s, y->d_dets, y->d_ndet, y->detCap, frame_cols, frame_rows, conf_threshold,
                        nms_threshold, d_boxes, d_class_ids, d_confidences, d_n_boxes);
     LAUNCH_CHECK("k_yolo_nms");
+    if (y->overlap) { HIPCHK(hipEventRecord(y->evNms, s)); y->haveNms = true; }
     return SD_OK;
 }
 

@@ -231,6 +231,12 @@ class Detector:
                                               fe._p(cf), fe._p(nb), C.c_void_p(stream or 0)))
         return [(b[i, :nb[i]].copy(), cid[i, :nb[i]].copy(), cf[i, :nb[i]].copy()) for i in range(n_images)]
 
+    def set_overlap(self, on=True):
+        """sd_yolo_set_overlap: blobFromImage / region decodes on internal streams around the convolution stream (f32-class modes)."""
+        L = fe.lib()
+        L.sd_yolo_set_overlap.argtypes = [C.c_void_p, C.c_int]
+        fe.check(L.sd_yolo_set_overlap(self.h, int(bool(on))))
+
     def boxes_device(self, n_images, frame_cols, frame_rows, d_boxes, d_cls, d_conf, d_n, conf=0.5, nms=0.4, stream=None):
         """The same post-processing into caller-owned DEVICE buffers ([n][MAXB][4] f64, [n][MAXB] i32, [n][MAXB] f32, [n] i32; MAXB = SD_MAX_BOXES), no synchronisation."""
         L = fe.lib()

@@ -62,13 +62,14 @@ def test_stereo_dense_band_takes_the_multi_pass_branches(gpu, fe, orc, synth):
             left[y:y + 3, x:x + 3] = rng.integers(20, 236)
     right = np.ascontiguousarray(left[:, 9:9 + W])      # disparity 9 px
     left = np.ascontiguousarray(left[:, :W])
-    ex = fe.ORBextractor(4000, cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+    NL = 5                                              # 160 rows: the sixth level would have no FAST cell left (spec Q8: unsupported geometry)
+    ex = fe.ORBextractor(4000, cfg["scale_factor"], NL, cfg["ini_th_fast"], cfg["min_th_fast"])
     b = fe.Batch(ex, W, H, 2)
     try:
         b.extract_host(np.stack([left, right]))
         b.stereo_match(1, cfg["bf"], cfg["fx"])
-        oL = orc.Extractor(4000, cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
-        oR = orc.Extractor(4000, cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+        oL = orc.Extractor(4000, cfg["scale_factor"], NL, cfg["ini_th_fast"], cfg["min_th_fast"])
+        oR = orc.Extractor(4000, cfg["scale_factor"], NL, cfg["ini_th_fast"], cfg["min_th_fast"])
         kL, dL = oL(left); kR, dR = oR(right)
         kpg, descg, _ = b.download(0)
         assert kpg.tobytes() == kL.tobytes() and np.array_equal(descg, dL), "left extraction"

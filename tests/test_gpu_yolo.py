@@ -361,3 +361,56 @@ def test_f32_class_modes_ranked_against_a_float64_forward(gpu, pkg, orc, synth):
             assert base < 5e-6, "%s layer %d: the direct f32 mode is %.3g from float64" % (name, layer, base)
             for mode in ("f32w", "f32x3"):
                 assert tb[mode][layer] <= max(1.5 * base, 2e-7), "%s layer %d: %s is %.3g from float64, the direct f32 mode %.3g" % (name, layer, mode, tb[mode][layer], base)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f32x3"])
+def test_overlap_mode_gives_the_same_boxes_with_passes_in_flight(gpu, pkg, synth, prec):
+    """sd_yolo_set_overlap: blobFromImage on an internal stream ahead of a pass's convolutions, the region decodes on another behind their heads, NMS on
+    the caller's box stream -- and three passes on different image pairs enqueued back to back without a host synchronisation between them (what
+    bench.py does, two passes ahead).  Every pass's boxes, classes, confidences and counts must be the bits the plain single-stream pass gives: the
+    events order blob / head tensors / row lists between consecutive passes."""
+    import torch
+    layers, anchors = pkg.yolo.v3_layers()
+    payload, _ = pkg.yolo.synth_weights(layers, seed=3)
+    cfg = synth.KITTI03_RGBD
+    M = pkg.frontend.MAXB
+    sets = []
+    for base in (0, 2, 4):
+        imgs = [np.ascontiguousarray(synth.rgbd_frame(6, base + k, cfg)[0][:, :, ::-1]) for k in range(2)]
+        sets.append(torch.from_numpy(np.stack(imgs)).cuda())
+    H, W = sets[0].shape[1:3]
+    d = pkg.yolo.Detector(layers, anchors, 640, 480, max_batch=2, precision=prec)
+
+    def out_buffers():
+        return dict(b=torch.zeros((2, M, 4), dtype=torch.float64, device="cuda"), c=torch.zeros((2, M), dtype=torch.int32, device="cuda"),
+                    f=torch.zeros((2, M), dtype=torch.float32, device="cuda"), n=torch.full((2,), -7, dtype=torch.int32, device="cuda"))
+    try:
+        d.load_weights(payload)
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        plain = []
+        for dev in sets:                                   # reference: one stream, synchronised after every pass
+            o = out_buffers()
+            d.forward_device(dev.data_ptr(), W, H, W * 3, W * H * 3, 2, 0.5, s1.cuda_stream)
+            d.boxes_device(2, W, H, o["b"].data_ptr(), o["c"].data_ptr(), o["f"].data_ptr(), o["n"].data_ptr(), stream=s1.cuda_stream)
+            torch.cuda.synchronize()
+            plain.append({k: v.cpu().numpy() for k, v in o.items()})
+        assert sum(int(p["n"].sum()) for p in plain) > 0 and all((p["n"] >= 0).all() for p in plain)
+        assert not np.array_equal(plain[0]["b"], plain[1]["b"]), "the passes must differ for the test to mean anything"
+        d.set_overlap(True)
+        outs = [out_buffers() for _ in sets]
+        for rep in range(2):                               # twice: the second round starts with every event already recorded once
+            for dev, o in zip(sets, outs):
+                d.forward_device(dev.data_ptr(), W, H, W * 3, W * H * 3, 2, 0.5, s1.cuda_stream)
+                d.boxes_device(2, W, H, o["b"].data_ptr(), o["c"].data_ptr(), o["f"].data_ptr(), o["n"].data_ptr(), stream=s2.cuda_stream)
+            torch.cuda.synchronize()
+            for k, (o, p) in enumerate(zip(outs, plain)):
+                for key in ("n", "b", "c", "f"):
+                    assert np.array_equal(o[key].cpu().numpy(), p[key]), "overlap mode, round %d, pass %d: %s differs" % (rep, k, key)
+        d.set_overlap(False)
+        o = out_buffers()
+        d.forward_device(sets[1].data_ptr(), W, H, W * 3, W * H * 3, 2, 0.5, s1.cuda_stream)
+        d.boxes_device(2, W, H, o["b"].data_ptr(), o["c"].data_ptr(), o["f"].data_ptr(), o["n"].data_ptr(), stream=s1.cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(o["b"].cpu().numpy(), plain[1]["b"]) and np.array_equal(o["n"].cpu().numpy(), plain[1]["n"])
+    finally:
+        d.close()
