@@ -535,8 +535,9 @@ class Workload:
             # stream of their own, and TWO passes are kept enqueued ahead of the frame being tracked -- the convolutions of pass t + 1 start the
             # moment pass t's last convolution ends, while t's decode / NMS / download and the host's turn-around run beside them.
             self.box_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_det)]
-            self.depth = 2 if self.det_prec != "f16" else 1
-            if self.det_prec != "f16":
+            self.overlap = self.det_prec != "f16" and os.environ.get("SD_BENCH_DET_OVERLAP", "1") != "0"      # developer switch: "0" = one stream, one pass ahead (A/B runs)
+            self.depth = 2 if self.overlap else 1
+            if self.overlap:
                 for d_ in self.dets:
                     d_.set_overlap(True)
             self.det_enqueued = -1            # last time step whose pass has been enqueued
@@ -650,7 +651,7 @@ class Workload:
         Sn = self.S_det
         for p in range(self.n_det):
             ds = self.det_streams[p].cuda_stream
-            bst = self.box_streams[p] if self.det_prec != "f16" else self.det_streams[p]
+            bst = self.box_streams[p] if self.overlap else self.det_streams[p]
             lo, hi = p * Sn, (p + 1) * Sn
             self.dets[p].forward_device(fr["images"].data_ptr() + lo * self.ipl * W * H * 3, W, H, W * 3, self.ipl * W * H * 3, Sn, 0.5, ds)
             self.dets[p].boxes_device(Sn, W, H, d["b"][lo:hi].data_ptr(), d["c"][lo:hi].data_ptr(), d["f"][lo:hi].data_ptr(), d["n"][lo:hi].data_ptr(), stream=bst.cuda_stream)

@@ -35,6 +35,18 @@ __device__ __forceinline__ int sd_wave_append(bool pred, int* counter)
     return pred ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
 }
 
+// Slot reservation by ONE LDS atomic per lane (returns the old counter value).  Written as the instruction itself: handed an atomicAdd on a
+// workgroup-uniform address the compiler's atomic optimiser rebuilds the wave-level form -- a scan over the active lanes (v_readlane / v_writelane
+// per lane, or six DPP adds) around one atomic -- i.e. exactly the vector-ALU work this kernel, bound by vector-ALU issue, wants to hand to the LDS
+// unit.  The same-address atomics of a wave serialise there; the LDS unit has the time (its other traffic here: ~20 byte reads per candidate).
+__device__ __forceinline__ int sd_lds_add_rtn(int* counter, int v)
+{
+    int old;
+    const unsigned addr = (unsigned)(size_t)counter;          // generic address of an LDS object: the low half is the LDS offset
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(addr), "v"(v) : "memory");
+    return old;
+}
+
 // Per-cell descriptor of the staged kernel: everything the window fetch needs in ONE scalar load (the generic SdCell needs the
 // level table behind it, a second dependent load before the first pixel can be requested).
 struct SdFastCell {
@@ -149,20 +161,15 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 const int nvalid = sw - 4 * gq;                               // pixels of this group inside the scan
                 if (nvalid < 4) pmask &= (1u << (8 * nvalid)) - 1u;
             }
-            // one slot reservation per wave: the four candidate bits of a lane go out bit plane by bit plane (ballot + mbcnt,
-            // ~5 VALU each) instead of through a six-step prefix scan of the per-lane counts; list order is free
-            const unsigned long long b0 = __ballot(pmask & 0x80u), b1 = __ballot(pmask & 0x8000u), b2 = __ballot(pmask & 0x800000u), b3 = __ballot(pmask & 0x80000000u);
-            const int c0 = __popcll(b0), c1 = __popcll(b1), c2 = __popcll(b2), c3 = __popcll(b3);
-            const int wtot = c0 + c1 + c2 + c3;
-            if (wtot) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&s_cnt1, wtot);
-                base = __builtin_amdgcn_readfirstlane(base);
+            // Slot reservation: ONE LDS atomic per lane that holds candidates (sd_lds_add_rtn; list order is free).  The wave-level form (four
+            // bit-plane ballots + mbcnt + the per-plane offsets) was ~45 vector instructions per iteration, more than the compass test itself.
+            if (pmask) {
+                int pos = sd_lds_add_rtn(&s_cnt1, __popc(pmask));
                 const unsigned short e0 = (unsigned short)((sy << 8) | (4 * gq));
-                if (pmask & 0x80u) list1[base + __builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, 0u))] = e0;
-                if (pmask & 0x8000u) list1[base + c0 + __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0u))] = e0 + 1;
-                if (pmask & 0x800000u) list1[base + c0 + c1 + __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b2, 0u))] = e0 + 2;
-                if (pmask & 0x80000000u) list1[base + c0 + c1 + c2 + __builtin_amdgcn_mbcnt_hi((unsigned)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b3, 0u))] = e0 + 3;
+                if (pmask & 0x80u) list1[pos++] = e0;
+                if (pmask & 0x8000u) list1[pos++] = e0 + 1;
+                if (pmask & 0x800000u) list1[pos++] = e0 + 2;
+                if (pmask & 0x80000000u) list1[pos] = e0 + 3;
             }
         }
         __syncthreads();
@@ -186,9 +193,12 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 // (0.2 - 0.7 % of the survivors) is handled by a second evaluation in the waves that hold such a pixel; a polarity
                 // that cannot reach T contributes nothing to max(dark, bright) of a corner, so the stored score is unchanged.
                 const int r0 = p[3 * S], r4 = p[3], r8 = p[-3 * S], r12 = p[-3];
-                const int lo = v - T, hi = v + T;
-                const bool dark = (r0 < lo) + (r4 < lo) + (r8 < lo) + (r12 < lo) >= 2;
-                const bool both = dark && (r0 > hi) + (r4 > hi) + (r8 > hi) + (r12 > hi) >= 2;
+                // "two compass points darker than v - T" <=> the SECOND SMALLEST of the four is; "two brighter than v + T" <=> the second largest is
+                // (six min / max for both, no compare-and-count chains)
+                const int m1 = min(r0, r4), M1 = max(r0, r4), m2 = min(r8, r12), M2 = max(r8, r12);
+                const int second_lo = min(max(m1, m2), min(M1, M2)), second_hi = max(min(M1, M2), max(m1, m2));
+                const bool dark = second_lo < v - T;
+                const bool both = dark && second_hi > v + T;
                 auto side = [&](const int sg) -> int {
                     const int sv = sg * v, ng = -sg;
                     int d[16];
@@ -206,12 +216,15 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
                     return max(max(max(a9[0], a9[3]), a9[6]), max(max(a9[9], a9[12]), a9[15]));
                 };
                 int sc = side(dark ? 1 : -1) - 1;
-                if (__any(both)) { if (both) sc = max(sc, side(-1) - 1); }
+                // the other polarity only where the first one did not make the pixel a corner (a pixel is a corner in at most one polarity: 9 + 9 > 16)
+                const bool again = both && sc < T;
+                if (__any(again)) { if (again) sc = side(-1) - 1; }
                 corner = sc >= T;
-                if (corner) score[(sy + 1) * SD_FS_SW + sx + 1] = (uint8_t)sc;
+                if (corner) {
+                    score[(sy + 1) * SD_FS_SW + sx + 1] = (uint8_t)sc;
+                    list2[sd_lds_add_rtn(&s_cnt2, 1)] = ent;       // one LDS atomic per corner (see phase 1)
+                }
             }
-            const int slot = sd_wave_append(corner, &s_cnt2);
-            if (corner) list2[slot] = ent;
         }
         __syncthreads();
         // ---- phase 3: 3x3 strict-maximum NMS over the corner list (zero frame = outside the scanned area); survivors go to a
@@ -229,10 +242,8 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 ok = s > q[-SD_FS_SW - 1] && s > q[-SD_FS_SW] && s > q[-SD_FS_SW + 1] && s > q[-1] && s > q[1] &&
                      s > q[SD_FS_SW - 1] && s > q[SD_FS_SW] && s > q[SD_FS_SW + 1];
                 key = ((unsigned)ent << 8) | (unsigned)s;
-                if (ok) atomicOr(&rowAll[sy], 1ull << sx);
+                if (ok) { atomicOr(&rowAll[sy], 1ull << sx); kept[sd_lds_add_rtn(&s_cnt3, 1)] = key; }
             }
-            const int slot = sd_wave_append(ok, &s_cnt3);
-            if (ok) kept[slot] = key;
         }
         __syncthreads();
         n3 = s_cnt3;

@@ -385,6 +385,11 @@ def test_time_batched_prefetch_equals_sequential(gpu, fe, orc, synth, kind):
             pending.append(bi)
         nxt = 2
         for t in range(T):
+            if t in (1, 4):
+                # a call that fails on its arguments (more than SD_MAX_BOXES boxes) must leave the pool of prefetched frames -- and the lanes -- as they
+                # were: the frame it would have consumed is still the next one (mid-block at t = 1, a block's first frame at t = 4)
+                with pytest.raises(fe.SdError):
+                    trk.track(0, W * ch, W * H * ch, [stamp(t)] * S, boxes=np.zeros((S, fe.MAXB, 4)), n_boxes=np.full(S, fe.MAXB + 1, np.int32))
             res = trk.track(0, W * ch, W * H * ch, [stamp(t)] * S, boxes=boxes[t])
             for l in range(S):
                 F = oracles[l].track(frames[t][l][0], frames[t][l][1], boxes[t][l], stamp(t))
