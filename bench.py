@@ -1012,7 +1012,9 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline, vocab=None):
     # they run 5 x as many steps behind 3 warm-up steps
     steps, warm = (args.steps, args.warmup) if headline else ((args.extra_steps, 1) if name.startswith("stereo-yolo") else (5 * args.extra_steps, 3))
     prof_steps = 4 if (not args.no_profile and (headline or name in ("stereo", "rgbd-bow", "stereo-yolo-f32w", "stereo-yolo-f32x3"))) else 0
-    wl.prepare(1 + warm + steps + prof_steps + 1)
+    # every timed step enqueues ONE detector pass `depth` frames ahead: the run needs that many frames beyond the last timed / profiled step, or the
+    # last timed steps would find nothing left to enqueue and the timed region would hold fewer passes than steps
+    wl.prepare(1 + warm + steps + prof_steps + max(1, getattr(wl, "depth", 1)))
     batch = wl.batch
     cap = batch.cap
     gatherer, rec_parts, layout = make_gatherer(wl, fe, dist, world, rank, dev)

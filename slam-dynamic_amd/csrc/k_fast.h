@@ -256,9 +256,15 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         const unsigned long long* rows = rowAll;
         if (tid >= 64 && tid - lane >= n3) return;     // a wave without a survivor of its own has nothing to emit (wave 0 writes the count; n3 <= 64 almost always)
         const int rowPop = lane < SD_FS_ROWS ? __popcll(rows[lane]) : 0;
+        // inclusive wave scan on the DPP network (row_shr 1, 2, 4, 8, then lane 15 / 31 of the rows below broadcast): six vector instructions
+        // where six __shfl_up steps were thirty (a bpermute through the LDS unit, a compare and a select each)
         int incl = rowPop;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);
         const int excl = incl - rowPop;
         uint32_t* out = cellList + (size_t)img * A.cellListCap + c.listOffset;
         for (int i0 = 0; i0 < n3; i0 += NT) {
