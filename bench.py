@@ -531,11 +531,14 @@ class Workload:
             # (a high-priority detector stream -- torch.cuda.Stream(priority=-1) -- was measured: 1,042.4 / 1,042.9 frames/s against 1,041.5 / 1,042.5: no effect)
             self.det_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_det)]
             self.det_stream = self.det_streams[0]
-            # Overlap mode (f32-class modes): a pass's blobFromImage and region decodes run on the detector's internal streams, NMS + download on a
-            # stream of their own, and TWO passes are kept enqueued ahead of the frame being tracked -- the convolutions of pass t + 1 start the
-            # moment pass t's last convolution ends, while t's decode / NMS / download and the host's turn-around run beside them.
+            # Overlap mode (sd_yolo_set_overlap; SD_BENCH_DET_OVERLAP=1): a pass's blobFromImage and region decodes on the detector's internal streams, NMS +
+            # download on a stream of their own, TWO passes kept enqueued ahead of the frame being tracked, so that the convolutions of pass t + 1 start the
+            # moment pass t's last convolution ends.  MEASURED on one box, back to back (round 4, 12 and 20 timed steps): one stream / one pass ahead
+            # 1,067.6 and 1,066.2 frames/s, overlap 1,060.4 and 1,057.6 -- the small kernels (3 ms per 256-image pass) cost the convolutions more when they
+            # share the CUs with them than when they wait their turn (every layer is a dependent launch that ends with its slowest workgroup, and a
+            # latency-bound kernel camps on a few CUs for its whole 0.4 - 0.9 ms).  So the default stays the single stream; the mode stays tested and switchable.
             self.box_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_det)]
-            self.overlap = self.det_prec != "f16" and os.environ.get("SD_BENCH_DET_OVERLAP", "1") != "0"      # developer switch: "0" = one stream, one pass ahead (A/B runs)
+            self.overlap = self.det_prec != "f16" and os.environ.get("SD_BENCH_DET_OVERLAP", "0") == "1"
             self.depth = 2 if self.overlap else 1
             if self.overlap:
                 for d_ in self.dets:
@@ -1309,7 +1312,7 @@ def main():
                          "scaling": "strong" if w == "kitti-batch" else "weak",
                          "workload": WORKLOAD_TEXT[w] % args.kitti_frames if w == "kitti-batch" else WORKLOAD_TEXT[w], "lane0_last_frame": o["lane0_last_frame"]}
             for k in ("roofline", "frames", "frames_per_block_per_lane", "frames_in_one_extraction_batch", "blocks", "distinct_frames_generated_per_sequence",
-                      "max_detector_boxes_in_a_frame"):
+                      "max_detector_boxes_in_a_frame", "record_bytes_per_frame"):
                 if k in o:
                     extras[w][k] = o[k]
 

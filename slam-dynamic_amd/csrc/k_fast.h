@@ -47,6 +47,21 @@ __device__ __forceinline__ int sd_lds_add_rtn(int* counter, int v)
     return old;
 }
 
+// How the three lists are appended to -- measured on one box, k_fast_cells_staged per 512 images (tools/fast_append_ab.sh, two rounds each):
+//   round 3: four bit-plane ballots + mbcnt in phase 1, sd_wave_append (ballot, ffs, shuffle) in phases 2 / 3                      1.50 ms
+//   one LDS atomic per LANE everywhere (sd_lds_add_rtn)                                                                            1.33 / 1.38
+//   phase 1 one atomic per 16-lane ROW (DPP row scan + bpermute), phases 2 / 3 per lane                                            1.31 / 1.34
+//   phase 1 per row, phases 2 / 3 atomicAdd(p, 1) = the compiler's wave-aggregated form (ballot + mbcnt around one atomic)         1.28 / 1.24
+//   phase 1 per LANE, phases 2 / 3 atomicAdd(p, 1)                                                                     <- kept     1.25 / 1.25
+// Phase 1's count differs per lane (0 .. 4 candidates), where the wave-level forms need a scan; phases 2 / 3 add 1, where the compiler's form is a
+// ballot and two mbcnt -- and ~28 lanes of a wave hitting one LDS address cost more than that.
+#ifndef SD_FAST_APPEND
+#define SD_FAST_APPEND 0                       // 0: one atomic per lane in phase 1; 1: one per 16-lane row
+#endif
+#ifndef SD_FAST_ADD1
+#define SD_FAST_ADD1(p) atomicAdd((p), 1)      // or sd_lds_add_rtn((p), 1): one atomic per lane
+#endif
+
 // Per-cell descriptor of the staged kernel: everything the window fetch needs in ONE scalar load (the generic SdCell needs the
 // level table behind it, a second dependent load before the first pixel can be requested).
 struct SdFastCell {
@@ -163,9 +178,25 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
             }
             // Slot reservation: ONE LDS atomic per lane that holds candidates (sd_lds_add_rtn; list order is free).  The wave-level form (four
             // bit-plane ballots + mbcnt + the per-plane offsets) was ~45 vector instructions per iteration, more than the compass test itself.
+#if SD_FAST_APPEND == 1
+            // experiment: candidates counted per 16-lane row on the DPP network, one atomic per row (four per wave) instead of one per lane
+            const int cnt = __popc(pmask);
+            int inc = cnt;
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);
+            int rowBase = 0;
+            if ((lane & 15) == 15 && inc) rowBase = sd_lds_add_rtn(&s_cnt1, inc);
+            rowBase = __shfl(rowBase, lane | 15, 64);
+            if (pmask) {
+                int pos = rowBase + inc - cnt;
+                const unsigned short e0 = (unsigned short)((sy << 8) | (4 * gq));
+#else
             if (pmask) {
                 int pos = sd_lds_add_rtn(&s_cnt1, __popc(pmask));
                 const unsigned short e0 = (unsigned short)((sy << 8) | (4 * gq));
+#endif
                 if (pmask & 0x80u) list1[pos++] = e0;
                 if (pmask & 0x8000u) list1[pos++] = e0 + 1;
                 if (pmask & 0x800000u) list1[pos++] = e0 + 2;
@@ -222,7 +253,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 corner = sc >= T;
                 if (corner) {
                     score[(sy + 1) * SD_FS_SW + sx + 1] = (uint8_t)sc;
-                    list2[sd_lds_add_rtn(&s_cnt2, 1)] = ent;       // one LDS atomic per corner (see phase 1)
+                    list2[SD_FAST_ADD1(&s_cnt2)] = ent;       // one LDS atomic per corner (see phase 1)
                 }
             }
         }
@@ -242,7 +273,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 ok = s > q[-SD_FS_SW - 1] && s > q[-SD_FS_SW] && s > q[-SD_FS_SW + 1] && s > q[-1] && s > q[1] &&
                      s > q[SD_FS_SW - 1] && s > q[SD_FS_SW] && s > q[SD_FS_SW + 1];
                 key = ((unsigned)ent << 8) | (unsigned)s;
-                if (ok) { atomicOr(&rowAll[sy], 1ull << sx); kept[sd_lds_add_rtn(&s_cnt3, 1)] = key; }
+                if (ok) { atomicOr(&rowAll[sy], 1ull << sx); kept[SD_FAST_ADD1(&s_cnt3)] = key; }
             }
         }
         __syncthreads();
