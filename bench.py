@@ -679,6 +679,18 @@ def block_plan(T, S, block_frames, resident):
     return D, [(t0, min(D, T - t0), [pingpong_index(t, P) for t in range(t0, min(t0 + D, T))]) for t0 in range(0, T, D)]
 
 
+def block_schedule(T, D):
+    """Frames per time block of a T-frame job whose full blocks hold D frames: D / 8, D / 4, D / 2, D, ..., D, [rest], D / 2, D / 4, D / 8.
+    Nothing overlaps the FIRST block's detector pass (the pipeline fills) or the LAST block's recurrence (it drains): with plain blocks of D that is
+    a full block of each -- at 8 ranks (D = 94, three blocks) a third of the job.  The ramps make both ends an eighth of a block; every block's
+    recurrence (n frames x ~0.4 ms) still hides behind the next block's detector pass (half the frames x ~0.9 ms x sequences / ranks)."""
+    ramp = sorted({max(1, D // 8), max(1, D // 4), max(1, D // 2)} - {D})
+    if 2 * sum(ramp) + D > T:
+        return [min(D, T - t0) for t0 in range(0, T, D)]
+    mid = T - 2 * sum(ramp)
+    return ramp + [D] * (mid // D) + ([mid % D] if mid % D else []) + ramp[::-1]
+
+
 def frame_shard_plan(n_seq, T, world, block_frames, resident=24):
     """BASELINE configs[4] with FRAMES -- not sequences -- sharded over the ranks (north star: "independent frames shard across the 8 GPUs").
 
@@ -687,7 +699,8 @@ def frame_shard_plan(n_seq, T, world, block_frames, resident=24):
     the rank that owns the sequence.  Time is cut into blocks of D consecutive frames of every sequence; the n_seq * n frames ("units") of a
     block, in sequence-major order u = q * n + k, are cut into `world` contiguous pieces of equal size (+- 1, the pieces rotated over the ranks
     from block to block); each rank runs the history-free half of its piece in one batch and the units' records go to the owners in ONE
-    all-to-all per block.  D is chosen so that a rank's piece holds about `block_frames` units.
+    all-to-all per block.  D is chosen so that a rank's piece of a full block holds about `block_frames` units; the first and last blocks are shorter
+    (block_schedule).
 
     -> dict(owner, lanes (per rank: the sequences of its tracker lanes, padded by repetition to S), S, D, blocks); a block = dict(t0, n, idx
     (resident frame index per k), units [(q, k)], piece [(lo, hi) per rank])."""
@@ -700,12 +713,13 @@ def frame_shard_plan(n_seq, T, world, block_frames, resident=24):
     D = max(1, min(T, -(-block_frames * world // n_seq)))
     P = min(resident, T)
     blocks = []
-    for bi, t0 in enumerate(range(0, T, D)):
-        n = min(D, T - t0)
+    t0 = 0
+    for bi, n in enumerate(block_schedule(T, D)):
         U = n_seq * n
         bounds = [(U * j) // world for j in range(world + 1)]
         piece = [(bounds[(r + bi) % world], bounds[(r + bi) % world + 1]) for r in range(world)]
         blocks.append(dict(t0=t0, n=n, idx=[pingpong_index(t, P) for t in range(t0, t0 + n)], units=[(q, k) for q in range(n_seq) for k in range(n)], piece=piece))
+        t0 += n
     return dict(owner=owner, lanes=lanes, S=S, D=D, blocks=blocks, n_seq=n_seq, T=T, world=world)
 
 

@@ -74,11 +74,11 @@ def _run_ranks(argv, timeout=900):
 
 def test_kitti_batch_as_benched_f32_detector(gpu):
     """BASELINE configs[4] exactly as bench.py times it at N = 1 (bench.SequenceBatchWorkload.run; /root/reference Examples/Stereo/stereo_kitti.cc:81-155):
-    two 3-channel stereo sequences x 7 frames, the f32 detector over blocks of D = 3 frames per sequence, the history-free half through
-    sd_tracker_prefetch -> export -> import, boxes handed over behind the records, three blocks (3 + 3 + 1 frames: the second outstanding block is
-    consumed while the third is in flight).  Every frame of every lane == torch-fp32 boxes -> SequenceOracle."""
+    two 3-channel stereo sequences x 7 frames, the f32 detector over blocks of up to D = 3 frames per sequence, the history-free half through
+    sd_tracker_prefetch -> export -> import, boxes handed over behind the records, four blocks (1 + 3 + 2 + 1 frames, bench.block_schedule: an
+    outstanding block is consumed while the next is in flight).  Every frame of every lane == torch-fp32 boxes -> SequenceOracle."""
     ok = _run_ranks(["--gpus", "1", "--sequences", "2", "--frames", "7", "--block-frames", "6"])
-    assert len(ok) == 1 and "blocks 3 D 3" in ok[0] and "frames 14" in ok[0], ok
+    assert len(ok) == 1 and "blocks 4 D 3" in ok[0] and "frames 14" in ok[0], ok
 
 
 def test_kitti_batch_frames_sharded_over_two_ranks(gpu):
