@@ -738,6 +738,19 @@ __global__ void __launch_bounds__(256) k_region_decode(const T* __restrict__ hea
         }
         if (lane == src) { best = m; bc = m > 0.f ? mc : 0; }
     }
+    // Slots of the surviving rows: counted per WORKGROUP in LDS (its 256 consecutive rows belong to two images, or to a few more of a very small
+    // network: at most 256 / 3 + 2), then ONE global atomic per image and workgroup.  One atomic per row -- a thousand of them on one image's counter with the synthetic heads, every one a round trip to L2
+    // behind the others -- was what a launch waited for (0.86 ms for the 80 x 60 head of a 256-image batch).  The list's order is free (k_yolo_nms sorts).
+    __shared__ int s_cnt[128], s_base[128];
+    if (threadIdx.x < 128) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int n0 = (int)(((size_t)blockIdx.x * 256) / (size_t)perImg);
+    const bool keep = want && best > confThreshold;
+    int local = 0;
+    if (keep) local = atomicAdd(&s_cnt[n - n0], 1);
+    __syncthreads();
+    if (threadIdx.x < 128 && s_cnt[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(&ndet[n0 + threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
     if (!want) return;
     const float aw = a == 0 ? aw0 : a == 1 ? aw1 : aw2, ah = a == 0 ? ah0 : a == 1 ? ah1 : ah2;
     const float cx = (sig((float)t[0]) + (float)x) / (float)gw;
@@ -748,8 +761,8 @@ __global__ void __launch_bounds__(256) k_region_decode(const T* __restrict__ hea
         float* o = rawOut + (size_t)(rowBase + r) * 85;
         o[0] = cx; o[1] = cy; o[2] = bw; o[3] = bh; o[4] = obj;
     }
-    if (best > confThreshold) {
-        const int slot = atomicAdd(&ndet[n], 1);
+    if (keep) {
+        const int slot = s_base[n - n0] + local;
         if (slot < detCap) {
             SdDet d; d.row = rowBase + r; d.cls = bc; d.conf = best; d.cx = cx; d.cy = cy; d.w = bw; d.h = bh;
             dets[(size_t)n * detCap + slot] = d;
