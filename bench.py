@@ -48,7 +48,7 @@ import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming)
 MFMA_PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "f32w": 157.3, "f32x3": 2500.0}   # dense peaks, MI355X_MICROARCH.md
-AUTO_EXTRAS = ("stereo-yolo-f32x3", "stereo", "rgbd", "tum-mask", "kitti-batch")
+AUTO_EXTRAS = ("stereo-yolo-f32x3", "stereo-yolo-f32w", "stereo", "rgbd", "tum-mask", "kitti-batch")
 WORKLOADS = ["stereo-yolo", "stereo-yolo-f32w", "stereo-yolo-f32x3", "stereo-yolo-f16", "stereo", "rgbd", "rgbd-cull", "rgbd-bow", "tum-mask", "kitti-batch"]
 
 
@@ -278,7 +278,7 @@ def compact_line(full, detail_path=None):
         out["cpu_baseline"] = None
     out["extra"] = {k: (v.get("value") if isinstance(v, dict) and "value" in v else {"error": _clip(v.get("error", "?"), 80)} if isinstance(v, dict) else v)
                     for k, v in (full.get("extra") or {}).items()}
-    for k in ("value_f32x3", "dtype_f32x3", "gathered_record_check", "vocabulary_broadcast_ms"):
+    for k in ("value_f32x3", "dtype_f32x3", "value_f32w", "dtype_f32w", "gathered_record_check", "vocabulary_broadcast_ms"):
         if full.get(k) is not None:
             out[k] = full[k]
     if detail_path:
@@ -1303,7 +1303,7 @@ def main():
     names = []
     if args.extra == "auto":
         # the other BASELINE configs (configs[1] rgbd, configs[3] tum-mask, configs[4] kitti-batch), the detector-less stereo front end (the HBM-side
-        # kernel table) and the f32x3 detector chain (value_f32x3); every other workload only on request (--extra a,b,c)
+        # kernel table) and the two other f32-class detector chains (value_f32x3, value_f32w); every other workload only on request (--extra a,b,c)
         names = [w for w in AUTO_EXTRAS if w != args.workload] if world == 1 else []
     elif args.extra != "none":
         names = [w for w in args.extra.split(",") if w]
@@ -1371,6 +1371,11 @@ def main():
             # to a float64 forward): a second figure beside `value`, which stays the direct f32 sums
             out["value_f32x3"] = x3["value"]
             out["dtype_f32x3"] = "u8+f32 operands as 3xbf16 limbs, f32 accumulate"
+        xw = extras.get("stereo-yolo-f32w")
+        if args.workload == "stereo-yolo" and xw and "value" in xw:
+            # ... and with the 3 x 3 stride-1 layers as Winograd F(2x2, 3x3) in f32: the mode CLOSEST to a float64 forward of the three (same test)
+            out["value_f32w"] = xw["value"]
+            out["dtype_f32w"] = "u8+f32, Winograd F(2x2,3x3) on the 3x3 stride-1 layers"
         detail = write_detail(out, args.detail)
         print(compact_line(out, detail))
         sys.stdout.flush()

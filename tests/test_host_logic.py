@@ -278,7 +278,7 @@ def test_bench_line_is_compact_and_complete(tmp_path):
 
 
 def test_bench_auto_extras_are_the_baseline_configs():
-    assert set(("rgbd", "tum-mask", "kitti-batch")) <= set(bench.AUTO_EXTRAS) and len(bench.AUTO_EXTRAS) <= 5
+    assert set(("rgbd", "tum-mask", "kitti-batch")) <= set(bench.AUTO_EXTRAS) and len(bench.AUTO_EXTRAS) <= 6
     assert all(w in bench.WORKLOADS for w in bench.AUTO_EXTRAS)
 
 
