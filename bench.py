@@ -819,6 +819,8 @@ class SequenceBatchWorkload:
         self.pool = [torch.zeros((self.D * self.S, self.RB), dtype=torch.uint8, device=dev) for _ in range(2)]
         self.host_tail = [torch.zeros((self.D * self.S, self.BOX_BYTES), dtype=torch.uint8).pin_memory() for _ in range(2)]
         self.ready = [torch.cuda.Event() for _ in range(2)]
+        self.ev_det = [torch.cuda.Event() for _ in range(2)]
+        self.ev_pre = [torch.cuda.Event() for _ in range(2)]
         self.blocks = []
 
     def prepare(self):
@@ -876,10 +878,11 @@ class SequenceBatchWorkload:
             self.worker.prefetch(B["images"].data_ptr(), W * 3, W * H * 3, U, stream=ps)      # one lane: U consecutive "frames"
             self.worker.export_prefetched(0, U, rec.data_ptr(), record_stride=self.RB, stream=ps)
             self.worker.discard_prefetched()
-        with torch.cuda.stream(self.xchg_stream):
-            self.xchg_stream.wait_stream(self.det_stream)
-            self.xchg_stream.wait_stream(self.pre_stream)
-            B["send"] = rec[:U] if B["send_perm"] is None else rec[:U].index_select(0, B["send_perm"])      # rows grouped by destination rank
+        # The exchange stream must NOT wait here: a wait queued now would hold everything queued behind it -- the hand-over of the PREVIOUS block, which is
+        # consumed after this call -- until THIS block's detector pass has finished, and the detector would then idle through that block's recurrence
+        # (a 13 ms hole per block in the first version's trace, 10 % of the run).  The block's events are waited for when it is consumed.
+        self.ev_det[k].record(self.det_stream)
+        self.ev_pre[k].record(self.pre_stream)
 
     def _to_pool(self, bi):
         """Owner side, on the exchange stream: the received rows in pool order (frame-major over this rank's lanes), their box tails to the host."""
@@ -897,7 +900,12 @@ class SequenceBatchWorkload:
         torch = self.torch
         B, k = self.blocks[bi], bi & 1
         v = B["view"]
+        U = len(v["mine"])
         with torch.cuda.stream(self.xchg_stream):
+            self.xchg_stream.wait_event(self.ev_det[k])
+            self.xchg_stream.wait_event(self.ev_pre[k])
+            rec = self.rec[k]
+            B["send"] = rec[:U] if B["send_perm"] is None else rec[:U].index_select(0, B["send_perm"])      # rows grouped by destination rank
             B["rows"], work = exchange_rows(self.dist, self.world, B["send"], v["send_splits"], v["recv_splits"])
             if work is not None:
                 work.wait()
