@@ -680,15 +680,23 @@ def block_plan(T, S, block_frames, resident):
 
 
 def block_schedule(T, D):
-    """Frames per time block of a T-frame job whose full blocks hold D frames: D / 8, D / 4, D / 2, D, ..., D, [rest], D / 2, D / 4, D / 8.
+    """Frames per time block of a T-frame job whose full blocks hold about D frames: D / 8, D / 4, D / 2, D, ..., D, D / 2, D / 4, D / 8.
     Nothing overlaps the FIRST block's detector pass (the pipeline fills) or the LAST block's recurrence (it drains): with plain blocks of D that is
     a full block of each -- at 8 ranks (D = 94, three blocks) a third of the job.  The ramps make both ends an eighth of a block; every block's
-    recurrence (n frames x ~0.4 ms) still hides behind the next block's detector pass (half the frames x ~0.9 ms x sequences / ranks)."""
-    ramp = sorted({max(1, D // 8), max(1, D // 4), max(1, D // 2)} - {D})
+    recurrence (n frames x ~1 ms) still hides behind the next block's detector pass (>= half the frames x ~0.9 ms x sequences / ranks).  A job too
+    short for the ramps of D gets smaller blocks (D halved until they fit); the frames between the ramps are cut into equal blocks of at most D."""
+    D = max(1, min(D, T))
+    while True:
+        ramp = sorted({max(1, D // 8), max(1, D // 4), max(1, D // 2)} - {D})
+        if 2 * sum(ramp) + D <= T or D == 1:
+            break
+        D = max(1, D // 2)
     if 2 * sum(ramp) + D > T:
-        return [min(D, T - t0) for t0 in range(0, T, D)]
+        ramp = []
     mid = T - 2 * sum(ramp)
-    return ramp + [D] * (mid // D) + ([mid % D] if mid % D else []) + ramp[::-1]
+    m = -(-mid // D)
+    base, extra = divmod(mid, m)
+    return ramp + [base + 1] * extra + [base] * (m - extra) + ramp[::-1]
 
 
 def frame_shard_plan(n_seq, T, world, block_frames, resident=24):
@@ -720,7 +728,7 @@ def frame_shard_plan(n_seq, T, world, block_frames, resident=24):
         piece = [(bounds[(r + bi) % world], bounds[(r + bi) % world + 1]) for r in range(world)]
         blocks.append(dict(t0=t0, n=n, idx=[pingpong_index(t, P) for t in range(t0, t0 + n)], units=[(q, k) for q in range(n_seq) for k in range(n)], piece=piece))
         t0 += n
-    return dict(owner=owner, lanes=lanes, S=S, D=D, blocks=blocks, n_seq=n_seq, T=T, world=world)
+    return dict(owner=owner, lanes=lanes, S=S, D=max(B["n"] for B in blocks), blocks=blocks, n_seq=n_seq, T=T, world=world)
 
 
 def frame_shard_rank_view(plan, block, rank):

@@ -323,9 +323,9 @@ def test_frame_shard_plan_balances_frames_and_delivers_every_frame_to_its_owner(
         assert sum(computed) == 11 * 256
         mean = sum(computed) / world
         assert max(computed) / mean - 1 <= 0.05, (world, computed)                             # history-free load imbalance <= 5 %
-        full = [B for B in plan["blocks"] if B["n"] == plan["D"]]
+        full = [B for B in plan["blocks"] if B["n"] >= plan["D"] - 1]
         per_block = [len(bench.frame_shard_rank_view(plan, B, r)["mine"]) for B in full for r in range(world)]
-        assert full and min(per_block) >= 120                                                  # a full block's detector batch is about --block-frames images
+        assert full and min(per_block) >= 110                                                  # a full block's detector batch is about --block-frames images
         sizes = [B["n"] for B in plan["blocks"]]
         assert sum(sizes) == 256 and sizes[0] <= max(1, plan["D"] // 8) and sizes[-1] <= max(1, plan["D"] // 8)      # short first / last blocks: fill and drain
         owned = sorted(q for r in range(world) for q in set(plan["lanes"][r]))
@@ -338,7 +338,8 @@ def test_frame_shard_plan_balances_frames_and_delivers_every_frame_to_its_owner(
     small = bench.frame_shard_plan(11, 7, 2, 16, 24)                                           # a short job: ramp, one full block, a ragged one, ramp
     assert small["D"] == 3 and [B["n"] for B in small["blocks"]] == [1, 3, 2, 1]
     _simulate_frame_shard(small)
-    assert bench.block_schedule(256, 94) == [11, 23, 47, 94, 47, 23, 11] and bench.block_schedule(20, 12) == [12, 8]
+    assert bench.block_schedule(256, 94) == [11, 23, 47, 94, 47, 23, 11] and bench.block_schedule(20, 12) == [1, 3, 6, 6, 3, 1]
+    assert bench.block_schedule(256, 187) == [11, 23, 46, 48, 48, 46, 23, 11]                  # blocks too long for the job: halved until the ramps fit
     assert all(sum(bench.block_schedule(T, D)) == T for T in (1, 5, 7, 64, 256, 1000) for D in (1, 2, 3, 12, 47, 94, 300))
     with pytest.raises(ValueError):
         bench.frame_shard_plan(11, 256, 12, 128)
