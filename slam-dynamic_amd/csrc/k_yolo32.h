@@ -311,11 +311,27 @@ __global__ void __launch_bounds__(256) k_blob_from_image_f32(const uint8_t* __re
     const int r0 = min(max((int)re.x, 0), sh - 1), r1 = min(max((int)re.x + 1, 0), sh - 1);
     const uint8_t* S0 = src + (size_t)img * spitch + (size_t)r0 * sstride;
     const uint8_t* S1 = src + (size_t)img * spitch + (size_t)r1 * sstride;
+    // the two source pixels of a row are six consecutive bytes: one unaligned dword + one unaligned halfword per row instead of six byte loads (the
+    // kernel was bound by the issue of its twelve byte loads per output pixel, not by its 16-byte store); the last source column repeats itself
+    // (sx1 == sx) and takes the byte path, which never reads past its pixel
+    uint32_t a0, a1, b0, b1;                                    // bytes 0-3 and 4-5 of the pair, rows r0 / r1
+    if (sx1 == sx + 1) {
+        typedef uint32_t __attribute__((aligned(1))) u32u; typedef uint16_t __attribute__((aligned(1))) u16u;
+        a0 = *(const u32u*)(S0 + 3 * sx); b0 = *(const u16u*)(S0 + 3 * sx + 4);
+        a1 = *(const u32u*)(S1 + 3 * sx); b1 = *(const u16u*)(S1 + 3 * sx + 4);
+    } else {
+        a0 = (uint32_t)S0[3 * sx] | ((uint32_t)S0[3 * sx + 1] << 8) | ((uint32_t)S0[3 * sx + 2] << 16) | ((uint32_t)S0[3 * sx1] << 24);
+        b0 = (uint32_t)S0[3 * sx1 + 1] | ((uint32_t)S0[3 * sx1 + 2] << 8);
+        a1 = (uint32_t)S1[3 * sx] | ((uint32_t)S1[3 * sx + 1] << 8) | ((uint32_t)S1[3 * sx + 2] << 16) | ((uint32_t)S1[3 * sx1] << 24);
+        b1 = (uint32_t)S1[3 * sx1 + 1] | ((uint32_t)S1[3 * sx1 + 2] << 8);
+    }
+    const int p0[6] = {(int)(a0 & 255), (int)((a0 >> 8) & 255), (int)((a0 >> 16) & 255), (int)(a0 >> 24), (int)(b0 & 255), (int)((b0 >> 8) & 255)};
+    const int p1[6] = {(int)(a1 & 255), (int)((a1 >> 8) & 255), (int)((a1 >> 16) & 255), (int)(a1 >> 24), (int)(b1 & 255), (int)((b1 >> 8) & 255)};
     float ch[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        const int h0 = S0[3 * sx + c] * ce.y + S0[3 * sx1 + c] * ce.z;
-        const int h1 = S1[3 * sx + c] * ce.y + S1[3 * sx1 + c] * ce.z;
+        const int h0 = p0[c] * ce.y + p0[3 + c] * ce.z;
+        const int h1 = p1[c] * ce.y + p1[3 + c] * ce.z;
         const int v = ((((int)re.y * (h0 >> 4)) >> 16) + (((int)re.z * (h1 >> 4)) >> 16) + 2) >> 2;
         ch[c] = (float)(v & 255) * (float)(1 / 255.0);
     }
