@@ -536,7 +536,7 @@ HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_b3c<5>, hipFuncAttributeMaxDyn
                     hipLaunchKernelGGL(k_conv_b3<1>, dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(256), SD_B3_LDS(1), s, A, (const uint4*)(y->d_wgtB + r.wOffB));
                 } else
                 hipLaunchKernelGGL(k_conv_b3<2>, dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(256), SD_B3_LDS(2), s, A, (const uint4*)(y->d_wgtB + r.wOffB));
-            } else if (i == 0)                         // 3 (-> 8) input channels, <= 32 filters
+            } else if (i == 0)                         // 3 (-> 8) input channels, <= 32 filters (round 4: the same tile on 4 waves, two workgroups per CU: 118.4 vs 118.3 ms per 128-image pass, no change)
                 { A.tilesX = (npix + 511) / 512; A.tilesY = (l.filters + 31) / 32; A.groupY = f32_group_y(A.tilesY, 32, A.cin * l.size * l.size); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<8, 1, 1, 8>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(512), SD_F32_LDS(8, 1, 1, 8), s, A); }
             else if (l.filters <= 32 && small4)
                 { A.tilesX = (npix + 255) / 256; A.tilesY = 1; A.groupY = f32_group_y(A.tilesY, 32, A.cin * l.size * l.size); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_f32<16, 1, 1, 4>), dim3(SD_F32_GRID(A.tilesX, A.tilesY)), dim3(256), SD_F32_LDS(16, 1, 1, 4), s, A); }
