@@ -1368,8 +1368,10 @@ def main():
                        "detector_arithmetic": ("%s operands, f32 accumulation (v_mfma_f32_32x32x%s)" % (wl.det_prec[:3], "16_f16" if wl.det_prec == "f16" else ("16_bf16 on three bf16 limbs per operand" if wl.det_prec == "f32x3" else "2_f32"))
                                                + ("; 3 x 3 stride-1 layers as Winograd F(2x2, 3x3)" if wl.det_prec == "f32w" else "")) if wl.detector else None,
                        "lane0_last_frame": head["lane0_last_frame"],
-                       "sharding": ("independent lanes per rank, no data-path collective; per-step async gather of the result records to rank 0"
-                                    if world > 1 else "single GPU")},
+                       "sharding": ("single GPU" if world == 1 else
+                                    "frames of a time block dealt evenly to all ranks (history-free half), one RCCL all-to-all per block to the sequence owners "
+                                    "(recurrence); per-step async gather of the result records to rank 0" if wl.strong else
+                                    "independent lanes per rank, no data-path collective; per-step async gather of the result records to rank 0")},
             "roofline": head.get("roofline"), "cpu_baseline": cpu, "extra": extras,
         }
         for k in ("max_detector_boxes_in_a_frame", "frames_per_block_per_lane", "frames_in_one_extraction_batch", "blocks",
