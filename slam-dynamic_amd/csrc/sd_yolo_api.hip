@@ -224,6 +224,9 @@ int sd_yolo_set_overlap(sd_yolo* y, int on)
 {
     if (!y) return SD_ERR_INVALID;
     if (on && !y->f32) return set_err(SD_ERR_UNSUPPORTED, "overlap mode exists for the f32-class detector modes");
+    int heads = 0;
+    for (const sd_yolo_layer& l : y->L) heads += l.type == SD_YOLO_YOLO;
+    if (on && heads > 3) return set_err(SD_ERR_UNSUPPORTED, "overlap mode orders at most three [yolo] heads");
     if (on && !y->sPre) {
         HIPCHK(hipStreamCreateWithFlags(&y->sPre, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&y->sPost, hipStreamNonBlocking));
