@@ -181,7 +181,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (WM == 2 && BK == 16 ? 
     // swizzled rows, a ring of three 16 KB stages at three workgroups per CU, counted vmcnt(4) + one barrier per step; results
     // identical) 132.6 against 120.3: slower, not kept.  The weight operand kept out of LDS altogether (each lane fetches its own A
     // fragments from L2 one step ahead, only the activations are staged: half the LDS writes and reads; results identical) 136.0
-    // against 119.7: slower, not kept -- so the ~9 % that vanish with the staging are not the LDS writes as such.  PMC: clock 2.37-2.39 GHz in these kernels (no DVFS give-back), MFMA pipe busy
+    // against 119.7: slower, not kept -- so the ~9 % that vanish with the staging are not the LDS writes as such.  s_setprio 1 / 3 around every MFMA cluster (round 4): 117.7 / 117.6
+    // and 118.0 / 118.0 against 118.1 and 118.0 -- nothing.  PMC: clock 2.37-2.39 GHz in these kernels (no DVFS give-back), MFMA pipe busy
     // 83 % in the 3 x 3 body layers.
     auto step = [&](const int ks, const int par) {     // par = ks & 1, a literal at both call sites
         const int cur = par;
