@@ -1263,6 +1263,11 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
 
+    # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, and two streams on one queue serialise.  A process that has
+    # run several workloads has created dozens of streams (every sd_batch, detector and torch.cuda.Stream owns one), and which of the NEXT workload's
+    # streams then share a queue is luck: kitti-batch after the headline ran 8 % slower than alone (957 against 1,042 frames/s on one box) because its detector
+    # stream and its extraction / recurrence streams had landed on one queue; with 8 queues 998, with 16 1,049.  Set before the runtime initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
     if os.environ.get("SD_BENCH_SINGLE_DEVICE"):     # rehearsal only: several ranks share cuda:0 (gloo backend)
         local_rank = 0
