@@ -536,7 +536,9 @@ class Workload:
             # moment pass t's last convolution ends.  MEASURED on one box, back to back (round 4, 12 and 20 timed steps): one stream / one pass ahead
             # 1,067.6 and 1,066.2 frames/s, overlap 1,060.4 and 1,057.6 -- the small kernels (3 ms per 256-image pass) cost the convolutions more when they
             # share the CUs with them than when they wait their turn (every layer is a dependent launch that ends with its slowest workgroup, and a
-            # latency-bound kernel camps on a few CUs for its whole 0.4 - 0.9 ms).  So the default stays the single stream; the mode stays tested and switchable.
+            # latency-bound kernel camps on a few CUs for its whole 0.4 - 0.9 ms).  Part of that loss was stream aliasing (4 hardware queues; see
+            # GPU_MAX_HW_QUEUES in main()): with 16 queues, same box, 20 timed steps, off 1,068.7 / 1,067.0, on 1,070.3 / 1,068.9 -- + 0.15 %, inside the
+            # noise.  So the default stays the single stream; the mode stays tested and switchable.
             self.box_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_det)]
             self.overlap = self.det_prec != "f16" and os.environ.get("SD_BENCH_DET_OVERLAP", "0") == "1"
             self.depth = 2 if self.overlap else 1
