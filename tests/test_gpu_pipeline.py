@@ -406,3 +406,83 @@ def test_time_batched_prefetch_equals_sequential(gpu, fe, orc, synth, kind):
     finally:
         trk.close()
     assert flags >= 4, "TrackHomo must have run on the later frames"
+
+
+@pytest.mark.parametrize("kind", ["stereo", "rgbd-tum1"])
+def test_export_import_prefetched_between_trackers(gpu, fe, orc, synth, kind):
+    """Frames sharded over GPUs (BASELINE configs[4]): the history-free half of a frame runs in a WORKER tracker (sd_tracker_prefetch), leaves it as
+    fixed-stride records (sd_tracker_export_prefetched, here in two pieces with first_frame > 0 and a stride wider than the record: the caller's own
+    bytes behind every record must survive), and enters the OWNER tracker as a prefetched block (sd_tracker_import_prefetched) whose frames
+    sd_tracker_track(d_images = NULL) consumes.  Two lanes, blocks of 3, 4 and 3 frames, two blocks outstanding in the owner; a distorted RGB-D camera
+    (TUM1: the record then carries mvKeysUn too) and a stereo one.  EVERY frame equals the sequential frame-level oracle bit for bit."""
+    import torch
+    P = _pipe()
+    stereo = kind == "stereo"
+    cfg = synth.KITTI_STEREO if stereo else synth.TUM1
+    sensor = fe.SENSOR_STEREO if stereo else fe.SENSOR_RGBD
+    ch = 1 if stereo else 3
+    W, H = cfg["width"], cfg["height"]
+    S, blocks = 2, [3, 4, 3]
+    T = sum(blocks)
+    seqs = [93, 94]
+    ex = fe.ORBextractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
+    owner = fe.Tracker(ex, cfg, sensor, S, channels=ch, rgb_order=True, track_last=True, lookahead=4)
+    worker = fe.Tracker(ex, cfg, sensor, S, channels=ch, rgb_order=True, track_last=False, lookahead=4)
+    plain = fe.Tracker(ex, cfg, sensor, S, channels=ch, rgb_order=True, track_last=True)
+    oracles = [P.SequenceOracle(orc, cfg, sensor, rgb_order=True, track_last=True) for _ in range(S)]
+    frames = [[(synth.stereo_frame_dyn(q, t, cfg)[:2] if stereo else synth.rgbd_frame_dyn(q, t, cfg)[:2]) for q in seqs] for t in range(T)]
+    boxes = [[synth.rows_to_rects(synth.boxes_for_frame(q, t, cfg)) for q in seqs] for t in range(T)]
+    stamp = lambda t: t / float(cfg["fps"])
+
+    def upload(t0, n):
+        if stereo:
+            return torch.from_numpy(np.stack([np.stack([np.stack(frames[t][l]) for l in range(S)]) for t in range(t0, t0 + n)])).cuda(), None
+        img = torch.from_numpy(np.stack([np.stack([frames[t][l][0] for l in range(S)]) for t in range(t0, t0 + n)])).cuda()
+        dep = torch.from_numpy(np.stack([np.stack([frames[t][l][1] for l in range(S)]) for t in range(t0, t0 + n)]).view(np.int16)).cuda()
+        return img, dep
+
+    try:
+        R = owner.record_bytes()
+        assert R > 0 and R % 16 == 0 and R == worker.record_bytes() and plain.record_bytes() == 0
+        TAIL = 48
+        stride = R + TAIL
+        st = torch.cuda.Stream()
+        starts = np.cumsum([0] + blocks)
+        keep, recs = [], []
+
+        def hand_over(bi):
+            n = blocks[bi]
+            img, dep = upload(starts[bi], n); keep.append((img, dep))
+            worker.prefetch(img.data_ptr(), W * ch, W * H * ch, n, d_depth=dep.data_ptr() if dep is not None else 0, depth_stride=W, depth_pitch=W * H, stream=st.cuda_stream)
+            rec = torch.full((n * S, stride), 0xA5, dtype=torch.uint8, device="cuda"); recs.append(rec)
+            n1 = max(1, n // 2)                               # two pieces: [0, n1) and [n1, n)
+            worker.export_prefetched(0, n1, rec.data_ptr(), record_stride=stride, stream=st.cuda_stream)
+            worker.export_prefetched(n1, n - n1, rec[n1 * S:].data_ptr(), record_stride=stride, stream=st.cuda_stream)
+            worker.discard_prefetched()
+            owner.import_prefetched(rec.data_ptr(), n, record_stride=stride, stream=st.cuda_stream)
+            return rec
+
+        with pytest.raises(fe.SdError):
+            worker.export_prefetched(0, 1, torch.zeros(stride * S, dtype=torch.uint8, device="cuda").data_ptr(), record_stride=stride)      # nothing prefetched
+        with pytest.raises(fe.SdError):
+            owner.import_prefetched(torch.zeros(16, dtype=torch.uint8, device="cuda").data_ptr(), 5, record_stride=stride)                   # more than lookahead
+        with pytest.raises(fe.SdError):
+            owner.import_prefetched(torch.zeros(16, dtype=torch.uint8, device="cuda").data_ptr(), 1, record_stride=R - 16)                  # stride below the record
+        hand_over(0); hand_over(1)                                # two blocks outstanding in the owner before the first frame is tracked
+        nxt, pending, flags = 2, [0, 1], 0
+        for t in range(T):
+            res = owner.track(0, W * ch, W * H * ch, [stamp(t)] * S, boxes=boxes[t])
+            for l in range(S):
+                F = oracles[l].track(frames[t][l][0], frames[t][l][1], boxes[t][l], stamp(t))
+                _check_frame(fe, owner, l, res[l], F, "%s frame %d lane %d" % (kind, t, l))
+                flags += F.track_flag != 0
+            if t + 1 == starts[pending[0] + 1]:
+                pending.pop(0)
+                if nxt < len(blocks):
+                    hand_over(nxt); pending.append(nxt); nxt += 1
+        torch.cuda.synchronize()
+        for rec in recs:                                          # the bytes behind every record are the caller's
+            assert bool((rec[:, R:] == 0xA5).all()), "export wrote past the record"
+        assert flags >= 1, "TrackHomo must have run on the later frames"
+    finally:
+        owner.close(); worker.close(); plain.close()
