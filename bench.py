@@ -746,7 +746,7 @@ def frame_shard_rank_view(plan, block, rank):
     recv_units, recv_splits = [], []
     for src in range(world):
         a, b = piece[src]
-        got = sorted((u for u in units[a:b] if owner[u[0]] == rank), key=lambda u: 0)      # stable: the source's own order
+        got = [u for u in units[a:b] if owner[u[0]] == rank]                                 # in the source's own order
         recv_units += got
         recv_splits.append(len(got))
     pos = {u: i for i, u in enumerate(recv_units)}
