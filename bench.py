@@ -760,7 +760,7 @@ def exchange_rows(dist, world, send, send_splits, recv_splits):
     is tens of MB, the links idle otherwise); gloo (CPU tests, single-GPU rehearsal): the same call on host copies.  -> (rows, work or None)."""
     import torch
     n_recv = int(sum(recv_splits))
-    if dist is None or world == 1:
+    if dist is None or (world == 1 and not os.environ.get("SD_BENCH_FORCE_DIST")):      # FORCE_DIST: the collective itself on a one-rank RCCL group (1-GPU rehearsal)
         return send, None
     out = torch.empty((n_recv,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
     if dist.get_backend() == "nccl":
