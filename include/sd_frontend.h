@@ -286,11 +286,10 @@ int sd_box_track(double* boxes, int n_box, int cap, const double* last_objects, 
  * (mvdynKeys/mdynDescriptors/mvudynRight/mvdynDepth) are index lists into the frame's arrays.
  * boxes: [n_frames][SD_MAX_BOXES][4], box_idx: [n_frames][SD_MAX_BOXES] (boxTrack outputs).  Run after the
  * stereo / RGB-D step (the lookup is per keypoint, so the order relative to the reorder is immaterial).
- * BOUND (this library's, the reference has none -- Frame.cc:555-604 works on std::vectors): the dynamic-object path keeps a frame's
- * key-point masks and a box's descriptors in LDS, 2048 key points per image at most.  An extractor whose nFeatures yields more than 2048
- * key points per image (every shipped YAML asks for <= 2000; the 2 * nFeatures monocular initialisation extractor never meets boxes:
- * Frame.cc:406-461 takes none) makes this call return SD_ERR_UNSUPPORTED; sd_batch_separate flags a box with more than 2048 key points on
- * either side as SD_ERR_CAPACITY at the next synchronisation.  Nothing is ever truncated silently. */
+ * BOUND (this library's, the reference has none -- Frame.cc:555-604 works on std::vectors): the dynamic-object kernels keep a frame's key-point masks
+ * in LDS (20 bytes per key-point slot): on a workspace whose extractor yields more than about 6,800 key points per image this call and
+ * sd_batch_separate return SD_ERR_UNSUPPORTED (extraction and matching are not affected).  Rounds 1-3 stopped at 2,048; since round 4 the tables are sized by the workspace and a box's descriptors pass
+ * through LDS in chunks of 2,048 (tests/test_gpu_cull.py: 5,000 features, one box holding 4,600 of them).  Nothing is ever truncated silently. */
 int sd_batch_first_separate(sd_batch* b, int n_frames, const int32_t* slots, const double* boxes, const int32_t* n_boxes,
                             const int32_t* box_idx, void* stream);
 /* Frame::objects / box_idx / box_status and the per-box lists of a slot.  kept_orig[j] = index (before the

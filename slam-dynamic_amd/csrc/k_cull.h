@@ -8,7 +8,10 @@
 #include "k_frame.h"
 
 #define SD_MAXB SD_MAX_BOXES // boxes per frame the device tables hold (64: box masks are one 64-bit word per key point)
-#define SD_BF_TCAP 2048     // train descriptors of one box staged in LDS
+#define SD_BF_TCAP 2048     // train descriptors of one box staged in LDS at a time (larger boxes pass through in chunks)
+// dynamic LDS of the two kernels whose tables are per key point (cap = key-point slots per image)
+static inline size_t sd_separate_lds(int cap) { return (size_t)SD_BF_TCAP * 32 + (size_t)cap * 8 + 64; }       // descriptor chunk + colBest / rowBest
+static inline size_t sd_box_separate_lds(int cap) { return (size_t)cap * 20 + 64; }                               // two 64-bit box masks + a partition code per key point
 
 struct SdFrameBoxes {       // per frame slot, lives in HBM
     int nb;                 // boxes (after firstSeparate: the reference's `objects`)
@@ -56,7 +59,8 @@ __global__ void __launch_bounds__(256) k_box_separate(SdCullPtrs A, const int* _
     extern __shared__ __align__(16) unsigned char smem[];
     typedef unsigned long long bmask;               // bit j = the key point lies in box j (SD_MAXB <= 64)
     bmask* smask = (bmask*)smem;                    // [cap] box mask per keypoint (original order)
-    bmask* dmask = smask + A.cap;                   // [cap] box mask per dynamic keypoint (new order); first the partition codes
+    bmask* dmask = smask + A.cap;                   // [cap] box mask per dynamic keypoint (new order)
+    unsigned* code = (unsigned*)(dmask + A.cap);    // [cap] partition code: static rank, or 0x80000000 | dynamic rank
     __shared__ int s_wsum[4];
     __shared__ bmask s_has;
     __shared__ int s_nb2, s_empty, s_remap[SD_MAXB], s_kept[SD_MAXB], s_cnt[SD_MAXB], s_start[SD_MAXB + 1];
@@ -125,8 +129,8 @@ __global__ void __launch_bounds__(256) k_box_separate(SdCullPtrs A, const int* _
             const int ex = sd_block_scan256(isStatic, s_wsum, tot);
             if (i < N) {
                 const int sBefore = carry + ex;                 // static keypoints before i
-                // destination is final only once N_s is known: remember the static rank (or -(dynamic rank) - 1)
-                dmask[i] = isStatic ? (bmask)(unsigned)sBefore : (bmask)(0x80000000u | (unsigned)(i - sBefore));
+                // destination is final only once N_s is known: remember the static rank (or the dynamic rank, flagged)
+                code[i] = isStatic ? (unsigned)sBefore : (0x80000000u | (unsigned)(i - sBefore));
             }
             carry += tot;
             __syncthreads();
@@ -136,9 +140,10 @@ __global__ void __launch_bounds__(256) k_box_separate(SdCullPtrs A, const int* _
     const int Ns = nStaticTotal, Nd = N - Ns;
     // static keypoints -> staging rows (then back, compacted); dynamic ones -> the frame's dynamic arrays
     for (int i = tid; i < N; i += 256) {
-        const unsigned code = (unsigned)dmask[i];
-        const bool dynk = (code & 0x80000000u) != 0;
-        const int dst = (int)(code & 0x7FFFFFFFu);
+        const unsigned cd = code[i];
+        const bool dynk = (cd & 0x80000000u) != 0;
+        const int dst = (int)(cd & 0x7FFFFFFFu);
+        if (dynk) dmask[dst] = smask[i];                        // the masks of the dynamic keypoints in their new order
         sd_keypoint k = A.kp[base + i];
         if (dynk) k.class_id = i;                               // class_id = original index (Frame.cc:567-570)
         const uint4* ds = (const uint4*)(A.desc + (base + i) * 32);
@@ -157,24 +162,6 @@ __global__ void __launch_bounds__(256) k_box_separate(SdCullPtrs A, const int* _
         }
     }
     __syncthreads();
-    // masks of the dynamic keypoints in their new order (reuse smask after everyone has read it)
-    bmask myMask[8];
-    int myDst[8];
-    {
-        int k = 0;
-        for (int i = tid; i < N && k < 8; i += 256, k++) {
-            const unsigned code = (unsigned)dmask[i];
-            myMask[k] = smask[i];
-            myDst[k] = (code & 0x80000000u) ? (int)(code & 0x7FFFFFFFu) : -1;
-        }
-    }
-    __syncthreads();
-    {
-        int k = 0;
-        for (int i = tid; i < N && k < 8; i += 256, k++)
-            if (myDst[k] >= 0) dmask[myDst[k]] = myMask[k];
-    }
-    if (N > 8 * 256 && tid == 0) atomicOr(A.errFlag, 8);
     // static part back to the frame's arrays: positions >= N_s are free for UpdateFrame's re-admissions
     for (int i = tid; i < Ns; i += 256) {
         A.kp[base + i] = A.kpT[base + i];
@@ -312,9 +299,9 @@ __global__ void k_motion_to_sep(const SdMotionResult* __restrict__ res, float* _
 __global__ void __launch_bounds__(256) k_separate(SdCullPtrs A, SdSepArgs G)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint4* tdesc = (uint4*)smem;                                   // [SD_BF_TCAP][2]
-    unsigned* colBest = (unsigned*)(tdesc + 2 * SD_BF_TCAP);       // [SD_BF_TCAP]
-    unsigned* rowBest = colBest + SD_BF_TCAP;                      // [SD_BF_TCAP] (queries)
+    uint4* tdesc = (uint4*)smem;                                   // [SD_BF_TCAP][2]: one CHUNK of the train descriptors
+    unsigned* colBest = (unsigned*)(tdesc + 2 * SD_BF_TCAP);       // [cap] nearest query of every train descriptor
+    unsigned* rowBest = colBest + A.cap;                           // [cap] nearest train descriptor of every query
     __shared__ int s_wsum[4];
     __shared__ float s_M[9], s_Mi[9];
     __shared__ int s_num0, s_static;
@@ -350,28 +337,34 @@ __global__ void __launch_bounds__(256) k_separate(SdCullPtrs A, SdSepArgs G)
         const int q0 = FC.boxStart[nbx], nq = FC.boxStart[nbx + 1] - q0;
         const int t0 = FR.boxStart[ref], nt = FR.boxStart[ref + 1] - t0;
         if (nq == 0 || nt == 0) continue;
-        if (nq > SD_BF_TCAP || nt > SD_BF_TCAP) { if (tid == 0) atomicOr(A.errFlag, 32); continue; }
+        if (nq > A.cap || nt > A.cap) { if (tid == 0) atomicOr(A.errFlag, 32); continue; }      // cannot happen: a box's lists are subsets of a frame's keypoints
         __syncthreads();
-        for (int j = tid; j < nt; j += 256) {
-            const uint4* d = (const uint4*)(A.descD + (baseR + itemsR[t0 + j]) * 32);
-            tdesc[2 * j] = d[0]; tdesc[2 * j + 1] = d[1];
-            colBest[j] = 0xFFFFFFFFu;
-        }
-        __syncthreads();
-        for (int i = tid; i < nq; i += 256) {
-            const uint4* d = (const uint4*)(A.descD + (baseC + itemsC[q0 + i]) * 32);
-            const uint4 a0 = d[0], a1 = d[1];
-            unsigned best = 0xFFFFFFFFu;
-            int j = tid % nt;                                     // staggered start: lanes hit different trains
-            for (int s = 0; s < nt; s++) {
-                const unsigned dist = (unsigned)sd_hamming256(a0, a1, tdesc[2 * j], tdesc[2 * j + 1]);
-                best = min(best, (dist << 16) | (unsigned)j);
-                atomicMin(&colBest[j], (dist << 16) | (unsigned)i);
-                j++; if (j == nt) j = 0;
+        for (int i = tid; i < nq; i += 256) rowBest[i] = 0xFFFFFFFFu;
+        // the train descriptors pass through LDS in chunks of SD_BF_TCAP (a box of a 2000-feature frame is one chunk); minima of
+        // (distance << 16 | index) are order-free, so "first nearest wins" holds across chunks as it does across lanes
+        for (int c0 = 0; c0 < nt; c0 += SD_BF_TCAP) {
+            const int nc = min(SD_BF_TCAP, nt - c0);
+            for (int j = tid; j < nc; j += 256) {
+                const uint4* d = (const uint4*)(A.descD + (baseR + itemsR[t0 + c0 + j]) * 32);
+                tdesc[2 * j] = d[0]; tdesc[2 * j + 1] = d[1];
+                colBest[c0 + j] = 0xFFFFFFFFu;
             }
-            rowBest[i] = best;
+            __syncthreads();
+            for (int i = tid; i < nq; i += 256) {
+                const uint4* d = (const uint4*)(A.descD + (baseC + itemsC[q0 + i]) * 32);
+                const uint4 a0 = d[0], a1 = d[1];
+                unsigned best = rowBest[i];
+                int j = tid % nc;                                 // staggered start: lanes hit different trains
+                for (int s = 0; s < nc; s++) {
+                    const unsigned dist = (unsigned)sd_hamming256(a0, a1, tdesc[2 * j], tdesc[2 * j + 1]);
+                    best = min(best, (dist << 16) | (unsigned)(c0 + j));
+                    atomicMin(&colBest[c0 + j], (dist << 16) | (unsigned)i);
+                    j++; if (j == nc) j = 0;
+                }
+                rowBest[i] = best;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         // cross-check + ordered compaction by query index
         int carry = 0;
         for (int i0 = 0; i0 < nq; i0 += 256) {

@@ -70,6 +70,7 @@ struct sd_batch {
     uint8_t* d_desc = nullptr;
     int* d_count = nullptr;
     int* d_err = nullptr;
+    bool cullOk = true;              // the per-key-point LDS tables of k_box_separate / k_separate fit this workspace's capacity
     float* d_uright = nullptr;
     float* d_depth = nullptr;
     int* d_sad = nullptr;
@@ -377,7 +378,15 @@ static int batch_create_impl(sd_batch** out, sd_extractor* ex, int width, int he
     if (e == hipSuccess) e = hipMemcpy(b->d_tabs, P.tabs.data(), sizeof(int16_t) * P.tabs.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(b->d_err, 0, 4);
     if (e == hipSuccess) e = hipMemset(b->d_fb, 0, nI * sizeof(SdFrameBoxes));
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_separate, hipFuncAttributeMaxDynamicSharedMemorySize, SD_BF_TCAP * 40 + 64);
+    // the dynamic-object kernels keep per-key-point tables in LDS: sized by this workspace's capacity, the limit only ever raised (workspaces of
+    // different capacities share the kernels: a monocular tracker's 2 x nFeatures initialisation workspace beside the regular one)
+    {
+        static int ldsSeparate = 0, ldsBoxSeparate = 0;
+        const int needSep = (int)sd_separate_lds(P.kpCap), needBox = (int)sd_box_separate_lds(P.kpCap);
+        b->cullOk = needSep <= 160 * 1024 && needBox <= 160 * 1024;       // otherwise sd_batch_first_separate / sd_batch_separate refuse (extraction and matching are not affected)
+        if (b->cullOk && e == hipSuccess && needSep > ldsSeparate) { e = hipFuncSetAttribute((const void*)k_separate, hipFuncAttributeMaxDynamicSharedMemorySize, needSep); ldsSeparate = needSep; }
+        if (b->cullOk && e == hipSuccess && needBox > ldsBoxSeparate && needBox > 64 * 1024) { e = hipFuncSetAttribute((const void*)k_box_separate, hipFuncAttributeMaxDynamicSharedMemorySize, needBox); ldsBoxSeparate = needBox; }
+    }
     if (e == hipSuccess) e = hipMemset(b->d_count, 0, nI * 4);
     if (e == hipSuccess) e = hipMemset(b->d_lvlCount, 0, nI * P.nlevels * 4);
     if (e == hipSuccess && lds > 64 * 1024)
@@ -1740,7 +1749,7 @@ int sd_batch_first_separate(sd_batch* b, int n_frames, const int32_t* slots, con
 {
     if (!b || n_frames < 0 || n_frames > b->maxImages || (n_frames > 0 && (!slots || !boxes || !n_boxes || !box_idx)))
         return set_err(SD_ERR_INVALID, "bad first_separate arguments");
-    if (b->plan.kpMax > 2048) return set_err(SD_ERR_UNSUPPORTED, "box separation supports up to 2048 keypoints per image");
+    if (!b->cullOk) return set_err(SD_ERR_UNSUPPORTED, "more key points per image than the dynamic-object kernels' LDS tables hold (about 6,800)");
     hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
     b->lastStream = s;
     if (n_frames == 0) return SD_OK;
@@ -1761,8 +1770,7 @@ int sd_batch_first_separate(sd_batch* b, int n_frames, const int32_t* slots, con
     HIPCHK(hipMemcpyAsync(b->d_slots, slots, (size_t)n_frames * 4, hipMemcpyHostToDevice, s));
     {
         ProfScope ps(b, s, K_BOXSEP);
-        const size_t lds = (size_t)b->plan.kpCap * 16 + 64;      // two 64-bit box masks per key point
-        hipLaunchKernelGGL(k_box_separate, dim3(n_frames), dim3(256), lds, s, cull_ptrs(b), b->d_slots, b->d_fbStage);
+        hipLaunchKernelGGL(k_box_separate, dim3(n_frames), dim3(256), sd_box_separate_lds(b->plan.kpCap), s, cull_ptrs(b), b->d_slots, b->d_fbStage);
     }
     LAUNCH_CHECK("k_box_separate");
     return SD_OK;
@@ -1840,6 +1848,7 @@ static int separate_impl(sd_batch* b, int n_pairs, const int32_t* cur_index, con
     if (!b || n_pairs < 0 || n_pairs > b->maxImages ||
         (n_pairs > 0 && (!cur_index || !ref_index || (!HorF) != (!flag) || (!last_slot && (!last_box_idx || !last_box_status || !n_last)))))
         return set_err(SD_ERR_INVALID, "bad separate arguments");
+    if (!b->cullOk) return set_err(SD_ERR_UNSUPPORTED, "more key points per image than the dynamic-object kernels' LDS tables hold (about 6,800)");
     const bool fromMotion = n_pairs > 0 && !HorF;          // HorF == flag == NULL: pair p uses the model fit of pair p
     if (fromMotion && b->nMotion < n_pairs) return set_err(SD_ERR_STATE, "separate: no sd_batch_estimate_motion results for these pairs");
     hipStream_t s = stream_ ? (hipStream_t)stream_ : b->lastStream;
@@ -1876,7 +1885,7 @@ static int separate_impl(sd_batch* b, int n_pairs, const int32_t* cur_index, con
     b->sepActive = d_active;
     {
         ProfScope ps(b, s, K_SEPARATE);
-        hipLaunchKernelGGL(k_separate, dim3(n_pairs), dim3(256), (size_t)SD_BF_TCAP * 40 + 64, s, cull_ptrs(b), G);
+        hipLaunchKernelGGL(k_separate, dim3(n_pairs), dim3(256), sd_separate_lds(b->plan.kpCap), s, cull_ptrs(b), G);
     }
     LAUNCH_CHECK("k_separate");
     b->nSepPairs = n_pairs;

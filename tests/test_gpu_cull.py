@@ -19,10 +19,17 @@ def _boxes(synth, cfg, seq, t, extra):
     return np.concatenate([rects, extra]) if len(extra) else rects
 
 
-@pytest.fixture(scope="module")
-def scene(gpu, fe, orc, synth):
+@pytest.fixture(scope="module", params=[0, 5000], ids=["settings", "5000-features-one-box-over-2048"])
+def scene(request, gpu, fe, orc, synth):
+    """params: 0 = the settings file's nFeatures (2000); 5000 = an extractor that yields more than 2048 key points per image AND a box that holds more
+    than 2048 of them in both frames -- the reference has no bound here (Frame.cc:555-604 and Tracking.cc:1093-1239 work on std::vectors); rounds 1-3
+    refused it (SD_ERR_UNSUPPORTED), since round 4 the key-point tables of k_box_separate / k_separate are sized by the workspace and a box's train
+    descriptors pass through LDS in chunks."""
     import torch
-    cfg = synth.KITTI03_RGBD
+    cfg = dict(synth.KITTI03_RGBD)
+    big = request.param > 0
+    if big:
+        cfg["n_features"] = request.param
     ts = [0, 3]
     fr = _frames(synth, orc, cfg, 8, ts)
     ex = fe.ORBextractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
@@ -38,7 +45,7 @@ def scene(gpu, fe, orc, synth):
         base = _boxes(synth, cfg, 8, t, np.zeros((0, 4)))
         empty = np.array([[0.25, 0.25, 1.5, 1.5]])
         overlap = base[0:1] + np.array([[20., 10., 0., 0.]])
-        boxes = np.concatenate([base[:1], empty, base[1:], overlap])
+        boxes = np.concatenate([base[:1], empty, base[1:], overlap] + ([np.array([[60., 30., 1100., 320.]])] if big else []))
         idx = np.arange(len(boxes), dtype=np.int32) + 10
         per_frame.append((boxes, idx))
     # oracle side
@@ -51,6 +58,9 @@ def scene(gpu, fe, orc, synth):
         r["ur"] = ur[r["perm"]]; r["dep"] = dep[r["perm"]]
         ref.append(r)
     b.first_separate([0, 1], [p[0] for p in per_frame], [p[1] for p in per_frame])
+    if big:
+        for r in ref:
+            assert r["Ns"] + r["Nd"] > 2048 and np.diff(r["boxStart"]).max() > 2048, "the big case must put more than 2048 key points into one box (%d, %d)" % (r["Ns"] + r["Nd"], np.diff(r["boxStart"]).max())
     yield dict(b=b, cfg=cfg, ref=ref, ts=ts)
     b.close()
 
