@@ -771,6 +771,23 @@ def exchange_rows(dist, world, send, send_splits, recv_splits):
     return out, None
 
 
+def cu_partition_streams(torch, dev, k):
+    """(stream on the first k compute units only, stream on all the others): hipExtStreamCreateWithCUMask through ctypes, wrapped for torch."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    words = (n_cu + 31) // 32
+
+    def make(bits):
+        mask = (C.c_uint32 * words)(*[sum(1 << (i - 32 * w) for i in bits if 32 * w <= i < 32 * w + 32) for w in range(words)])
+        h = C.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(C.byref(h), C.c_uint32(words), mask)
+        if rc != 0:
+            raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
+        return torch.cuda.ExternalStream(h.value, device=dev)
+    return make(range(k)), make(range(k, n_cu))
+
+
 class SequenceBatchWorkload:
     """BASELINE configs[4] ("kitti-batch"): 11 KITTI stereo sequences x T frames with the f32 detector in the loop, FRAMES sharded over the
     ranks (frame_shard_plan).  A sequence cannot be cut into independently processed chunks -- Frame::boxTrack's ids (`max + 1`,
@@ -811,10 +828,19 @@ class SequenceBatchWorkload:
         self.R = self.trk.record_bytes()
         assert self.R == self.worker.record_bytes() and self.R % 16 == 0
         self.RB = self.R + self.BOX_BYTES
-        self.main = torch.cuda.current_stream()
+        # The recurrence is ~20 small dependent launches per frame beside a detector that keeps every CU slot occupied: each launch waits for a slot.  On a
+        # high-priority stream the slots that convolution workgroups free (one every few microseconds somewhere on the chip) go to it first.
+        prio = int(os.environ.get("SD_BENCH_RECURRENCE_PRIORITY", "-1"))
+        self.main = torch.cuda.Stream(device=dev, priority=prio)
         self.pre_stream = torch.cuda.Stream(device=dev)
         self.det_stream = torch.cuda.Stream(device=dev)
         self.xchg_stream = torch.cuda.Stream(device=dev)
+        # CU partition (experiment, SD_BENCH_CU_PARTITION=K): the recurrence's ~20 tiny kernels per frame share their CUs with convolution waves and
+        # run 5-10 x longer than alone; with few lanes per rank (8 ranks: one or two sequences each) the recurrence, not the detector, then bounds the
+        # job.  K CUs are taken out of the detector's stream (hipExtStreamCreateWithCUMask) and given to the recurrence's alone.
+        self.cu_reserved = int(os.environ.get("SD_BENCH_CU_PARTITION", "0"))
+        if self.cu_reserved > 0:
+            self.main, self.det_stream = cu_partition_streams(torch, dev, self.cu_reserved)
         self.det = None
         self.max_det_boxes = 0
         M = fe.MAXB
