@@ -771,23 +771,6 @@ def exchange_rows(dist, world, send, send_splits, recv_splits):
     return out, None
 
 
-def cu_partition_streams(torch, dev, k):
-    """(stream on the first k compute units only, stream on all the others): hipExtStreamCreateWithCUMask through ctypes, wrapped for torch."""
-    import ctypes as C
-    hip = C.CDLL("libamdhip64.so")
-    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-    words = (n_cu + 31) // 32
-
-    def make(bits):
-        mask = (C.c_uint32 * words)(*[sum(1 << (i - 32 * w) for i in bits if 32 * w <= i < 32 * w + 32) for w in range(words)])
-        h = C.c_void_p()
-        rc = hip.hipExtStreamCreateWithCUMask(C.byref(h), C.c_uint32(words), mask)
-        if rc != 0:
-            raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
-        return torch.cuda.ExternalStream(h.value, device=dev)
-    return make(range(k)), make(range(k, n_cu))
-
-
 class SequenceBatchWorkload:
     """BASELINE configs[4] ("kitti-batch"): 11 KITTI stereo sequences x T frames with the f32 detector in the loop, FRAMES sharded over the
     ranks (frame_shard_plan).  A sequence cannot be cut into independently processed chunks -- Frame::boxTrack's ids (`max + 1`,
@@ -835,12 +818,16 @@ class SequenceBatchWorkload:
         self.pre_stream = torch.cuda.Stream(device=dev)
         self.det_stream = torch.cuda.Stream(device=dev)
         self.xchg_stream = torch.cuda.Stream(device=dev)
-        # CU partition (experiment, SD_BENCH_CU_PARTITION=K): the recurrence's ~20 tiny kernels per frame share their CUs with convolution waves and
-        # run 5-10 x longer than alone; with few lanes per rank (8 ranks: one or two sequences each) the recurrence, not the detector, then bounds the
-        # job.  K CUs are taken out of the detector's stream (hipExtStreamCreateWithCUMask) and given to the recurrence's alone.
-        self.cu_reserved = int(os.environ.get("SD_BENCH_CU_PARTITION", "0"))
-        if self.cu_reserved > 0:
-            self.main, self.det_stream = cu_partition_streams(torch, dev, self.cu_reserved)
+        # (Measured with two sequences on the rank -- what a rank of an 8-GPU job owns: the recurrence then costs ~2.4 ms per frame step against the
+        # detector's 1.85 and bounds the job, 820 frames/s against 1,030 with eleven.  Stream priority -1 / 0: 825 / 817.  A CU partition --
+        # hipExtStreamCreateWithCUMask: K CUs for the recurrence alone, the rest for the detector -- 647 / 653 / 650 for K = 8 / 16 / 32: worse, the
+        # recurrence also holds wide kernels (grid sort, projection search, the 18-array frame copy) that want the whole chip.)
+        ea = getattr(args, "kitti_enqueue_at", -1.0)
+        if ea is None or ea < 0:
+            # auto: the detector's share of a frame step (units per frame of this rank x ~0.93 ms in f32) against the stretched recurrence's ~2.4 ms
+            det_ms = (self.plan["n_seq"] / float(world)) * 0.93
+            ea = min(0.6, max(0.0, 1.0 - det_ms / 2.4))
+        self.enqueue_at = float(ea)
         self.det = None
         self.max_det_boxes = 0
         M = fe.MAXB
@@ -969,11 +956,19 @@ class SequenceBatchWorkload:
         res = None
         self.enqueue(0)
         for bi in range(nb):
-            if bi + 1 < nb:
-                self.enqueue(bi + 1)
             B = self.blocks[bi]
+            # When block b + 1's detector pass goes out: before block b's recurrence (enqueue_at = 0: the pass runs beside all of it) or after a
+            # fraction of its frames.  The recurrence is ~20 tiny dependent kernels per frame: beside the detector each of them shares its CU with
+            # convolution waves and a frame step takes ~2.4 ms instead of ~0.4.  With many lanes per rank that hides behind the pass (11 sequences:
+            # 10 ms of detector per frame step); with one or two sequences per rank (8 ranks) the detector's share is 1.3 - 1.9 ms per frame step and
+            # the stretched recurrence bounds the job -- so part of the recurrence runs alone first.
+            k_enq = min(B["n"], int(round(self.enqueue_at * B["n"])))
+            if bi + 1 < nb and k_enq == 0:
+                self.enqueue(bi + 1)
             bx_all, nb_all = self.consume_begin(bi)
             for k in range(B["n"]):
+                if bi + 1 < nb and k == k_enq and k_enq > 0:
+                    self.enqueue(bi + 1)
                 t = B["t0"] + k
                 res = self.trk.track(0, W * 3, W * H * 3, np.full(S, t / float(self.cfg["fps"]), np.float64), boxes=bx_all[k * S:(k + 1) * S],
                                      n_boxes=nb_all[k * S:(k + 1) * S], stream=self.main.cuda_stream)
@@ -981,6 +976,8 @@ class SequenceBatchWorkload:
                     on_frame(t, res)
                 if after_step is not None:
                     after_step()
+            if bi + 1 < nb and k_enq >= B["n"]:
+                self.enqueue(bi + 1)
         return res
 
     def close(self):
@@ -1023,6 +1020,7 @@ def run_sequence_batch(args, rank, world, dev, pkg, dist, detector=True):
         out = {"workload": "kitti-batch", "value": round(frames / elapsed, 2), "ms_per_step": round(elapsed / wl.T * 1e3, 4), "steps": wl.T, "frames": frames,
                "timed_s": round(elapsed, 3), "lanes_per_gpu": wl.S, "images_per_frame": 2, "frames_per_block_per_lane": wl.D, "blocks": len(wl.blocks),
                "frames_in_one_extraction_batch": wl.U_max, "distinct_frames_generated_per_sequence": wl.P, "record_bytes_per_frame": wl.RB,
+               "enqueue_at": round(wl.enqueue_at, 3),
                "max_detector_boxes_in_a_frame": wl.max_det_boxes if wl.det is not None else None,
                "lane0_last_frame": {"N": R.N, "N_s": R.N_s, "N_d": R.N_d, "n_boxes": R.n_boxes, "track_flag": R.track_flag, "separate_ret": R.separate_ret,
                                     "n_track_matches": R.n_track_matches, "n_last_matches": R.n_last_matches}}
@@ -1273,6 +1271,8 @@ def main():
     ap.add_argument("--kitti-sequences", type=int, default=11, help="kitti-batch: sequences of the job (BASELINE configs[4]: KITTI 00-10 = 11)")
     ap.add_argument("--block-frames", type=int, default=128, help="kitti-batch: frames per rank whose detector pass / extraction / stereo matching form one batch "
                     "(a time block = ceil(block_frames * ranks / sequences) consecutive frames of every sequence, its frames dealt evenly to the ranks)")
+    ap.add_argument("--kitti-enqueue-at", type=float, default=-1.0, help="kitti-batch: fraction of a block's recurrence that runs before the next block's detector pass is enqueued "
+                    "(0 = the pass runs beside all of it; -1 = auto from the sequences per rank)")
     ap.add_argument("--kitti-no-detector", action="store_true", help="kitti-batch with the 3 given boxes per frame instead of the detector")
     ap.add_argument("--det-split", type=int, default=1, help="sub-batches the detector processes a step's images in, each on its own stream "
                     "(measured on MI355X: 1 -> 995.5, 2 -> 995.1, 4 -> 989.7 frames/s: the convolutions' drain phases are not worth filling)")
