@@ -821,7 +821,9 @@ class SequenceBatchWorkload:
         # (Measured with two sequences on the rank -- what a rank of an 8-GPU job owns: the recurrence then costs ~2.4 ms per frame step against the
         # detector's 1.85 and bounds the job, 820 frames/s against 1,030 with eleven.  Stream priority -1 / 0: 825 / 817.  A CU partition --
         # hipExtStreamCreateWithCUMask: K CUs for the recurrence alone, the rest for the detector -- 647 / 653 / 650 for K = 8 / 16 / 32: worse, the
-        # recurrence also holds wide kernels (grid sort, projection search, the 18-array frame copy) that want the whole chip.)
+        # recurrence also holds wide kernels (grid sort, projection search, the 18-array frame copy) that want the whole chip.  Enqueueing the next
+        # block's pass only after a fraction f of the block's recurrence: 822 / 816 / 805 / 718 for f = 0 / 0.25 / 0.5 / 1 -- alone the recurrence still
+        # takes 0.94 ms per frame step (host + ~20 launches + one synchronisation), so running it alone buys nothing.)
         ea = getattr(args, "kitti_enqueue_at", -1.0)
         if ea is None or ea < 0:
             # auto: the detector's share of a frame step (units per frame of this rank x ~0.93 ms in f32) against the stretched recurrence's ~2.4 ms
