@@ -824,12 +824,6 @@ class SequenceBatchWorkload:
         # recurrence also holds wide kernels (grid sort, projection search, the 18-array frame copy) that want the whole chip.  Enqueueing the next
         # block's pass only after a fraction f of the block's recurrence: 822 / 816 / 805 / 718 for f = 0 / 0.25 / 0.5 / 1 -- alone the recurrence still
         # takes 0.94 ms per frame step (host + ~20 launches + one synchronisation), so running it alone buys nothing.)
-        ea = getattr(args, "kitti_enqueue_at", -1.0)
-        if ea is None or ea < 0:
-            # auto: the detector's share of a frame step (units per frame of this rank x ~0.93 ms in f32) against the stretched recurrence's ~2.4 ms
-            det_ms = (self.plan["n_seq"] / float(world)) * 0.93
-            ea = min(0.6, max(0.0, 1.0 - det_ms / 2.4))
-        self.enqueue_at = float(ea)
         self.det = None
         self.max_det_boxes = 0
         M = fe.MAXB
@@ -959,18 +953,10 @@ class SequenceBatchWorkload:
         self.enqueue(0)
         for bi in range(nb):
             B = self.blocks[bi]
-            # When block b + 1's detector pass goes out: before block b's recurrence (enqueue_at = 0: the pass runs beside all of it) or after a
-            # fraction of its frames.  The recurrence is ~20 tiny dependent kernels per frame: beside the detector each of them shares its CU with
-            # convolution waves and a frame step takes ~2.4 ms instead of ~0.4.  With many lanes per rank that hides behind the pass (11 sequences:
-            # 10 ms of detector per frame step); with one or two sequences per rank (8 ranks) the detector's share is 1.3 - 1.9 ms per frame step and
-            # the stretched recurrence bounds the job -- so part of the recurrence runs alone first.
-            k_enq = min(B["n"], int(round(self.enqueue_at * B["n"])))
-            if bi + 1 < nb and k_enq == 0:
+            if bi + 1 < nb:
                 self.enqueue(bi + 1)
             bx_all, nb_all = self.consume_begin(bi)
             for k in range(B["n"]):
-                if bi + 1 < nb and k == k_enq and k_enq > 0:
-                    self.enqueue(bi + 1)
                 t = B["t0"] + k
                 res = self.trk.track(0, W * 3, W * H * 3, np.full(S, t / float(self.cfg["fps"]), np.float64), boxes=bx_all[k * S:(k + 1) * S],
                                      n_boxes=nb_all[k * S:(k + 1) * S], stream=self.main.cuda_stream)
@@ -978,8 +964,6 @@ class SequenceBatchWorkload:
                     on_frame(t, res)
                 if after_step is not None:
                     after_step()
-            if bi + 1 < nb and k_enq >= B["n"]:
-                self.enqueue(bi + 1)
         return res
 
     def close(self):
@@ -1022,7 +1006,7 @@ def run_sequence_batch(args, rank, world, dev, pkg, dist, detector=True):
         out = {"workload": "kitti-batch", "value": round(frames / elapsed, 2), "ms_per_step": round(elapsed / wl.T * 1e3, 4), "steps": wl.T, "frames": frames,
                "timed_s": round(elapsed, 3), "lanes_per_gpu": wl.S, "images_per_frame": 2, "frames_per_block_per_lane": wl.D, "blocks": len(wl.blocks),
                "frames_in_one_extraction_batch": wl.U_max, "distinct_frames_generated_per_sequence": wl.P, "record_bytes_per_frame": wl.RB,
-               "enqueue_at": round(wl.enqueue_at, 3),
+
                "max_detector_boxes_in_a_frame": wl.max_det_boxes if wl.det is not None else None,
                "lane0_last_frame": {"N": R.N, "N_s": R.N_s, "N_d": R.N_d, "n_boxes": R.n_boxes, "track_flag": R.track_flag, "separate_ret": R.separate_ret,
                                     "n_track_matches": R.n_track_matches, "n_last_matches": R.n_last_matches}}
@@ -1273,8 +1257,6 @@ def main():
     ap.add_argument("--kitti-sequences", type=int, default=11, help="kitti-batch: sequences of the job (BASELINE configs[4]: KITTI 00-10 = 11)")
     ap.add_argument("--block-frames", type=int, default=128, help="kitti-batch: frames per rank whose detector pass / extraction / stereo matching form one batch "
                     "(a time block = ceil(block_frames * ranks / sequences) consecutive frames of every sequence, its frames dealt evenly to the ranks)")
-    ap.add_argument("--kitti-enqueue-at", type=float, default=-1.0, help="kitti-batch: fraction of a block's recurrence that runs before the next block's detector pass is enqueued "
-                    "(0 = the pass runs beside all of it; -1 = auto from the sequences per rank)")
     ap.add_argument("--kitti-no-detector", action="store_true", help="kitti-batch with the 3 given boxes per frame instead of the detector")
     ap.add_argument("--det-split", type=int, default=1, help="sub-batches the detector processes a step's images in, each on its own stream "
                     "(measured on MI355X: 1 -> 995.5, 2 -> 995.1, 4 -> 989.7 frames/s: the convolutions' drain phases are not worth filling)")
