@@ -508,9 +508,15 @@ class Workload:
         self.idle = False
         self.distinct = min(args.distinct, self.S)
         self.ex = fe.ORBextractor(cfg["n_features"], cfg["scale_factor"], cfg["n_levels"], cfg["ini_th_fast"], cfg["min_th_fast"])
-        self.trk = fe.Tracker(self.ex, cfg, self.sensor, self.S, channels=3, rgb_order=True, track_last=True)
+        # Detector-less workloads pipeline the steps through the library's time-batched mode with a look-ahead of ONE frame: the history-free half of frame
+        # t + 1 (sd_tracker_prefetch) is enqueued before frame t's call synchronises, so the GPU never waits for the host's turn-around between steps
+        # (~0.1 ms of a 4.1 ms step).  Results are those of plain calls (tests/test_gpu_pipeline.py::test_time_batched_prefetch_equals_sequential).
+        self.pipelined = not self.detector and os.environ.get("SD_BENCH_PIPELINE", "1") != "0"
+        self.trk = fe.Tracker(self.ex, cfg, self.sensor, self.S, channels=3, rgb_order=True, track_last=True, lookahead=1 if self.pipelined else 0)
         self.batch = self.trk.batch
         self.main = torch.cuda.current_stream()
+        self.prefetched = -1              # last time step whose history-free half has been enqueued
+        self.prefetch_limit = None        # drain: no history-free half beyond this step is enqueued any more
         self.det = None
         if self.detector:
             # --det-split n: the frame's images go through the detector as n independent sub-batches on their own streams (one
@@ -623,9 +629,18 @@ class Workload:
             boxes = self.det_host[k]["b"].numpy().copy()
             if self.lookahead and self.det_enqueued < min(self.t + self.depth, last):     # one more pass goes out behind the ones in flight
                 self.enqueue_detector(self.det_enqueued + 1)
-        res = self.trk.track(fr["images"].data_ptr(), W * 3, W * H * 3, fr["stamps"], boxes=boxes, n_boxes=n_boxes,
-                             d_depth=fr["depth"].data_ptr() if fr["depth"] is not None else 0, depth_stride=W, depth_pitch=W * H,
-                             stream=self.main.cuda_stream)
+        if self.pipelined:
+            for tt in (self.t, self.t + 1):
+                if tt > self.prefetched and tt < (self.n_total if self.prefetch_limit is None else self.prefetch_limit):
+                    f2 = self.frame_at(tt)
+                    self.trk.prefetch(f2["images"].data_ptr(), W * 3, W * H * 3, 1, d_depth=f2["depth"].data_ptr() if f2["depth"] is not None else 0,
+                                      depth_stride=W, depth_pitch=W * H, stream=self.main.cuda_stream)
+                    self.prefetched = tt
+            res = self.trk.track(0, W * 3, W * H * 3, fr["stamps"], boxes=boxes, n_boxes=n_boxes, stream=self.main.cuda_stream)
+        else:
+            res = self.trk.track(fr["images"].data_ptr(), W * 3, W * H * 3, fr["stamps"], boxes=boxes, n_boxes=n_boxes,
+                                 d_depth=fr["depth"].data_ptr() if fr["depth"] is not None else 0, depth_stride=W, depth_pitch=W * H,
+                                 stream=self.main.cuda_stream)
         if self.bow:
             # Frame::ComputeBoW of mCurrentFrame and of the queued frame two steps (0.2 s at 10 fps) back -- its ring slot is still
             # q_frame's oldest entry after this step --, then SearchByBoW(that frame as the key frame, mCurrentFrame)
@@ -1059,7 +1074,7 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline, vocab=None):
     prof_steps = 4 if (not args.no_profile and (headline or name in ("stereo", "rgbd-bow", "stereo-yolo-f32w", "stereo-yolo-f32x3"))) else 0
     # every timed step enqueues ONE detector pass `depth` frames ahead: the run needs that many frames beyond the last timed / profiled step, or the
     # last timed steps would find nothing left to enqueue and the timed region would hold fewer passes than steps
-    wl.prepare(1 + warm + steps + prof_steps + max(1, getattr(wl, "depth", 1)))
+    wl.prepare(1 + warm + steps + prof_steps + max(1, getattr(wl, "depth", 1)) + (2 if getattr(wl, "pipelined", False) else 0))
     batch = wl.batch
     cap = batch.cap
     gatherer, rec_parts, layout = make_gatherer(wl, fe, dist, world, rank, dev)
@@ -1105,6 +1120,11 @@ def run_workload(name, args, rank, world, dev, pkg, dist, headline, vocab=None):
                                             "bytes_per_frame": layout["_stride"], "finite_depths": int(np.isfinite(d["depth"]).sum())}
     # ---- separate, untimed pass: per-kernel durations (hipEvents on the kernels' own stream) for the roofline
     if prof_steps:
+        if getattr(wl, "pipelined", False):      # the per-kernel pass times plain steps (the library's kernel timers belong to the tracker's own workspace)
+            wl.prefetch_limit = wl.prefetched + 1
+            while wl.t <= wl.prefetched:
+                wl.step()
+            wl.pipelined = False
         batch.set_profiling(True); batch.reset_kernel_times()
         det_ms = None
         if wl.det is not None:                 # the detector alone, nothing else on the GPU: the MFMA block

@@ -90,3 +90,36 @@ def test_kitti_batch_frames_sharded_over_two_ranks(gpu):
     assert len(ok) == 1 or len(ok) == 2, ok          # rank 0's line is always passed through
     ok = _run_ranks(["--gpus", "2", "--sequences", "3", "--frames", "5", "--block-frames", "4"])
     assert ok, ok
+
+
+@pytest.mark.parametrize("name", ["stereo", "rgbd-cull"])
+def test_pipelined_detectorless_workloads_as_benched(gpu, fe, orc, synth, pkg, name):
+    """bench.Workload for the detector-less workloads as bench.py steps them since round 4: the history-free half of frame t + 1 (sd_tracker_prefetch,
+    look-ahead 1) is enqueued before frame t's call synchronises.  Two lanes x 6 frames of `stereo` (colour pairs, no boxes) and `rgbd-cull` (colour +
+    depth, three given boxes per frame: the cull runs on the prefetched frames): every lane of every frame equals the sequential frame-level oracle."""
+    import torch
+    sys.path.insert(0, graft.ROOT)
+    import bench
+    from test_gpu_pipeline import _check_frame, _pipe
+    P = _pipe()
+    S, T = 2, 6
+    args = argparse.Namespace(lanes=S, distinct=S, det_split=1, kitti_frames=256)
+    wl = bench.Workload(name, args, 0, 1, torch.device("cuda", 0), pkg, None)
+    cfg = wl.cfg
+    sensor = P.SENSOR_STEREO if wl.kind == "stereo" else P.SENSOR_RGBD
+    oracles = [P.SequenceOracle(orc, cfg, sensor, rgb_order=True, track_last=True) for _ in range(S)]
+    flags = 0
+    try:
+        assert wl.pipelined and wl.det is None
+        wl.prepare(T)
+        for t in range(T):
+            res = wl.step()
+            for l in range(S):
+                fr = bench.synth_timestep(synth, wl.kind, cfg, 10 + l, t)
+                second = fr["images"][1] if wl.kind == "stereo" else fr["depth"]
+                F = oracles[l].track(fr["images"][0], second, fr["boxes"] if wl.with_boxes else None, fr["stamp"])
+                _check_frame(fe, wl.trk, l, res[l], F, "%s frame %d lane %d" % (name, t, l))
+                flags += F.track_flag != 0
+    finally:
+        wl.close()
+    assert name == "stereo" or flags >= 2, "TrackHomo must have run on the later frames of the cull workload"
